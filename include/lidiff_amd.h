@@ -1,0 +1,138 @@
+/*
+ * lidiff_amd.h -- C ABI of the MI355X-native sparse-tensor operator library behind LiDiff.
+ *
+ * The reference has no FFI of its own: `import MinkowskiEngine as ME` IS its operator
+ * interface (lidiff/models/minkunet.py:6, models.py:6, models_refine.py:6,
+ * tools/diff_completion_pipeline.py:2).  Every entry point below replaces the native
+ * kernel(s) that one of those Python call sites lands in; the call site is cited per
+ * function (paths relative to /root/reference/lidiff).  The Python shim
+ * lidiff_amd/MinkowskiEngine re-creates the ME symbols on top of this ABI.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises, nothing allocates: outputs and workspaces are caller-allocated;
+ *   - coordinates are int32 rows (b, x, y, z); every column must lie in [-32768, 32767]
+ *     (64-bit packed hash key, 16 bits per column); violations set bit 0 of *d_status;
+ *   - return value 0 = enqueued; != 0 = rejected on the host (bad argument / launch error),
+ *     text available from lidiff_last_error() (thread-local);
+ *   - row-major, fp32 features, int32 row indices, int64 only where torch indexing wants it.
+ */
+#ifndef LIDIFF_AMD_H
+#define LIDIFF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIDIFF_ABI_VERSION 1
+#define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
+#define LIDIFF_STATUS_HASH_FULL 2   /* *d_status bit: hash table too small (cap < 2*rows)     */
+
+int lidiff_abi_version(void);
+const char* lidiff_last_error(void);
+
+/* Capacity (slots, power of two >= 2*n_rows, >= 1024) of the open-addressing table that
+ * lidiff_vox_unique / lidiff_map_stride fill.  Host-only helper. */
+int64_t lidiff_hash_capacity(int64_t n_rows);
+
+/* Bytes of scratch lidiff_vox_unique / lidiff_map_stride need for n_rows. Host-only. */
+int64_t lidiff_unique_workspace_bytes(int64_t n_rows);
+
+/* TensorField.sparse(), coordinate part -- pipeline:149, models.py:99,202,
+ * minkunet.py:135,597 (ME: floor -> CoordinateMapManager::insert_field + hash map).
+ * coords_f [n,4] float (integral after LiDiff's round, pipeline:72) -> floor -> int32. */
+int lidiff_coords_floor(const float* coords_f, int64_t n_rows, int32_t* coords_i, void* stream);
+
+/* Voxel hashing: unique rows of coords[n,4] in FIRST-OCCURRENCE order.
+ *   hkeys[cap] / hvals[cap]: the coordinate map's hash table (filled here; hvals = row id);
+ *   uniq[n,4] (first *d_m rows valid), first_idx[n] (point index of each voxel's first
+ *   member), inverse[n] (point -> voxel row, int64 as torch indexing wants), *d_m = #voxels.
+ * Replaces ME's concurrent hash-map insert + unique_index/inverse_mapping. */
+int lidiff_vox_unique(const int32_t* coords, int64_t n_rows,
+                      uint64_t* hkeys, int32_t* hvals, int64_t cap,
+                      int32_t* uniq, int32_t* first_idx, int64_t* inverse,
+                      int32_t* d_m, int32_t* d_status, void* workspace, void* stream);
+
+/* UNWEIGHTED_AVERAGE quantisation -- pipeline:77, models.py:171 (ME:
+ * MinkowskiSPMMAverageFunction): out[v] = mean of feats[i] over inverse[i]==v.
+ * counts[m] (float) is an output too (kept for the backward). */
+int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, int32_t c,
+                    int64_t m, float* out, float* counts, void* stream);
+/* backward of the above: grad_feats[i] = grad_out[inverse[i]] / counts[inverse[i]] */
+int lidiff_vox_mean_bwd(const float* grad_out, const int64_t* inverse, const float* counts,
+                        int64_t n_rows, int32_t c, float* grad_feats, void* stream);
+
+/* Strided coordinate map -- BasicConvolutionBlock(ks=2,stride=2) minkunet.py:13-29 (ME:
+ * CoordinateMapManager::stride): coarse = floor(c / s_out) * s_out on columns 1..3,
+ * deduplicated in first-occurrence order over the fine rows.
+ *   coarse[n,4] (first *d_m valid), parent[n] = coarse row of each fine row. */
+int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out,
+                      uint64_t* hkeys, int32_t* hvals, int64_t cap,
+                      int32_t* coarse, int32_t* parent,
+                      int32_t* d_m, int32_t* d_status, void* workspace, void* stream);
+
+/* Kernel map (rulebook) as a neighbour table -- MinkowskiConvolution ks=3 (minkunet.py:
+ * 53-66,94,97,156,159,512,515) and ks=2/stride 2 (13-29) (ME: CoordinateMapManager::
+ * kernel_map).  nbr[k*m_out + o] = row of the INPUT map holding out_coords[o] +
+ * offset_k*step, or -1.  Offsets iterate x fastest; ks odd: centred {-1,0,1}; ks even:
+ * {0,1}.  (hkeys,hvals,cap) is the INPUT map's table. */
+int lidiff_kernel_map(const int32_t* out_coords, int64_t m_out,
+                      const uint64_t* hkeys_in, const int32_t* hvals_in, int64_t cap_in,
+                      int32_t ks, int32_t step, int32_t* nbr, void* stream);
+
+/* Kernel map of MinkowskiConvolutionTranspose(ks=2,stride=2) -- minkunet.py:32-46 (ME:
+ * swapped fine->coarse map): nbr_up[k*m_fine + j] = parent[j] if k == kernel index of
+ * (fine_coords[j] - coarse coordinate)/ts_fine (x fastest) else -1. */
+int lidiff_kernel_map_up(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine,
+                         int32_t ts_fine, int32_t* nbr_up, void* stream);
+
+/* ME-layout rulebook from a neighbour table: for every k the (in,out) pairs sorted by
+ * out row, concatenated; offset_ptr[K+1] (device).  Two-phase: call with pairs_in == NULL
+ * to fill offset_ptr only (count pass), then with arrays of offset_ptr[K] entries. */
+int lidiff_rulebook_compact(const int32_t* nbr, int32_t k_vol, int64_t m_out,
+                            int32_t* offset_ptr, int32_t* pairs_in, int32_t* pairs_out,
+                            void* workspace, void* stream);
+int64_t lidiff_rulebook_workspace_bytes(int32_t k_vol, int64_t m_out);
+
+/* Sparse convolution forward -- MinkowskiConvolution / MinkowskiConvolutionTranspose
+ * (ME: ConvolutionForwardGPU gather-GEMM-scatter), output-stationary, fp32 MFMA:
+ *   out[o, :] = epilogue( sum_k  in[nbr[k,o], :] @ w[k] ),  in = [in_a | in_b] column-wise
+ *   (in_b may be NULL; it fuses ME.cat(in_a, in_b), minkunet.py:464,474,484,494).
+ *   nbr == NULL means K == 1 identity map (kernel_size=1, minkunet.py:72).
+ *   epilogue: v = acc*ep_scale[c] + ep_shift[c] (either may be NULL) ; v += residual[o,c]
+ *   (may be NULL) ; relu if relu != 0.   (eval-mode MinkowskiBatchNorm + MinkowskiReLU +
+ *   ResidualBlock add, minkunet.py:23-24,59-60,79.)
+ * w is [K, c_in_a + c_in_b, c_out] row-major. */
+int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
+                      const float* w, const int32_t* nbr, int32_t k_vol,
+                      int64_t m_in, int64_t m_out, int32_t c_out, float* out,
+                      const float* ep_scale, const float* ep_shift, const float* residual,
+                      int32_t relu, void* stream);
+
+/* Weight gradient of the above: dw[k] += gather(in)[pairs_k]^T @ grad_out[pairs_k]. dw must
+ * be zeroed by the caller. */
+int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
+                        const float* grad_out, const int32_t* nbr, int32_t k_vol,
+                        int64_t m_in, int64_t m_out, int32_t c_out, float* dw, void* stream);
+
+/* Row gather / scatter-add -- SparseTensor.slice(field).F minkunet.py:497,619 and the
+ * x_part.F[idx] of match_part_to_full minkunet.py:418; scatter-add is their backward. */
+int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
+                       float* dst, void* stream);
+int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
+                            float* dst, void* stream);
+
+/* MinkUNetDiff.match_part_to_full -- minkunet.py:403-418 (pykeops argKmin(1)): for every
+ * full row the index of the nearest part row by squared L2 over (b*scale, x, y, z), ties to
+ * the lowest index. scale = 2 * (*d_max_coord) as in the reference (d_max_coord: device int32,
+ * the max over ALL columns of full). */
+int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
+                    const int32_t* d_max_coord, int64_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDIFF_AMD_H */

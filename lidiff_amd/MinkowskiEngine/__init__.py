@@ -1,0 +1,398 @@
+"""Drop-in for the subset of the MinkowskiEngine 0.5.4 Python API that LiDiff consumes
+(SURVEY.md 8b): ``import lidiff_amd.MinkowskiEngine as ME``.
+
+Symbols (reference call sites, paths relative to /root/reference/lidiff):
+  ME.utils.batched_coordinates            tools/diff_completion_pipeline.py:69, models/models.py:163
+  ME.utils.sparse_quantize                map_from_scans.py:91, SemanticKITTITemporalAggr.py:87
+  ME.TensorField(.F .C .sparse())         pipeline:74-80,149; models.py:168-174
+  ME.SparseTensor(.F .C * + .slice)       models/minkunet.py:431,79,497
+  ME.MinkowskiConvolution[Transpose]      minkunet.py:17,36,53,61,72
+  ME.MinkowskiBatchNorm / SyncBatchNorm   minkunet.py:23; train.py:90
+  ME.MinkowskiReLU, ME.cat                minkunet.py:24,464
+  ME.SparseTensorQuantizationMode, ME.MinkowskiAlgorithm   pipeline:77-78
+
+Everything runs on the GPU through the C ABI in include/lidiff_amd.h (hand-written HIP
+kernels); there is no CPU path.  Row order is deterministic: first occurrence in point
+order (level 0) / in finer-row order (strided maps) -- SURVEY.md Appendix A.7.
+"""
+from __future__ import annotations
+
+import enum
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import utils  # noqa: F401  (ME.utils.*)
+
+
+class SparseTensorQuantizationMode(enum.Enum):
+    RANDOM_SUBSAMPLE = 0
+    UNWEIGHTED_AVERAGE = 1
+    UNWEIGHTED_SUM = 2
+    NO_QUANTIZATION = 3
+
+
+class MinkowskiAlgorithm(enum.Enum):
+    DEFAULT = 0
+    MEMORY_EFFICIENT = 1
+    SPEED_OPTIMIZED = 2
+
+
+# ----------------------------------------------------------------------------------------
+# coordinate manager
+# ----------------------------------------------------------------------------------------
+class CoordinateMap:
+    __slots__ = ("coords", "table", "ts")
+
+    def __init__(self, coords, table, ts):
+        self.coords, self.table, self.ts = coords, table, ts
+
+
+class CoordinateManager:
+    """Per-field cache of coordinate maps (keyed by tensor stride) and kernel maps (keyed by
+    (ts_in, ts_out, kernel_size, transposed)) -- the reuse LiDiff relies on: across layers,
+    across the cond/uncond forwards of a step (pipeline:149-151), and transposed convs landing
+    on the encoder's maps so ME.cat is legal (SURVEY.md 8b 'Ownership / lifetime')."""
+
+    def __init__(self, device):
+        self.device = device
+        self.maps: dict[int, CoordinateMap] = {}
+        self.parents: dict[int, torch.Tensor] = {}      # ts_out -> parent row of every finer row
+        self.kmaps: dict[tuple, torch.Tensor] = {}
+        self.aux: dict = {}                             # derived per-map caches (match indices, ...)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def insert(self, coords_i32: torch.Tensor):
+        uniq, inverse, first_idx, table = ops.vox_unique(coords_i32, self.status)
+        self.maps[1] = CoordinateMap(uniq, table, 1)
+        return inverse, first_idx
+
+    def stride(self, ts: int, s: int) -> int:
+        ts_out = ts * s
+        if ts_out not in self.maps:
+            coarse, parent, table = ops.map_stride(self.maps[ts].coords, ts_out, self.status)
+            self.maps[ts_out] = CoordinateMap(coarse, table, ts_out)
+            self.parents[ts_out] = parent
+        return ts_out
+
+    def kernel_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False) -> torch.Tensor:
+        key = (ts_in, ts_out, ks, transposed)
+        nbr = self.kmaps.get(key)
+        if nbr is None:
+            if transposed:      # input = coarse map (ts_in), output = existing fine map (ts_out)
+                if ks != 2 or ts_in != 2 * ts_out or ts_in not in self.parents:
+                    raise RuntimeError("transposed convolution supported for kernel_size=2, stride=2 "
+                                       "onto a map created by the matching strided convolution")
+                nbr = ops.kernel_map_up(self.maps[ts_out].coords, self.parents[ts_in], ts_out)
+            else:
+                nbr = ops.kernel_map(self.maps[ts_out].coords, self.maps[ts_in].table, ks, ts_in)
+            self.kmaps[key] = nbr
+        return nbr
+
+    def check(self):
+        """Raise if a kernel flagged a coordinate outside the hash-key range (host sync)."""
+        s = int(self.status.item())
+        if s & ops.STATUS_KEY_RANGE:
+            raise RuntimeError("coordinate outside [-32768, 32767]: not representable in the 64-bit key")
+        if s & ops.STATUS_HASH_FULL:
+            raise RuntimeError("coordinate hash table overflow")
+
+
+# ----------------------------------------------------------------------------------------
+# autograd functions
+# ----------------------------------------------------------------------------------------
+class _VoxelMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, inverse, m):
+        out, counts = ops.vox_mean(feats, inverse, m)
+        ctx.save_for_backward(inverse, counts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        inverse, counts = ctx.saved_tensors
+        return ops.vox_mean_bwd(g, inverse, counts), None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx):
+        ctx.save_for_backward(idx)
+        ctx.m = src.shape[0]
+        return ops.gather_rows(src, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return ops.scatter_add_rows(g, idx, ctx.m), None
+
+
+class _SparseConv(torch.autograd.Function):
+    """out = sum_k in[nbr[k]] @ W[k].  backward: dX is the same operator over the swapped map
+    with W^T (for a centred odd kernel on one map the swap is k -> K-1-k); dW = gather^T @ g."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, nbr, nbr_swapped, m_out, flip):
+        ctx.save_for_backward(x, kernel, nbr, nbr_swapped)
+        ctx.flip = flip
+        return ops.spconv_fwd(x, kernel, nbr, m_out)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, kernel, nbr, nbr_swapped = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = None
+        w3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
+        if ctx.needs_input_grad[0]:
+            wt = (w3.flip(0) if ctx.flip else w3).transpose(1, 2).contiguous()
+            gx = ops.spconv_fwd(g, wt, nbr_swapped, x.shape[0])
+        if ctx.needs_input_grad[1]:
+            gw = ops.spconv_bwd_w(x, g, nbr, w3.shape[0]).reshape(kernel.shape)
+        return gx, gw, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------
+# tensors
+# ----------------------------------------------------------------------------------------
+class TensorField:
+    """ME.TensorField (pipeline:74-80): per-point features + float coordinates [N, 1+D] whose
+    column 0 is the batch index.  ``.sparse()`` floors the coordinates to int32, hashes them
+    into unique voxels and averages member features (UNWEIGHTED_AVERAGE)."""
+
+    def __init__(self, features, coordinates, quantization_mode=SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                 minkowski_algorithm=MinkowskiAlgorithm.DEFAULT, coordinate_manager=None, device=None):
+        if quantization_mode not in (SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,):
+            raise NotImplementedError("LiDiff only uses UNWEIGHTED_AVERAGE quantisation")
+        if device is not None:
+            features, coordinates = features.to(device), coordinates.to(device)
+        ops.require_device(features, coordinates)
+        if coordinates.dim() != 2 or coordinates.shape[1] != 4:
+            raise ValueError("coordinates must be [N, 4] = (batch, x, y, z)")
+        if features.shape[0] != coordinates.shape[0]:
+            raise ValueError("features and coordinates disagree on the number of points")
+        self._F = features
+        self._C = coordinates
+        self.quantization_mode = quantization_mode
+        self.coordinate_manager = coordinate_manager or CoordinateManager(features.device)
+        self.inverse_mapping = None
+        self._sparse = None
+
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self._C
+
+    @property
+    def device(self):
+        return self._F.device
+
+    def sparse(self) -> "SparseTensor":
+        mgr = self.coordinate_manager
+        if self.inverse_mapping is None:
+            ci = self._C if self._C.dtype == torch.int32 else ops.coords_floor(self._C)
+            self.inverse_mapping, _ = mgr.insert(ci)
+        m = mgr.maps[1].coords.shape[0]
+        return SparseTensor(_VoxelMean.apply(self._F.float(), self.inverse_mapping, m),
+                            tensor_stride=1, coordinate_manager=mgr)
+
+
+class SparseTensor:
+    """ME.SparseTensor: features [M, C] on the coordinate map `tensor_stride` of a manager."""
+
+    def __init__(self, features, coordinates=None, tensor_stride=1, coordinate_manager=None, device=None):
+        if coordinate_manager is None:
+            if coordinates is None:
+                raise ValueError("need coordinates or a coordinate manager")
+            # ME.SparseTensor(features, coordinates): quantise like a field and average duplicates
+            field = TensorField(features, coordinates.float() if coordinates.is_floating_point() else coordinates,
+                                device=device)
+            sp = field.sparse()
+            features, coordinate_manager, tensor_stride = sp.F, sp.coordinate_manager, 1
+        self._F = features
+        self.tensor_stride = int(tensor_stride)
+        self.coordinate_manager = coordinate_manager
+
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self.coordinate_manager.maps[self.tensor_stride].coords
+
+    @property
+    def device(self):
+        return self._F.device
+
+    def _like(self, features):
+        return SparseTensor(features, tensor_stride=self.tensor_stride, coordinate_manager=self.coordinate_manager)
+
+    def __mul__(self, other):
+        if isinstance(other, SparseTensor):
+            _same_map(self, other)
+            other = other.F
+        return self._like(self._F * other)
+
+    def __add__(self, other):
+        if isinstance(other, SparseTensor):
+            _same_map(self, other)
+            other = other.F
+        return self._like(self._F + other)
+
+    def slice(self, field: TensorField) -> TensorField:
+        """F_vox[inverse_mapping] -> per-point features (minkunet.py:497,619)."""
+        if field.coordinate_manager is not self.coordinate_manager or self.tensor_stride != 1:
+            raise RuntimeError("slice needs the stride-1 tensor of the field's own coordinate manager")
+        out = TensorField.__new__(TensorField)
+        out._F = _GatherRows.apply(self._F, field.inverse_mapping)
+        out._C = field._C
+        out.quantization_mode = field.quantization_mode
+        out.coordinate_manager = field.coordinate_manager
+        out.inverse_mapping = field.inverse_mapping
+        return out
+
+
+def _same_map(a: SparseTensor, b: SparseTensor):
+    if a.coordinate_manager is not b.coordinate_manager or a.tensor_stride != b.tensor_stride:
+        raise RuntimeError("sparse tensors live on different coordinate maps")
+
+
+def cat(*tensors):
+    """ME.cat: channel concat of tensors on the same coordinate map (minkunet.py:464,...)."""
+    if len(tensors) == 1 and isinstance(tensors[0], (list, tuple)):
+        tensors = tuple(tensors[0])
+    for t in tensors[1:]:
+        _same_map(tensors[0], t)
+    return tensors[0]._like(torch.cat([t.F for t in tensors], dim=1))
+
+
+# ----------------------------------------------------------------------------------------
+# modules (state-dict compatible with ME: `.kernel`, `.bn.*`)
+# ----------------------------------------------------------------------------------------
+class _ConvBase(nn.Module):
+    transposed = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 dimension=None):
+        super().__init__()
+        if dimension != 3:
+            raise NotImplementedError("LiDiff is 3-D: dimension must be 3")
+        if dilation != 1:
+            raise NotImplementedError("dilation != 1 is not used by LiDiff")
+        if bias:
+            raise NotImplementedError("LiDiff's convolutions have no bias")
+        if (kernel_size, stride) not in ((3, 1), (2, 2), (1, 1)):
+            raise NotImplementedError(f"kernel_size={kernel_size}, stride={stride} is not on LiDiff's path")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.dilation, self.dimension = kernel_size, stride, dilation, dimension
+        k_vol = kernel_size ** 3
+        shape = (in_channels, out_channels) if k_vol == 1 else (k_vol, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        self.bias = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # ME: U(-1/sqrt(n), 1/sqrt(n)), n = (C_out if transposed else C_in) * kernel_volume (App. A.6)
+        n = (self.out_channels if self.transposed else self.in_channels) * self.kernel_size ** 3
+        with torch.no_grad():
+            self.kernel.uniform_(-1.0 / math.sqrt(n), 1.0 / math.sqrt(n))
+
+    def maps(self, x: SparseTensor):
+        """(nbr, nbr_swapped, ts_out, flip) for input x; builds / reuses the manager's maps."""
+        mgr, ts = x.coordinate_manager, x.tensor_stride
+        if self.kernel_size == 1:
+            return None, None, ts, False
+        if self.transposed:
+            ts_out = ts // self.stride
+            if ts_out < 1 or ts_out not in mgr.maps:
+                raise RuntimeError("transposed convolution needs the finer map created by the encoder")
+            return (mgr.kernel_map(ts, ts_out, self.kernel_size, True),
+                    mgr.kernel_map(ts_out, ts, self.kernel_size, False), ts_out, False)
+        if self.stride == 1:
+            nbr = mgr.kernel_map(ts, ts, self.kernel_size)
+            return nbr, nbr, ts, True
+        ts_out = mgr.stride(ts, self.stride)
+        return (mgr.kernel_map(ts, ts_out, self.kernel_size, False),
+                mgr.kernel_map(ts_out, ts, self.kernel_size, True), ts_out, False)
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        nbr, nbr_sw, ts_out, flip = self.maps(x)
+        mgr = x.coordinate_manager
+        m_out = mgr.maps[ts_out].coords.shape[0]
+        if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad):
+            f = _SparseConv.apply(x.F, self.kernel, nbr, nbr_sw, m_out, flip)
+        else:
+            f = ops.spconv_fwd(x.F, self.kernel, nbr, m_out)
+        return SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
+
+    def extra_repr(self):
+        return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
+                f"stride={self.stride}, transposed={self.transposed}")
+
+
+class MinkowskiConvolution(_ConvBase):
+    """ME.MinkowskiConvolution (minkunet.py:17,53,61,72,94,97,...)."""
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    """ME.MinkowskiConvolutionTranspose(ks=2, stride=2) (minkunet.py:36): upsamples onto the
+    encoder's existing finer map through the swapped fine->coarse kernel map."""
+    transposed = True
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """ME.MinkowskiBatchNorm = nn.BatchNorm1d on F (child module `.bn`, which LiDiff's
+    weight_initialization relies on, minkunet.py:128-132)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        return x._like(self.bn(x.F))
+
+
+class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
+    """ME.MinkowskiSyncBatchNorm: statistics all-reduced over the process group (RCCL)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True,
+                 process_group=None):
+        nn.Module.__init__(self)
+        self.bn = nn.SyncBatchNorm(num_features, eps=eps, momentum=momentum, affine=affine,
+                                   track_running_stats=track_running_stats, process_group=process_group)
+
+    @classmethod
+    def convert_sync_batchnorm(cls, module, process_group=None):
+        """train.py:90 / train_refine.py:58: swap every MinkowskiBatchNorm for the sync version."""
+        out = module
+        if isinstance(module, MinkowskiBatchNorm) and not isinstance(module, MinkowskiSyncBatchNorm):
+            src = module.bn
+            out = cls(src.num_features, src.eps, src.momentum, src.affine, src.track_running_stats, process_group)
+            if src.affine:
+                with torch.no_grad():
+                    out.bn.weight = src.weight
+                    out.bn.bias = src.bias
+            out.bn.running_mean = src.running_mean
+            out.bn.running_var = src.running_var
+            out.bn.num_batches_tracked = src.num_batches_tracked
+        for name, child in module.named_children():
+            if out is module:
+                new = cls.convert_sync_batchnorm(child, process_group)
+                if new is not child:
+                    module.add_module(name, new)
+        return out
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        return x._like(torch.relu(x.F))

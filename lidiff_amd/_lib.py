@@ -1,0 +1,80 @@
+"""ctypes binding of liblidiff_amd.so (the C ABI declared in include/lidiff_amd.h).
+
+There is no CPU fallback: if the shared library is missing or a call is rejected, this
+module raises.  Torch is only plumbing here -- it owns device memory and the HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblidiff_amd.so")
+
+_p, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+
+# name -> (restype, argtypes); mirrors include/lidiff_amd.h one to one
+SIGNATURES = {
+    "lidiff_abi_version": (_i32, []),
+    "lidiff_last_error": (C.c_char_p, []),
+    "lidiff_hash_capacity": (_i64, [_i64]),
+    "lidiff_unique_workspace_bytes": (_i64, [_i64]),
+    "lidiff_coords_floor": (_i32, [_p, _i64, _p, _p]),
+    "lidiff_vox_unique": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "lidiff_vox_mean": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p]),
+    "lidiff_vox_mean_bwd": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
+    "lidiff_map_stride": (_i32, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "lidiff_kernel_map": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
+    "lidiff_kernel_map_up": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "lidiff_rulebook_compact": (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _p]),
+    "lidiff_rulebook_workspace_bytes": (_i64, [_i32, _i64]),
+    "lidiff_spconv_fwd": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p]),
+    "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p]),
+    "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "lidiff_scatter_add_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "lidiff_nn_match": (_i32, [_p, _i64, _p, _i64, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP extension; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"lidiff_amd HIP extension missing: {LIB_PATH}. Build it with "
+                "`python -m lidiff_amd.csrc.build` (needs hipcc); there is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if lib.lidiff_abi_version() != 1:
+            raise RuntimeError("lidiff_amd ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def ptr(t: torch.Tensor | None):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point; non-zero status -> RuntimeError (ME raises too)."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {load().lidiff_last_error().decode()}")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("lidiff_amd operators run on the GPU only (no CPU fallback); "
+                               f"got a {t.device} tensor")

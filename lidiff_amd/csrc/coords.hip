@@ -1,0 +1,513 @@
+// Coordinate-side kernels: voxel hashing, first-occurrence unique, inverse map, voxel mean,
+// strided maps, kernel maps (neighbour tables), ME-layout rulebook compaction, row
+// gather/scatter, nearest-part-voxel match.  All HBM-bound integer/byte work: one row per
+// lane, coalesced row-major traffic, wave ballot + mbcnt for ordered compaction.
+// Reference call sites are cited in include/lidiff_amd.h.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace lidiff {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// ---------------------------------------------------------------------------------------
+__global__ void floor_kernel(const float* __restrict__ in, int32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)floorf(in[i]);
+}
+
+// Key of row i after flooring columns 1..3 to a multiple of s (s == 1: identity).
+__device__ __forceinline__ int4 strided_row(const int32_t* __restrict__ coords, int64_t i, int s) {
+    int4 c = reinterpret_cast<const int4*>(coords)[i];
+    if (s > 1) {
+        c.y = floor_div(c.y, s) * s;
+        c.z = floor_div(c.z, s) * s;
+        c.w = floor_div(c.w, s) * s;
+    }
+    return c;
+}
+
+// Phase 1: insert every row's key; the slot remembers the smallest row index that hit it.
+__global__ void insert_kernel(const int32_t* __restrict__ coords, int64_t n, int s,
+                              uint64_t* __restrict__ hkeys, int32_t* __restrict__ hvals,
+                              uint32_t mask, int32_t* __restrict__ slot_of,
+                              int32_t* __restrict__ d_status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = strided_row(coords, i, s);
+    bool ok;
+    const uint64_t key = pack_key(c.x, c.y, c.z, c.w, ok);
+    if (!ok) atomicOr(d_status, LIDIFF_STATUS_KEY_RANGE);
+    uint32_t slot = hash_key(key) & mask;
+    bool placed = false;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const uint64_t prev = atomicCAS((unsigned long long*)&hkeys[slot],
+                                        (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (prev == kEmptyKey || prev == key) { placed = true; break; }
+        slot = (slot + 1) & mask;
+    }
+    if (!placed) { atomicOr(d_status, LIDIFF_STATUS_HASH_FULL); slot = 0; }
+    atomicMin(&hvals[slot], (int32_t)i);
+    slot_of[i] = (int32_t)slot;
+}
+
+// Phase 2: a row is its voxel's first occurrence iff the slot kept its index.  The flag is
+// parked in bit 31 of slot_of; per-block counts feed the ordered compaction.
+__global__ void flag_count_kernel(const int32_t* __restrict__ hvals, int64_t n,
+                                  int32_t* __restrict__ slot_of, int32_t* __restrict__ blk_counts) {
+    __shared__ int wave_cnt[kWavesPerBlock];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool first = false;
+    if (i < n) {
+        const int32_t slot = slot_of[i];
+        first = hvals[slot] == (int32_t)i;
+        if (first) slot_of[i] = slot | (int32_t)0x80000000;
+    }
+    const unsigned long long m = __ballot(first);
+    if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) t += wave_cnt[w];
+        blk_counts[blockIdx.x] = t;
+    }
+}
+
+// Sum of blk_counts[0 .. blockIdx.x) by the whole block.
+__device__ __forceinline__ int block_prefix_of_counts(const int32_t* __restrict__ blk_counts,
+                                                      int* smem /* kWavesPerBlock ints */) {
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += blockDim.x) part += blk_counts[b];
+    for (int off = kWave / 2; off > 0; off >>= 1) part += __shfl_down(part, off);
+    if (lane_id() == 0) smem[threadIdx.x / kWave] = part;
+    __syncthreads();
+    int total = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) total += smem[w];
+    __syncthreads();
+    return total;
+}
+
+// Phase 3: ordered compaction of the first occurrences: row id = #first occurrences before
+// this point.  Writes the unique rows, the first-point index, and the row id into the table.
+__global__ void scan_write_kernel(const int32_t* __restrict__ coords, int64_t n, int s,
+                                  const int32_t* __restrict__ slot_of,
+                                  const int32_t* __restrict__ blk_counts,
+                                  int32_t* __restrict__ hvals, int32_t* __restrict__ uniq,
+                                  int32_t* __restrict__ first_idx, int32_t* __restrict__ d_m) {
+    __shared__ int smem[kWavesPerBlock];
+    __shared__ int wave_cnt[kWavesPerBlock];
+    const int base = block_prefix_of_counts(blk_counts, smem);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t slot = 0;
+    bool first = false;
+    if (i < n) {
+        slot = slot_of[i];
+        first = slot < 0;
+        slot &= 0x7fffffff;
+    }
+    const unsigned long long m = __ballot(first);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    int wave_base = 0, block_total = 0;
+    for (int k = 0; k < kWavesPerBlock; ++k) {
+        if (k < w) wave_base += wave_cnt[k];
+        block_total += wave_cnt[k];
+    }
+    if (first) {
+        const int row = base + wave_base + popc_below(m);
+        const int4 c = strided_row(coords, i, s);
+        reinterpret_cast<int4*>(uniq)[row] = c;
+        if (first_idx) first_idx[row] = (int32_t)i;
+        hvals[slot] = row;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *d_m = base + block_total;
+}
+
+// Phase 4: point -> row through the table.
+template <typename OutT>
+__global__ void inverse_kernel(const int32_t* __restrict__ hvals, const int32_t* __restrict__ slot_of,
+                               int64_t n, OutT* __restrict__ inverse) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inverse[i] = (OutT)hvals[slot_of[i] & 0x7fffffff];
+}
+
+static int run_unique(const int32_t* coords, int64_t n, int s, uint64_t* hkeys, int32_t* hvals,
+                      int64_t cap, int32_t* uniq, int32_t* first_idx, void* inverse, bool inverse64,
+                      int32_t* d_m, int32_t* d_status, void* workspace, hipStream_t st) {
+    LIDIFF_CHECK_ARG(n >= 0 && n < (1ll << 30), "row count out of range");
+    LIDIFF_CHECK_ARG(cap >= 2 * n && (cap & (cap - 1)) == 0, "cap must be a power of two >= 2*n");
+    LIDIFF_CHECK_HIP(hipMemsetAsync(hkeys, 0xFF, (size_t)cap * sizeof(uint64_t), st));
+    LIDIFF_CHECK_HIP(hipMemsetAsync(hvals, 0x7F, (size_t)cap * sizeof(int32_t), st));
+    if (n == 0) {
+        LIDIFF_CHECK_HIP(hipMemsetAsync(d_m, 0, sizeof(int32_t), st));
+        return 0;
+    }
+    const int nblk = (int)ceil_div(n, kBlock);
+    int32_t* slot_of = (int32_t*)workspace;
+    int32_t* blk_counts = slot_of + n;
+    const uint32_t mask = (uint32_t)(cap - 1);
+    insert_kernel<<<nblk, kBlock, 0, st>>>(coords, n, s, hkeys, hvals, mask, slot_of, d_status);
+    flag_count_kernel<<<nblk, kBlock, 0, st>>>(hvals, n, slot_of, blk_counts);
+    scan_write_kernel<<<nblk, kBlock, 0, st>>>(coords, n, s, slot_of, blk_counts, hvals, uniq,
+                                               first_idx, d_m);
+    if (inverse64)
+        inverse_kernel<int64_t><<<nblk, kBlock, 0, st>>>(hvals, slot_of, n, (int64_t*)inverse);
+    else
+        inverse_kernel<int32_t><<<nblk, kBlock, 0, st>>>(hvals, slot_of, n, (int32_t*)inverse);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// voxel mean
+__global__ void mean_accum_kernel(const float* __restrict__ feats, const int64_t* __restrict__ inverse,
+                                  int64_t n, int c, float* __restrict__ out, float* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t row = inverse[i];
+    for (int j = 0; j < c; ++j) atomicAdd(&out[row * c + j], feats[i * c + j]);
+    atomicAdd(&counts[row], 1.0f);
+}
+
+__global__ void mean_div_kernel(float* __restrict__ out, const float* __restrict__ counts,
+                                int64_t total, int c) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) out[e] = out[e] / counts[e / c];
+}
+
+__global__ void mean_bwd_kernel(const float* __restrict__ grad_out, const int64_t* __restrict__ inverse,
+                                const float* __restrict__ counts, int64_t total, int c,
+                                float* __restrict__ grad_feats) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int64_t row = inverse[e / c];
+    grad_feats[e] = grad_out[row * c + e % c] / counts[row];
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel maps
+__global__ void kernel_map_kernel(const int32_t* __restrict__ out_coords, int64_t m_out,
+                                  const uint64_t* __restrict__ hkeys, const int32_t* __restrict__ hvals,
+                                  uint32_t mask, int ks, int step, int32_t* __restrict__ nbr) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= m_out) return;
+    const int4 c = reinterpret_cast<const int4*>(out_coords)[o];
+    const int lo = (ks & 1) ? -(ks - 1) / 2 : 0;
+    int k = 0;
+    for (int dz = 0; dz < ks; ++dz)
+        for (int dy = 0; dy < ks; ++dy)
+            for (int dx = 0; dx < ks; ++dx, ++k) {
+                bool ok;
+                const uint64_t key = pack_key(c.x, c.y + (dx + lo) * step, c.z + (dy + lo) * step,
+                                              c.w + (dz + lo) * step, ok);
+                nbr[(int64_t)k * m_out + o] = ok ? hash_find(hkeys, hvals, mask, key) : -1;
+            }
+}
+
+__global__ void kernel_map_up_kernel(const int32_t* __restrict__ fine, const int32_t* __restrict__ parent,
+                                     int64_t m, int ts, int32_t* __restrict__ nbr_up) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int4 c = reinterpret_cast<const int4*>(fine)[j];
+    const int s = 2 * ts;
+    const int dx = (c.y - floor_div(c.y, s) * s) / ts;
+    const int dy = (c.z - floor_div(c.z, s) * s) / ts;
+    const int dz = (c.w - floor_div(c.w, s) * s) / ts;
+    const int kj = dx + 2 * dy + 4 * dz;
+    const int p = parent[j];
+    for (int k = 0; k < 8; ++k) nbr_up[(int64_t)k * m + j] = (k == kj) ? p : -1;
+}
+
+// ---------------------------------------------------------------------------------------
+// ME-layout rulebook: ordered stream compaction of every offset's column of the table.
+// grid = (blocks over rows, K).  counts[k*nblk + b] -> exclusive scan -> fill.
+__global__ void rb_count_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int32_t* __restrict__ counts) {
+    __shared__ int wave_cnt[kWavesPerBlock];
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = o < m_out && nbr[(int64_t)blockIdx.y * m_out + o] >= 0;
+    const unsigned long long m = __ballot(valid);
+    if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) t += wave_cnt[w];
+        counts[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// single block: in-place exclusive scan of counts[0..n) ; counts[n] = total ;
+// offset_ptr[k] = scanned counts[k*nblk], offset_ptr[K] = total.
+__global__ void rb_scan_kernel(int32_t* __restrict__ counts, int n, int nblk, int k_vol,
+                               int32_t* __restrict__ offset_ptr) {
+    __shared__ int wave_tot[1024 / kWave];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int nw = blockDim.x / kWave;
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? counts[i] : 0;
+        int incl = v;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane_id() >= off) incl += t;
+        }
+        if (lane_id() == kWave - 1) wave_tot[threadIdx.x / kWave] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w = 0; w < nw; ++w) {
+            if (w < (int)(threadIdx.x / kWave)) wbase += wave_tot[w];
+            tot += wave_tot[w];
+        }
+        const int carry = carry_s;
+        if (i < n) counts[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[n] = carry_s;
+    __syncthreads();
+    for (int k = threadIdx.x; k <= k_vol; k += blockDim.x)
+        offset_ptr[k] = (k == k_vol) ? counts[n] : counts[(int64_t)k * nblk];
+}
+
+__global__ void rb_fill_kernel(const int32_t* __restrict__ nbr, int64_t m_out,
+                               const int32_t* __restrict__ scanned, int32_t* __restrict__ pairs_in,
+                               int32_t* __restrict__ pairs_out) {
+    __shared__ int wave_cnt[kWavesPerBlock];
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = -1;
+    if (o < m_out) v = nbr[(int64_t)blockIdx.y * m_out + o];
+    const bool valid = v >= 0;
+    const unsigned long long m = __ballot(valid);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    int wbase = 0;
+    for (int k = 0; k < w; ++k) wbase += wave_cnt[k];
+    if (valid) {
+        const int pos = scanned[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] + wbase + popc_below(m);
+        pairs_in[pos] = v;
+        pairs_out[pos] = (int32_t)o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// row gather / scatter-add
+template <bool VEC4>
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                   int64_t n, int c, float* __restrict__ dst) {
+    const int cw = VEC4 ? c / 4 : c;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * cw) return;
+    const int64_t r = e / cw;
+    const int j = (int)(e % cw);
+    const int64_t s = idx[r];
+    if (VEC4)
+        reinterpret_cast<float4*>(dst)[r * cw + j] = reinterpret_cast<const float4*>(src)[s * cw + j];
+    else
+        dst[r * c + j] = src[s * c + j];
+}
+
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                        int64_t n, int c, float* __restrict__ dst) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * c) return;
+    const int64_t r = e / c;
+    atomicAdd(&dst[idx[r] * c + e % c], src[e]);
+}
+
+// ---------------------------------------------------------------------------------------
+// nearest part voxel: one full row per lane, part rows streamed through LDS tiles; fp32
+// arithmetic as pykeops does (exact on integer coordinates below 2^12), strict '<' while
+// scanning j ascending => lowest index wins ties.
+constexpr int kMatchTile = 1024;
+__global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full,
+                                const int32_t* __restrict__ part, int64_t m_part,
+                                const int32_t* __restrict__ d_max_coord, int64_t* __restrict__ idx) {
+    __shared__ float4 tile[kMatchTile];
+    const float scale = 2.0f * (float)(*d_max_coord);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float fb = 0.f, fx = 0.f, fy = 0.f, fz = 0.f;
+    if (i < m_full) {
+        const int4 c = reinterpret_cast<const int4*>(full)[i];
+        fb = (float)c.x * scale; fx = (float)c.y; fy = (float)c.z; fz = (float)c.w;
+    }
+    float best = INFINITY;
+    int64_t best_j = 0;
+    for (int64_t base = 0; base < m_part; base += kMatchTile) {
+        const int cnt = (int)min((int64_t)kMatchTile, m_part - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+            const int4 c = reinterpret_cast<const int4*>(part)[base + t];
+            tile[t] = make_float4((float)c.x * scale, (float)c.y, (float)c.z, (float)c.w);
+        }
+        __syncthreads();
+        for (int t = 0; t < cnt; ++t) {
+            const float4 p = tile[t];
+            const float db = fb - p.x, dx = fx - p.y, dy = fy - p.z, dz = fz - p.w;
+            const float d = db * db + dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; best_j = base + t; }
+        }
+    }
+    if (i < m_full) idx[i] = best_j;
+}
+
+}  // namespace lidiff
+
+// =======================================================================================
+using namespace lidiff;
+
+extern "C" {
+
+int lidiff_abi_version(void) { return LIDIFF_ABI_VERSION; }
+const char* lidiff_last_error(void) { return g_err; }
+
+int64_t lidiff_hash_capacity(int64_t n_rows) {
+    int64_t cap = 1024;
+    while (cap < 2 * n_rows) cap <<= 1;
+    return cap;
+}
+
+int64_t lidiff_unique_workspace_bytes(int64_t n_rows) {
+    return (n_rows + ceil_div(n_rows > 0 ? n_rows : 1, kBlock) + 16) * (int64_t)sizeof(int32_t);
+}
+
+int lidiff_coords_floor(const float* coords_f, int64_t n_rows, int32_t* coords_i, void* stream) {
+    LIDIFF_CHECK_ARG(n_rows >= 0, "negative row count");
+    if (n_rows == 0) return 0;
+    const int64_t n = n_rows * 4;
+    floor_kernel<<<(unsigned)ceil_div(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(coords_f, coords_i, n);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_vox_unique(const int32_t* coords, int64_t n_rows, uint64_t* hkeys, int32_t* hvals,
+                      int64_t cap, int32_t* uniq, int32_t* first_idx, int64_t* inverse,
+                      int32_t* d_m, int32_t* d_status, void* workspace, void* stream) {
+    return run_unique(coords, n_rows, 1, hkeys, hvals, cap, uniq, first_idx, inverse, true, d_m,
+                      d_status, workspace, (hipStream_t)stream);
+}
+
+int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out, uint64_t* hkeys,
+                      int32_t* hvals, int64_t cap, int32_t* coarse, int32_t* parent, int32_t* d_m,
+                      int32_t* d_status, void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(s_out >= 1, "stride must be >= 1");
+    return run_unique(coords, n_rows, s_out, hkeys, hvals, cap, coarse, nullptr, parent, false, d_m,
+                      d_status, workspace, (hipStream_t)stream);
+}
+
+int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, int32_t c, int64_t m,
+                    float* out, float* counts, void* stream) {
+    LIDIFF_CHECK_ARG(c > 0 && m >= 0 && n_rows >= 0, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 0) return 0;
+    LIDIFF_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)m * c * sizeof(float), st));
+    LIDIFF_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)m * sizeof(float), st));
+    if (n_rows > 0)
+        mean_accum_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(feats, inverse, n_rows, c, out, counts);
+    mean_div_kernel<<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(out, counts, m * c, c);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_vox_mean_bwd(const float* grad_out, const int64_t* inverse, const float* counts,
+                        int64_t n_rows, int32_t c, float* grad_feats, void* stream) {
+    LIDIFF_CHECK_ARG(c > 0 && n_rows >= 0, "bad shape");
+    if (n_rows == 0) return 0;
+    mean_bwd_kernel<<<(unsigned)ceil_div(n_rows * c, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        grad_out, inverse, counts, n_rows * c, c, grad_feats);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_kernel_map(const int32_t* out_coords, int64_t m_out, const uint64_t* hkeys_in,
+                      const int32_t* hvals_in, int64_t cap_in, int32_t ks, int32_t step, int32_t* nbr,
+                      void* stream) {
+    LIDIFF_CHECK_ARG(ks >= 1 && ks <= 3, "kernel_size must be 1..3");
+    LIDIFF_CHECK_ARG(cap_in > 0 && (cap_in & (cap_in - 1)) == 0, "cap must be a power of two");
+    if (m_out == 0) return 0;
+    kernel_map_kernel<<<(unsigned)ceil_div(m_out, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        out_coords, m_out, hkeys_in, hvals_in, (uint32_t)(cap_in - 1), ks, step, nbr);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_kernel_map_up(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine,
+                         int32_t ts_fine, int32_t* nbr_up, void* stream) {
+    LIDIFF_CHECK_ARG(ts_fine >= 1, "tensor stride must be >= 1");
+    if (m_fine == 0) return 0;
+    kernel_map_up_kernel<<<(unsigned)ceil_div(m_fine, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        fine_coords, parent, m_fine, ts_fine, nbr_up);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int64_t lidiff_rulebook_workspace_bytes(int32_t k_vol, int64_t m_out) {
+    return ((int64_t)k_vol * ceil_div(m_out > 0 ? m_out : 1, kBlock) + 16) * (int64_t)sizeof(int32_t);
+}
+
+int lidiff_rulebook_compact(const int32_t* nbr, int32_t k_vol, int64_t m_out, int32_t* offset_ptr,
+                            int32_t* pairs_in, int32_t* pairs_out, void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(k_vol >= 1 && m_out >= 0, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (m_out == 0) {
+        LIDIFF_CHECK_HIP(hipMemsetAsync(offset_ptr, 0, (size_t)(k_vol + 1) * sizeof(int32_t), st));
+        return 0;
+    }
+    const int nblk = (int)ceil_div(m_out, kBlock);
+    int32_t* counts = (int32_t*)workspace;
+    rb_count_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, counts);
+    rb_scan_kernel<<<1, 1024, 0, st>>>(counts, nblk * k_vol, nblk, k_vol, offset_ptr);
+    if (pairs_in != nullptr)
+        rb_fill_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, counts, pairs_in, pairs_out);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c, float* dst,
+                       void* stream) {
+    LIDIFF_CHECK_ARG(c > 0 && n_rows >= 0, "bad shape");
+    if (n_rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    if (vec)
+        gather_rows_kernel<true><<<(unsigned)ceil_div(n_rows * (c / 4), kBlock), kBlock, 0, st>>>(src, idx, n_rows, c, dst);
+    else
+        gather_rows_kernel<false><<<(unsigned)ceil_div(n_rows * c, kBlock), kBlock, 0, st>>>(src, idx, n_rows, c, dst);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
+                            float* dst, void* stream) {
+    LIDIFF_CHECK_ARG(c > 0 && n_rows >= 0, "bad shape");
+    if (n_rows == 0) return 0;
+    scatter_add_rows_kernel<<<(unsigned)ceil_div(n_rows * c, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        src, idx, n_rows, c, dst);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
+                    const int32_t* d_max_coord, int64_t* idx, void* stream) {
+    LIDIFF_CHECK_ARG(m_part >= 1, "part tensor has no rows");
+    if (m_full == 0) return 0;
+    nn_match_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        full, m_full, part, m_part, d_max_coord, idx);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,383 @@
+// Sparse convolution for gfx950: output-stationary, pair-compacted, fp32 MFMA.
+//
+// One workgroup (4 waves) owns a tile of BM consecutive OUTPUT rows x BN output channels and
+// keeps that tile's fp32 accumulators in LDS for the whole kernel-volume loop, so every
+// output row is written to HBM exactly once (with the BatchNorm/ReLU/residual epilogue fused)
+// and there are no global atomics -- results are deterministic.
+//
+// For every kernel offset k the tile's column of the neighbour table nbr[k, row0:row0+BM] is
+// compacted with a wave ballot into a dense pair list (input row, local output row).  The
+// offset's contribution is then a small dense GEMM
+//        [n_k pairs x C_in] (gathered rows)  @  W[k] [C_in x BN]
+// executed with v_mfma_f32_32x32x2_f32 in 32-pair row blocks: only ceil(n_k/32) row blocks
+// are issued, so MFMA work tracks the REAL pair count (plus <32 rows of padding per offset)
+// instead of BM x 27 as a zero-padded implicit GEMM would.  The register accumulators of an
+// offset are flushed into the LDS tile through the pair list's local output row (each output
+// row occurs at most once per offset, and waves own disjoint row-block/column-block sets, so
+// plain LDS read-modify-write is race free).
+//
+// Data movement per K-slab (KS input channels): gathered A rows (coalesced float4, a full
+// 128-byte line per row for KS = 32) and the W[k] slab are prefetched global->registers while
+// the previous slab is being multiplied, then stored to LDS (A padded to KS+1 floats per row:
+// conflict-free ds_read_b32 for the MFMA A operand; B rows are read lane-contiguously).
+//
+// Replaces ME's ConvolutionForwardGPU (gather -> GEMM -> atomic scatter per offset) behind
+// MinkowskiConvolution / MinkowskiConvolutionTranspose; call sites in include/lidiff_amd.h.
+#include "common.h"
+
+namespace lidiff {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float* in_a;
+    const float* in_b;
+    const float* w;
+    const int32_t* nbr;
+    float* out;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    int64_t m_in, m_out;
+    int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
+    int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int KS>
+struct ConvCfg {
+    static constexpr int kThreads = 256;
+    static constexpr int NCB = BN / 32;                                   // 32-col blocks in the tile
+    static constexpr int WC = (NCB % 4 == 0) ? 4 : ((NCB % 2 == 0) ? 2 : 1);  // waves across columns
+    static constexpr int WR = 4 / WC;                                     // waves across row blocks
+    static constexpr int CPW = NCB / WC;                                  // col blocks per wave
+    static constexpr int NRB = BM / 32;
+    static constexpr int RPW = (NRB + WR - 1) / WR;                       // row blocks per wave
+    static constexpr int LDA = KS + 1;
+    static constexpr int A_VEC = (BM * KS / 4 + kThreads - 1) / kThreads;   // float4 per thread
+    static constexpr int B_VEC = (KS * BN / 4 + kThreads - 1) / kThreads;
+    static constexpr int A_SCL = BM * KS / kThreads;
+    static constexpr int B_SCL = (KS * BN + kThreads - 1) / kThreads;
+    static_assert(BM % 64 == 0 && BM <= 256, "BM");
+    static_assert(BN % 32 == 0, "BN");
+    static_assert(KS % 4 == 0 && (BM * KS) % (4 * kThreads) == 0, "KS");
+
+    static size_t lds_bytes(int k_vol) {
+        size_t b = (size_t)BM * BN * 4 + (size_t)KS * BN * 4 + (size_t)BM * LDA * 4;
+        b += (size_t)k_vol * BM * 4;      // in_list
+        b += (size_t)64 * 4 * 2;          // cnt, klist (k_vol <= 64)
+        b += (size_t)k_vol * BM;          // out_list (uint8)
+        return (b + 15) & ~(size_t)15;
+    }
+};
+
+template <int BM, int BN, int KS, bool VEC>
+__global__ __launch_bounds__(256) void spconv_fwd_kernel(const ConvParams p) {
+    using Cfg = ConvCfg<BM, BN, KS>;
+    constexpr int LDA = Cfg::LDA;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* acc_lds = reinterpret_cast<float*>(smem);
+    float* Bs = acc_lds + BM * BN;
+    float* As = Bs + KS * BN;
+    int32_t* in_list = reinterpret_cast<int32_t*>(As + BM * LDA);
+    int32_t* cnt = in_list + p.k_vol * BM;
+    int32_t* klist = cnt + 64;
+    uint8_t* out_list = reinterpret_cast<uint8_t*>(klist + 64);
+
+    // XCD-aware tile mapping: the column blocks of one row tile share an XCD (their gathers
+    // hit the same L2), consecutive row tiles round-robin over the 8 XCDs.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, g = bid >> 3;
+    const int tn = g % p.tiles_n;
+    const int tm = (g / p.tiles_n) * 8 + xcd;
+    if (tm >= p.tiles_m) return;
+    const int64_t row0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
+    if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
+        for (int r = tid; r < BM; r += 256) {
+            in_list[r] = (int32_t)(row0 + r);
+            out_list[r] = (uint8_t)r;
+        }
+        if (tid == 0) cnt[0] = rows_here;
+    } else {
+        for (int k = wave; k < p.k_vol; k += 4) {
+            int pos = 0;
+            for (int c = 0; c < BM; c += 64) {
+                const int r = c + lane;
+                int v = -1;
+                if (r < rows_here) v = p.nbr[(int64_t)k * p.m_out + row0 + r];
+                const bool valid = v >= 0;
+                const unsigned long long m = __ballot(valid);
+                if (valid) {
+                    const int q = pos + popc_below(m);
+                    in_list[k * BM + q] = v;
+                    out_list[k * BM + q] = (uint8_t)r;
+                }
+                pos += __popcll(m);
+            }
+            if (lane == 0) cnt[k] = pos;
+        }
+    }
+    // ---- zero the accumulator tile -----------------------------------------------------------
+    for (int e = tid; e < BM * BN / 4; e += 256)
+        reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    int nact;
+    {   // active offsets (n_k > 0), in ascending k: every wave computes the same list
+        const bool act = lane < p.k_vol && cnt[lane] > 0;
+        const unsigned long long m = __ballot(act);
+        if (wave == 0 && act) klist[popc_below(m)] = lane;
+        nact = __popcll(m);
+    }
+    __syncthreads();
+
+    const int nslab = (p.c_in + KS - 1) / KS;
+    const int nit = nact * nslab;
+
+    float4 a_v[Cfg::A_VEC];
+    float4 b_v[Cfg::B_VEC];
+    float a_s[VEC ? 1 : Cfg::A_SCL];
+    float b_s[VEC ? 1 : Cfg::B_SCL];
+
+    auto prefetch = [&](int it) {
+        const int k = klist[it / nslab];
+        const int k0 = (it % nslab) * KS;
+        const int n_k = cnt[k];
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < Cfg::A_VEC; ++j) {
+                const int e = tid + j * 256;
+                const int pos = e / (KS / 4), col = k0 + 4 * (e % (KS / 4));
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pos < n_k && col < p.c_in) {
+                    const int64_t row = in_list[k * BM + pos];
+                    const float* src = (col < p.c_in_a) ? p.in_a + row * p.c_in_a + col
+                                                        : p.in_b + row * p.c_in_b + (col - p.c_in_a);
+                    v = *reinterpret_cast<const float4*>(src);
+                }
+                a_v[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < Cfg::B_VEC; ++j) {
+                const int e = tid + j * 256;
+                const int kr = e / (BN / 4), cq = e % (BN / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < KS * BN / 4 && k0 + kr < p.c_in)
+                    v = *reinterpret_cast<const float4*>(
+                        p.w + ((int64_t)k * p.c_in + k0 + kr) * p.c_out + n0 + 4 * cq);
+                b_v[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < Cfg::A_SCL; ++j) {
+                const int e = tid + j * 256;
+                const int pos = e / KS, col = k0 + e % KS;
+                float v = 0.f;
+                if (pos < n_k && col < p.c_in) {
+                    const int64_t row = in_list[k * BM + pos];
+                    v = (col < p.c_in_a) ? p.in_a[row * p.c_in_a + col]
+                                         : p.in_b[row * p.c_in_b + (col - p.c_in_a)];
+                }
+                a_s[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < Cfg::B_SCL; ++j) {
+                const int e = tid + j * 256;
+                const int kr = e / BN, cc = e % BN;
+                float v = 0.f;
+                if (e < KS * BN && k0 + kr < p.c_in)
+                    v = p.w[((int64_t)k * p.c_in + k0 + kr) * p.c_out + n0 + cc];
+                b_s[j] = v;
+            }
+        }
+    };
+
+    auto store_slab = [&]() {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < Cfg::A_VEC; ++j) {
+                const int e = tid + j * 256;
+                float* dst = As + (e / (KS / 4)) * LDA + 4 * (e % (KS / 4));
+                dst[0] = a_v[j].x; dst[1] = a_v[j].y; dst[2] = a_v[j].z; dst[3] = a_v[j].w;
+            }
+#pragma unroll
+            for (int j = 0; j < Cfg::B_VEC; ++j) {
+                const int e = tid + j * 256;
+                if (e < KS * BN / 4) reinterpret_cast<float4*>(Bs)[e] = b_v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < Cfg::A_SCL; ++j) {
+                const int e = tid + j * 256;
+                As[(e / KS) * LDA + e % KS] = a_s[j];
+            }
+#pragma unroll
+            for (int j = 0; j < Cfg::B_SCL; ++j) {
+                const int e = tid + j * 256;
+                if (e < KS * BN) Bs[e] = b_s[j];
+            }
+        }
+    };
+
+    const int wc = wave % Cfg::WC, wr = wave / Cfg::WC;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    floatx16 acc[Cfg::RPW][Cfg::CPW];
+#pragma unroll
+    for (int ri = 0; ri < Cfg::RPW; ++ri)
+#pragma unroll
+        for (int ci = 0; ci < Cfg::CPW; ++ci)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ri][ci][r] = 0.f;
+
+    if (nit > 0) prefetch(0);
+    for (int it = 0; it < nit; ++it) {
+        __syncthreads();                 // previous slab fully consumed
+        store_slab();
+        __syncthreads();
+        if (it + 1 < nit) prefetch(it + 1);   // global loads fly during the MFMAs below
+
+        const int k = klist[it / nslab];
+        const int slab = it % nslab;
+        const int n_k = cnt[k];
+        const int nrb = (n_k + 31) >> 5;
+        const int klen = min(KS, p.c_in - slab * KS);
+        const int ksteps = (klen + 1) >> 1;
+
+        for (int kk = 0; kk < ksteps; ++kk) {
+            float bfrag[Cfg::CPW];
+#pragma unroll
+            for (int ci = 0; ci < Cfg::CPW; ++ci)
+                bfrag[ci] = Bs[(2 * kk + lhi) * BN + (wc * Cfg::CPW + ci) * 32 + l31];
+#pragma unroll
+            for (int ri = 0; ri < Cfg::RPW; ++ri) {
+                const int rb = wr + ri * Cfg::WR;
+                if (rb < nrb) {
+                    const float afrag = As[(rb * 32 + l31) * LDA + 2 * kk + lhi];
+#pragma unroll
+                    for (int ci = 0; ci < Cfg::CPW; ++ci)
+                        acc[ri][ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag[ci], acc[ri][ci], 0, 0, 0);
+                }
+            }
+        }
+
+        if (slab == nslab - 1) {         // offset finished: flush registers into the LDS tile
+#pragma unroll
+            for (int ri = 0; ri < Cfg::RPW; ++ri) {
+                const int rb = wr + ri * Cfg::WR;
+                if (rb < nrb) {
+#pragma unroll
+                    for (int ci = 0; ci < Cfg::CPW; ++ci) {
+                        const int col = (wc * Cfg::CPW + ci) * 32 + l31;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int prow = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                            if (prow < n_k) {
+                                const int orow = out_list[k * BM + prow];
+                                acc_lds[orow * BN + col] += acc[ri][ci][r];
+                            }
+                            acc[ri][ci][r] = 0.f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
+    for (int e = tid; e < rows_here * (BN / 4); e += 256) {
+        const int r = e / (BN / 4), cq = e % (BN / 4);
+        const int col = n0 + 4 * cq;
+        float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + cq];
+        if (p.scale) {
+            const float4 s = *reinterpret_cast<const float4*>(p.scale + col);
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+        }
+        if (p.shift) {
+            const float4 s = *reinterpret_cast<const float4*>(p.shift + col);
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        const int64_t o = (row0 + r) * p.c_out + col;
+        if (p.residual) {
+            const float4 s = *reinterpret_cast<const float4*>(p.residual + o);
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        if (p.relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(p.out + o) = v;
+    }
+}
+
+template <int BM, int BN, int KS, bool VEC>
+static int launch_fwd(const ConvParams& p, hipStream_t st) {
+    using Cfg = ConvCfg<BM, BN, KS>;
+    const size_t lds = Cfg::lds_bytes(p.k_vol);
+    LIDIFF_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded");
+    auto kern = spconv_fwd_kernel<BM, BN, KS, VEC>;
+    static thread_local size_t configured = 0;
+    if (lds > configured) {
+        LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    ConvParams q = p;
+    q.tiles_m = (int)ceil_div(p.m_out, BM);
+    q.tiles_n = p.c_out / BN;
+    const unsigned grid = (unsigned)(ceil_div(q.tiles_m, 8) * 8 * q.tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, q);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int BN>
+static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
+    if (vec) return launch_fwd<128, BN, 32, true>(p, st);
+    return launch_fwd<128, BN, 32, false>(p, st);
+}
+
+}  // namespace lidiff
+
+using namespace lidiff;
+
+extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
+                                 const float* w, const int32_t* nbr, int32_t k_vol, int64_t m_in,
+                                 int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
+                                 const float* ep_shift, const float* residual, int32_t relu,
+                                 void* stream) {
+    LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0, "in_a / c_in_a");
+    LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
+    LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
+    LIDIFF_CHECK_ARG(c_out > 0 && c_out % 32 == 0, "c_out must be a multiple of 32");
+    LIDIFF_CHECK_ARG(m_out >= 0 && m_in >= 0, "negative rows");
+    if (m_out == 0) return 0;
+    ConvParams p{};
+    p.in_a = in_a; p.in_b = in_b; p.w = w; p.nbr = nbr; p.out = out;
+    p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
+    p.m_in = m_in; p.m_out = m_out;
+    p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
+    p.k_vol = k_vol; p.relu = relu;
+    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+    LIDIFF_CHECK_ARG(al16(w) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
+                     "w/out/epilogue pointers must be 16-byte aligned");
+    const bool vec = c_in_a % 4 == 0 && c_in_b % 4 == 0 && al16(in_a) && al16(in_b);
+    hipStream_t st = (hipStream_t)stream;
+    if (c_out % 128 == 0) return dispatch_fwd<128>(p, vec, st);
+    if (c_out % 96 == 0) return dispatch_fwd<96>(p, vec, st);
+    if (c_out % 64 == 0) return dispatch_fwd<64>(p, vec, st);
+    return dispatch_fwd<32>(p, vec, st);
+}
+
+extern "C" int lidiff_spconv_bwd_w(const float*, int32_t, const float*, int32_t, const float*,
+                                   const int32_t*, int32_t, int64_t, int64_t, int32_t, float*, void*) {
+    set_error("lidiff_spconv_bwd_w: not built yet");
+    return 3;
+}

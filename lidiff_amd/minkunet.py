@@ -1,0 +1,336 @@
+"""LiDiff's three sparse networks on the MI355X-native operator library.
+
+Mirror of /root/reference/lidiff/models/minkunet.py -- same classes, constructor kwargs,
+module tree and ``state_dict`` keys/shapes (so ``diff_net.ckpt`` / ``refine_net.ckpt`` load
+unchanged), same forward semantics:
+
+  BasicConvolutionBlock   minkunet.py:13-29      MinkGlobalEnc   minkunet.py:83-141
+  BasicDeconvolutionBlock minkunet.py:32-46      MinkUNetDiff    minkunet.py:144-497
+  ResidualBlock           minkunet.py:49-80      MinkUNet        minkunet.py:500-619
+
+What is different is the execution plan in eval mode (``fused=True``, the default):
+  * eval-mode BatchNorm, ReLU and the residual add are folded into the sparse-conv epilogue
+    (one HBM round trip per conv instead of four);
+  * ``ME.cat(y, skip)`` is never materialised: the following convs read two sources;
+  * row-wise MLPs are applied BEFORE the row gather they commute with
+    (``latent(part.F[idx]) == latent(part.F)[idx]``, ``last(y.slice(x).F) == last(y.F)[inv]``),
+    and the first latemp Linear is split over its (p, t) inputs, so the per-voxel GEMM work is
+    only the h x C_l projection;
+  * the part->full nearest-voxel indices are computed once per coordinate map (decoder levels
+    share the encoder's maps).
+``fused=False`` (or training mode) runs the reference's op order through the ME-API shim.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import MinkowskiEngine as ME
+from . import ops
+
+__all__ = ["MinkGlobalEnc", "MinkUNetDiff", "MinkUNet"]
+
+CS = [32, 32, 64, 128, 256, 256, 128, 96, 96]
+
+
+# ----------------------------------------------------------------------------------------
+# fused conv + eval-BN (+ residual) (+ ReLU)
+# ----------------------------------------------------------------------------------------
+def _bn_affine(bn_mod: ME.MinkowskiBatchNorm):
+    """scale/shift of an eval-mode BatchNorm1d, cached on the module until a tensor changes."""
+    bn = bn_mod.bn
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.device)
+    cache = getattr(bn_mod, "_affine_cache", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+            shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        cache = (key, scale, shift)
+        bn_mod._affine_cache = cache
+    return cache[1], cache[2]
+
+
+def _fusable(*mods) -> bool:
+    return not torch.is_grad_enabled() and not any(m.training for m in mods)
+
+
+def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=None) -> ME.SparseTensor:
+    """relu?( bn(conv([x | extra])) + residual ) as ONE kernel launch (eval mode only)."""
+    nbr, _, ts_out, _ = conv.maps(x)
+    mgr = x.coordinate_manager
+    m_out = mgr.maps[ts_out].coords.shape[0]
+    scale, shift = _bn_affine(bn)
+    f = ops.spconv_fwd(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift,
+                       residual=residual, relu=relu)
+    return ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
+
+
+# ----------------------------------------------------------------------------------------
+# blocks
+# ----------------------------------------------------------------------------------------
+class BasicConvolutionBlock(nn.Module):
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1, D=3):
+        super().__init__()
+        self.net = nn.Sequential(
+            ME.MinkowskiConvolution(inc, outc, kernel_size=ks, dilation=dilation, stride=stride, dimension=D),
+            ME.MinkowskiBatchNorm(outc), ME.MinkowskiReLU(inplace=True))
+
+    def forward(self, x):
+        if _fusable(self):
+            return conv_bn_act(self.net[0], self.net[1], x, relu=True)
+        return self.net(x)
+
+
+class BasicDeconvolutionBlock(nn.Module):
+    def __init__(self, inc, outc, ks=3, stride=1, D=3):
+        super().__init__()
+        self.net = nn.Sequential(
+            ME.MinkowskiConvolutionTranspose(inc, outc, kernel_size=ks, stride=stride, dimension=D),
+            ME.MinkowskiBatchNorm(outc), ME.MinkowskiReLU(inplace=True))
+
+    def forward(self, x):
+        if _fusable(self):
+            return conv_bn_act(self.net[0], self.net[1], x, relu=True)
+        return self.net(x)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1, D=3):
+        super().__init__()
+        conv = lambda a, b, k, s: ME.MinkowskiConvolution(a, b, kernel_size=k, dilation=dilation if k > 1 else 1,
+                                                         stride=s, dimension=D)
+        self.net = nn.Sequential(conv(inc, outc, ks, stride), ME.MinkowskiBatchNorm(outc),
+                                 ME.MinkowskiReLU(inplace=True),
+                                 conv(outc, outc, ks, 1), ME.MinkowskiBatchNorm(outc))
+        self.downsample = nn.Sequential()
+        if inc != outc or stride != 1:
+            self.downsample = nn.Sequential(conv(inc, outc, 1, stride), ME.MinkowskiBatchNorm(outc))
+        self.relu = ME.MinkowskiReLU(inplace=True)
+
+    def forward(self, x, extra=None):
+        """extra: second feature source on x's map, standing for ME.cat(x, extra)."""
+        if _fusable(self):
+            y = conv_bn_act(self.net[0], self.net[1], x, relu=True, extra=extra)
+            if len(self.downsample):
+                short = conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False, extra=extra).F
+            else:
+                short = x.F if extra is None else torch.cat([x.F, extra], dim=1)
+            return conv_bn_act(self.net[3], self.net[4], y, relu=True, residual=short)
+        if extra is not None:
+            x = x._like(torch.cat([x.F, extra], dim=1))
+        return self.relu(self.net(x) + self.downsample(x))
+
+
+def _stem(cin, c, D):
+    return nn.Sequential(
+        ME.MinkowskiConvolution(cin, c, kernel_size=3, stride=1, dimension=D), ME.MinkowskiBatchNorm(c),
+        ME.MinkowskiReLU(True),
+        ME.MinkowskiConvolution(c, c, kernel_size=3, stride=1, dimension=D), ME.MinkowskiBatchNorm(c),
+        ME.MinkowskiReLU(inplace=True))
+
+
+def _run_stem(stem, x):
+    if _fusable(stem):
+        return conv_bn_act(stem[3], stem[4], conv_bn_act(stem[0], stem[1], x, relu=True), relu=True)
+    return stem(x)
+
+
+def _stage(cin, cout, D):
+    return nn.Sequential(BasicConvolutionBlock(cin, cin, ks=2, stride=2, dilation=1, D=D),
+                         ResidualBlock(cin, cout, ks=3, stride=1, dilation=1, D=D),
+                         ResidualBlock(cout, cout, ks=3, stride=1, dilation=1, D=D))
+
+
+def _up(cin, cout, cskip, D):
+    return nn.ModuleList([
+        BasicDeconvolutionBlock(cin, cout, ks=2, stride=2, D=D),
+        nn.Sequential(ResidualBlock(cout + cskip, cout, ks=3, stride=1, dilation=1, D=D),
+                      ResidualBlock(cout, cout, ks=3, stride=1, dilation=1, D=D))])
+
+
+def _run_up(up, x, skip):
+    y = up[0](x)
+    if _fusable(up):
+        return up[1][1](up[1][0](y, extra=skip.F))
+    return up[1](ME.cat(y, skip))
+
+
+def _mlp(cin, hidden, cout, tail=None):
+    layers = [nn.Linear(cin, hidden), nn.LeakyReLU(0.1, inplace=True), nn.Linear(hidden, cout)]
+    if tail is not None:
+        layers.append(tail)
+    return nn.Sequential(*layers)
+
+
+def _init_bn(module):
+    for m in module.modules():
+        if isinstance(m, nn.BatchNorm1d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+class _Base(nn.Module):
+    def _common(self, kwargs):
+        cr = kwargs.get("cr", 1.0)
+        self.cs = [int(cr * c) for c in CS]
+        self.run_up = kwargs.get("run_up", True)
+        self.D = kwargs.get("D", 3)
+        self.fused = kwargs.get("fused", True)
+        return kwargs.get("in_channels", 3)
+
+    def weight_initialization(self):
+        _init_bn(self)
+
+    def _encoder(self, cin):
+        cs = self.cs
+        self.stem = _stem(cin, cs[0], self.D)
+        for n in range(4):
+            setattr(self, f"stage{n + 1}", _stage(cs[n], cs[n + 1], self.D))
+
+
+# ----------------------------------------------------------------------------------------
+class MinkGlobalEnc(_Base):
+    """Encoder of the partial scan -> stride-16, 256-channel latent (minkunet.py:83-141)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cin = self._common(kwargs)
+        self.embed_dim = self.cs[-1]
+        self._encoder(cin)
+        self.weight_initialization()
+
+    def forward(self, x):
+        x = _run_stem(self.stem, x.sparse())
+        for n in (1, 2, 3, 4):
+            x = getattr(self, f"stage{n}")(x)
+        return x
+
+
+# level name -> (channels multiplied by w, hidden width of latemp); order of minkunet.py:420-495
+_LEVELS = ("stage1", "stage2", "stage3", "stage4", "up1", "up2", "up3", "up4")
+
+
+class MinkUNetDiff(_Base):
+    """The denoiser (minkunet.py:144-497)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cin = self._common(kwargs)
+        cs = self.cs
+        self.embed_dim = cs[-1]
+        self.stem = _stem(cin, cs[0], self.D)
+        lat, emb = cs[4], self.embed_dim
+        # width of x at each conditioning point and hidden width of the fused MLP
+        widths = {"stage1": (cs[0], cs[4]), "stage2": (cs[1], cs[4]), "stage3": (cs[2], cs[4]),
+                  "stage4": (cs[3], cs[4]), "up1": (cs[4], cs[4]), "up2": (cs[5], cs[5]),
+                  "up3": (cs[6], cs[6]), "up4": (cs[7], cs[7])}
+        for i, name in enumerate(_LEVELS):
+            cx, hid = widths[name]
+            setattr(self, f"latent_{name}", _mlp(lat, lat, lat))
+            setattr(self, f"latemp_{name}", _mlp(lat + lat, hid, cx))
+            setattr(self, f"{name}_temp", _mlp(emb, emb, lat))
+            if i < 4:
+                setattr(self, name, _stage(cs[i], cs[i + 1], self.D))
+            else:
+                j = i - 4
+                setattr(self, name, _up(cs[4 + j], cs[5 + j], cs[3 - j], self.D))
+        self.last = _mlp(cs[8], 20, 3)
+        self.weight_initialization()
+
+    # -- minkunet.py:390-401 --------------------------------------------------------------
+    def get_timestep_embedding(self, timesteps):
+        assert timesteps.dim() == 1
+        half = self.embed_dim // 2
+        freq = np.exp(np.arange(0, half) * -(np.log(10000) / (half - 1)))
+        freq = torch.from_numpy(freq).float().to(timesteps.device)
+        emb = timesteps[:, None] * freq[None, :]
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+        if self.embed_dim % 2 == 1:
+            emb = TF.pad(emb, (0, 1), "constant", 0)
+        return emb
+
+    # -- minkunet.py:403-418 --------------------------------------------------------------
+    def match_index(self, x_full, x_part):
+        """argmin_j ||C_full[i] - C_part[j]||^2 (batch column scaled by 2*max coord), cached per
+        (full map, part tensor): decoder levels reuse the encoder's maps."""
+        cache = x_full.coordinate_manager.aux
+        key = ("match", x_full.tensor_stride)
+        hit = cache.get(key)
+        if hit is not None and hit[0] is x_part.coordinate_manager and hit[1] == x_part.tensor_stride:
+            return hit[2]
+        idx = ops.nn_match(x_full.C, x_part.C)
+        cache[key] = (x_part.coordinate_manager, x_part.tensor_stride, idx)
+        return idx
+
+    def match_part_to_full(self, x_full, x_part):
+        return ME._GatherRows.apply(x_part.F, self.match_index(x_full, x_part))
+
+    @staticmethod
+    def _rows_per_batch(x):
+        return torch.unique(x.C[:, 0], return_counts=True)[1]
+
+    def _condition(self, name, x, part, temp_emb):
+        """x * w with w = latemp(cat(latent(match), temp)) -- e.g. minkunet.py:424-431."""
+        latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
+                                getattr(self, f"latemp_{name}"))
+        t_first = name == "up1"                      # minkunet.py:461: cat((t4, p4))
+        if self.fused and _fusable(self):
+            idx = self.match_index(x, part)
+            lat = latent(part.F)                                     # [M_p, 256] instead of [M_l, 256]
+            lin1, lin2 = latemp[0], latemp[2]
+            c = lat.shape[1]
+            w_t, w_p = (lin1.weight[:, :c], lin1.weight[:, c:]) if t_first else (lin1.weight[:, c:], lin1.weight[:, :c])
+            h_p = lat @ w_p.t()                                      # [M_p, h]
+            h_t = TF.linear(temp(temp_emb), w_t, lin1.bias)          # [B, h]
+            if h_t.shape[0] > 1:
+                h_t = torch.repeat_interleave(h_t, self._rows_per_batch(x), dim=0)
+            hidden = TF.leaky_relu(ops.gather_rows(h_p, idx) + h_t, 0.1)
+            return x * lin2(hidden)
+        p = latent(self.match_part_to_full(x, part))
+        t = temp(temp_emb)
+        t = torch.repeat_interleave(t, self._rows_per_batch(x), dim=0)
+        return x * latemp(torch.cat((t, p) if t_first else (p, t), -1))
+
+    # -- minkunet.py:420-497 --------------------------------------------------------------
+    def forward(self, x, x_sparse, part_feats, t):
+        temp_emb = self.get_timestep_embedding(t)
+        feats = [_run_stem(self.stem, x_sparse)]
+        for name in _LEVELS[:4]:
+            feats.append(getattr(self, name)(self._condition(name, feats[-1], part_feats, temp_emb)))
+        y = feats[4]
+        for j, name in enumerate(_LEVELS[4:]):
+            y = _run_up(getattr(self, name), self._condition(name, y, part_feats, temp_emb), feats[3 - j])
+        if self.fused and _fusable(self):
+            return ops.gather_rows(self.last(y.F), x.inverse_mapping)
+        return self.last(y.slice(x).F)
+
+
+class MinkUNet(_Base):
+    """The refinement network (minkunet.py:500-619): same UNet, no conditioning, Tanh head."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cin = self._common(kwargs)
+        cs = self.cs
+        self._encoder(cin)
+        for j in range(4):
+            setattr(self, f"up{j + 1}", _up(cs[4 + j], cs[5 + j], cs[3 - j], self.D))
+        self.last = _mlp(cs[8], 20, kwargs.get("out_channels", 3), tail=nn.Tanh())
+        self.weight_initialization()
+        self.dropout = nn.Dropout(0.3, True)
+
+    def forward(self, x):
+        feats = [_run_stem(self.stem, x.sparse())]
+        for n in (1, 2, 3, 4):
+            feats.append(getattr(self, f"stage{n}")(feats[-1]))
+        y = feats[4]
+        for j in range(4):
+            y = _run_up(getattr(self, f"up{j + 1}"), y, feats[3 - j])
+        if self.fused and _fusable(self):
+            return ops.gather_rows(self.last(y.F), x.inverse_mapping)
+        return self.last(y.slice(x).F)

@@ -1,0 +1,202 @@
+"""Tensor-level wrappers over the C ABI (include/lidiff_amd.h): allocate outputs with torch,
+pass raw device pointers + the current HIP stream, return torch tensors.  GPU only.
+
+Each function names the reference call site whose native kernel it stands in for (paths
+relative to /root/reference/lidiff).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, require_device, stream_ptr
+
+STATUS_KEY_RANGE = 1
+STATUS_HASH_FULL = 2
+
+
+class HashTable:
+    """Open-addressing table of one coordinate map: packed 64-bit key -> row id."""
+
+    def __init__(self, n_rows: int, device):
+        self.cap = _lib.load().lidiff_hash_capacity(int(n_rows))
+        self.keys = torch.empty(self.cap, dtype=torch.int64, device=device)
+        self.vals = torch.empty(self.cap, dtype=torch.int32, device=device)
+
+
+def _workspace(n_rows: int, device):
+    nbytes = _lib.load().lidiff_unique_workspace_bytes(int(n_rows))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def coords_floor(coords_f: torch.Tensor) -> torch.Tensor:
+    """TensorField.sparse() quantisation (pipeline:149): floor float coords -> int32 [N,4]."""
+    require_device(coords_f)
+    coords_f = coords_f.contiguous().float()
+    out = torch.empty(coords_f.shape, dtype=torch.int32, device=coords_f.device)
+    call("lidiff_coords_floor", ptr(coords_f), coords_f.shape[0], ptr(out), stream_ptr())
+    return out
+
+
+def vox_unique(coords: torch.Tensor, status: torch.Tensor):
+    """Voxel hashing (pipeline:149, minkunet.py:135,597).  Returns (uniq[M,4] int32,
+    inverse[N] int64, first_idx[M] int32, HashTable).  One device->host read of M."""
+    require_device(coords)
+    assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+    coords = coords.contiguous()
+    n, dev = coords.shape[0], coords.device
+    table = HashTable(n, dev)
+    uniq = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    first_idx = torch.empty(n, dtype=torch.int32, device=dev)
+    inverse = torch.empty(n, dtype=torch.int64, device=dev)
+    d_m = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _workspace(n, dev)
+    call("lidiff_vox_unique", ptr(coords), n, ptr(table.keys), ptr(table.vals), table.cap,
+         ptr(uniq), ptr(first_idx), ptr(inverse), ptr(d_m), ptr(status), ptr(ws), stream_ptr())
+    m = int(d_m.item())
+    return uniq[:m], inverse, first_idx[:m], table
+
+
+def map_stride(coords: torch.Tensor, s_out: int, status: torch.Tensor):
+    """Strided coordinate map (minkunet.py:13-29).  Returns (coarse[Mc,4], parent[M] int32,
+    HashTable of the coarse map)."""
+    require_device(coords)
+    coords = coords.contiguous()
+    n, dev = coords.shape[0], coords.device
+    table = HashTable(n, dev)
+    coarse = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    parent = torch.empty(n, dtype=torch.int32, device=dev)
+    d_m = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _workspace(n, dev)
+    call("lidiff_map_stride", ptr(coords), n, int(s_out), ptr(table.keys), ptr(table.vals), table.cap,
+         ptr(coarse), ptr(parent), ptr(d_m), ptr(status), ptr(ws), stream_ptr())
+    m = int(d_m.item())
+    return coarse[:m], parent, table
+
+
+def vox_mean(feats: torch.Tensor, inverse: torch.Tensor, m: int):
+    """UNWEIGHTED_AVERAGE features (pipeline:77).  Returns (out[M,C], counts[M])."""
+    require_device(feats, inverse)
+    feats = feats.contiguous().float()
+    n, c = feats.shape
+    out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
+    counts = torch.empty(m, dtype=torch.float32, device=feats.device)
+    call("lidiff_vox_mean", ptr(feats), ptr(inverse), n, c, m, ptr(out), ptr(counts), stream_ptr())
+    return out, counts
+
+
+def vox_mean_bwd(grad_out, inverse, counts):
+    grad_out = grad_out.contiguous()
+    n, c = inverse.shape[0], grad_out.shape[1]
+    g = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+    call("lidiff_vox_mean_bwd", ptr(grad_out), ptr(inverse), ptr(counts), n, c, ptr(g), stream_ptr())
+    return g
+
+
+def kernel_map(out_coords: torch.Tensor, in_table: HashTable, ks: int, step: int) -> torch.Tensor:
+    """Neighbour table nbr[K, M_out] (minkunet.py:53-66 ks=3; 13-29 ks=2/stride 2)."""
+    require_device(out_coords)
+    out_coords = out_coords.contiguous()
+    m = out_coords.shape[0]
+    nbr = torch.empty((ks ** 3, m), dtype=torch.int32, device=out_coords.device)
+    call("lidiff_kernel_map", ptr(out_coords), m, ptr(in_table.keys), ptr(in_table.vals), in_table.cap,
+         int(ks), int(step), ptr(nbr), stream_ptr())
+    return nbr
+
+
+def kernel_map_up(fine_coords: torch.Tensor, parent: torch.Tensor, ts_fine: int) -> torch.Tensor:
+    """Neighbour table of the transposed ks=2/stride-2 conv (minkunet.py:32-46)."""
+    require_device(fine_coords, parent)
+    m = fine_coords.shape[0]
+    nbr = torch.empty((8, m), dtype=torch.int32, device=fine_coords.device)
+    call("lidiff_kernel_map_up", ptr(fine_coords.contiguous()), ptr(parent), m, int(ts_fine), ptr(nbr),
+         stream_ptr())
+    return nbr
+
+
+def rulebook_compact(nbr: torch.Tensor):
+    """ME-layout rulebook from a neighbour table: (pairs_in, pairs_out, offset_ptr[K+1])."""
+    require_device(nbr)
+    k, m = nbr.shape
+    dev = nbr.device
+    ws = torch.empty(_lib.load().lidiff_rulebook_workspace_bytes(k, m), dtype=torch.uint8, device=dev)
+    off = torch.empty(k + 1, dtype=torch.int32, device=dev)
+    call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), None, None, ptr(ws), stream_ptr())
+    total = int(off[-1].item())
+    pin = torch.empty(total, dtype=torch.int32, device=dev)
+    pout = torch.empty(total, dtype=torch.int32, device=dev)
+    call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), ptr(pin), ptr(pout), ptr(ws), stream_ptr())
+    return pin, pout, off
+
+
+def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
+               in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
+               relu: bool = False) -> torch.Tensor:
+    """Sparse convolution forward with fused epilogue (MinkowskiConvolution[Transpose];
+    minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1)."""
+    require_device(in_a, w, nbr, in_b, scale, shift, residual)
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    in_a = in_a.contiguous()
+    w = w.contiguous()
+    k, c_in, c_out = w.shape
+    c_a = in_a.shape[1]
+    c_b = 0
+    if in_b is not None:
+        in_b = in_b.contiguous()
+        c_b = in_b.shape[1]
+        assert in_b.shape[0] == in_a.shape[0]
+    assert c_a + c_b == c_in, f"channel mismatch {c_a}+{c_b} != {c_in}"
+    if nbr is not None:
+        assert nbr.shape == (k, m_out) and nbr.dtype == torch.int32 and nbr.is_contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == (m_out, c_out)
+    out = torch.empty((m_out, c_out), dtype=torch.float32, device=in_a.device)
+    call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(w), ptr(nbr), k, in_a.shape[0], m_out,
+         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), stream_ptr())
+    return out
+
+
+def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None) -> torch.Tensor:
+    in_a = in_a.contiguous()
+    grad_out = grad_out.contiguous()
+    c_a, c_b = in_a.shape[1], 0 if in_b is None else in_b.shape[1]
+    m_out, c_out = grad_out.shape
+    dw = torch.zeros((k, c_a + c_b, c_out), dtype=torch.float32, device=in_a.device)
+    call("lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out), ptr(nbr), k, in_a.shape[0],
+         m_out, c_out, ptr(dw), stream_ptr())
+    return dw
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """SparseTensor.slice(field).F (minkunet.py:497,619) and x_part.F[idx] (:418)."""
+    require_device(src, idx)
+    src = src.contiguous()
+    idx = idx.contiguous()
+    assert idx.dtype == torch.int64
+    n, c = idx.shape[0], src.shape[1]
+    dst = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    call("lidiff_gather_rows", ptr(src), ptr(idx), n, c, ptr(dst), stream_ptr())
+    return dst
+
+
+def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tensor:
+    src = src.contiguous()
+    n, c = src.shape
+    dst = torch.zeros((m, c), dtype=torch.float32, device=src.device)
+    call("lidiff_scatter_add_rows", ptr(src), ptr(idx.contiguous()), n, c, ptr(dst), stream_ptr())
+    return dst
+
+
+def nn_match(full_c: torch.Tensor, part_c: torch.Tensor) -> torch.Tensor:
+    """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416)."""
+    require_device(full_c, part_c)
+    full_c = full_c.contiguous()
+    part_c = part_c.contiguous()
+    assert full_c.dtype == torch.int32 and part_c.dtype == torch.int32
+    max_coord = full_c.max().to(torch.int32).reshape(1)
+    idx = torch.empty(full_c.shape[0], dtype=torch.int64, device=full_c.device)
+    call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord),
+         ptr(idx), stream_ptr())
+    return idx

@@ -1,0 +1,243 @@
+"""Scan-completion inference pipeline: mirror of
+/root/reference/lidiff/tools/diff_completion_pipeline.py (``DiffCompletion``, lines 15-169;
+``load_pcd`` 171-177) without the Lightning / open3d / diffusers dependencies.
+
+Same method names, argument meaning and numerical behaviour:
+  points_to_tensor 68-84 (divides the batch column by the resolution too, App. D.2),
+  reset_partial_pcd 86-90, preprocess_scan 92-105, postprocess_scan 107-115,
+  complete_scan 117-132, refine_forward 134-138, forward 140-146,
+  classfree_forward 148-153, completion_loop 155-169.
+Host-side deviations (no effect on results): no ``torch.cuda.empty_cache()`` calls (App. D.10),
+timesteps are walked as host integers (no per-step device sync inside the scheduler), and a
+fresh scheduler state per scan (App. D.4).
+"""
+from __future__ import annotations
+
+import os
+import struct
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import MinkowskiEngine as ME
+from . import minkunet as minknet
+from .schedulers import DPMSolverMultistepScheduler
+
+DEFAULT_HPARAMS = {   # lidiff/config/config.yaml
+    "data": {"resolution": 0.05, "num_points": 180000, "max_range": 50.0},
+    "train": {"uncond_prob": 0.1, "uncond_w": 6.0, "lr": 1e-4, "batch_size": 2},
+    "diff": {"beta_start": 3.5e-5, "beta_end": 0.007, "beta_func": "linear", "t_steps": 1000,
+             "s_steps": 50, "reg_weight": 5.0},
+    "model": {"out_dim": 96},
+}
+
+
+class DiffCompletion(nn.Module):
+    def __init__(self, diff_path=None, refine_path=None, denoising_steps=50, cond_weight=6.0,
+                 hparams=None, device="cuda"):
+        super().__init__()
+        ckpt_diff = torch.load(diff_path, map_location="cpu") if diff_path else None
+        self.hparams = _merge(DEFAULT_HPARAMS, (ckpt_diff or {}).get("hyper_parameters", hparams or {}))
+        assert denoising_steps <= self.hparams["diff"]["t_steps"], \
+            f"The number of denoising steps cannot be bigger than T={self.hparams['diff']['t_steps']}"
+        out_dim = self.hparams["model"]["out_dim"]
+        self.partial_enc = minknet.MinkGlobalEnc(in_channels=3, out_channels=out_dim)
+        self.model = minknet.MinkUNetDiff(in_channels=3, out_channels=out_dim)
+        self.model_refine = minknet.MinkUNet(in_channels=3, out_channels=3 * 6)
+        if ckpt_diff is not None:
+            self.load_state_dict(ckpt_diff["state_dict"], strict=False)
+        if refine_path:
+            self.load_state_dict(torch.load(refine_path, map_location="cpu")["state_dict"], strict=False)
+        self.eval()
+        self.to(device)
+        self.device = torch.device(device)
+
+        self.hparams["diff"]["s_steps"] = denoising_steps
+        self.hparams["train"]["uncond_w"] = cond_weight
+        self.hparams["data"]["max_range"] = 50.0
+        self.w_uncond = cond_weight
+        self.new_scheduler()
+
+    def new_scheduler(self):
+        d = self.hparams["diff"]
+        self.dpm_scheduler = DPMSolverMultistepScheduler(
+            num_train_timesteps=d["t_steps"], beta_start=d["beta_start"], beta_end=d["beta_end"],
+            beta_schedule="linear", algorithm_type="sde-dpmsolver++", solver_order=2)
+        self.dpm_scheduler.set_timesteps(d["s_steps"])
+        self.dpm_scheduler.to(self.device)
+
+    # pipeline:68-84
+    def points_to_tensor(self, points):
+        x_feats = ME.utils.batched_coordinates(list(points[:]), dtype=torch.float32, device=self.device)
+        x_coord = torch.round(x_feats / self.hparams["data"]["resolution"])
+        return ME.TensorField(features=x_feats[:, 1:], coordinates=x_coord,
+                              quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                              minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
+
+    # pipeline:86-90
+    def reset_partial_pcd(self, x_part, x_uncond):
+        x_part = self.points_to_tensor(x_part.F.reshape(1, -1, 3).detach())
+        x_uncond = self.points_to_tensor(torch.zeros_like(x_part.F.reshape(1, -1, 3)))
+        return x_part, x_uncond
+
+    # pipeline:92-105
+    def preprocess_scan(self, scan):
+        scan = np.asarray(scan)
+        dist = np.sqrt(np.sum(scan ** 2, -1))
+        scan = scan[(dist < self.hparams["data"]["max_range"]) & (dist > 3.5)][:, :3]
+        pts = torch.tensor(scan, device=self.device)                     # float64 like the reference
+        keep = farthest_point_sample(pts, int(self.hparams["data"]["num_points"] / 10))
+        scan = pts[keep].repeat(10, 1)
+        return scan[None, :, :]
+
+    # pipeline:107-115
+    def postprocess_scan(self, completed_scan, input_scan):
+        dist = np.sqrt(np.sum(completed_scan ** 2, -1))
+        post_scan = completed_scan[dist < self.hparams["data"]["max_range"]]
+        max_z = input_scan[..., 2].max().item()
+        min_z = (input_scan[..., 2].mean() - 2 * input_scan[..., 2].std()).item()
+        return post_scan[(post_scan[:, 2] < max_z) & (post_scan[:, 2] > min_z)]
+
+    # pipeline:117-132
+    def complete_scan(self, scan, generator=None):
+        scan = self.preprocess_scan(scan)
+        x_feats = scan + torch.randn(scan.shape, device=self.device, generator=generator, dtype=scan.dtype)
+        x_full = self.points_to_tensor(x_feats)
+        x_cond = self.points_to_tensor(scan)
+        x_uncond = self.points_to_tensor(torch.zeros_like(scan))
+        self.new_scheduler()
+        completed_scan = self.completion_loop(scan, x_full, x_cond, x_uncond)
+        post_scan = self.postprocess_scan(completed_scan, scan)
+        refine_in = self.points_to_tensor(torch.as_tensor(post_scan[None, :, :]))
+        offset = self.refine_forward(refine_in).reshape(-1, 6, 3)
+        refine_complete_scan = post_scan[:, None, :] + offset.cpu().numpy()
+        return refine_complete_scan.reshape(-1, 3), post_scan
+
+    # pipeline:134-138
+    def refine_forward(self, x_in):
+        with torch.no_grad():
+            return self.model_refine(x_in)
+
+    # pipeline:140-146
+    def forward(self, x_full, x_full_sparse, x_part, t):
+        with torch.no_grad():
+            part_feat = self.partial_enc(x_part)
+            out = self.model(x_full, x_full_sparse, part_feat, t)
+        return out.reshape(t.shape[0], -1, 3)
+
+    # pipeline:148-153
+    def classfree_forward(self, x_t, x_cond, x_uncond, t):
+        with torch.no_grad():
+            x_t_sparse = x_t.sparse()
+        e_cond = self.forward(x_t, x_t_sparse, x_cond, t)
+        e_uncond = self.forward(x_t, x_t_sparse, x_uncond, t)
+        return e_uncond + self.w_uncond * (e_cond - e_uncond)
+
+    def denoise_step(self, x_init, x_t, x_cond, x_uncond, t_int: int, noise=None):
+        """One iteration of completion_loop (pipeline:158-167): CFG network pair, DPM-Solver++
+        update on the per-point offsets, re-voxelisation of x_t and the two conditions."""
+        t = torch.full((1,), t_int, dtype=torch.int64, device=self.device)
+        noise_t = self.classfree_forward(x_t, x_cond, x_uncond, t)
+        input_noise = x_t.F.reshape(t.shape[0], -1, 3) - x_init
+        x_new = x_init + self.dpm_scheduler.step(noise_t, t_int, input_noise, noise=noise)["prev_sample"]
+        x_t = self.points_to_tensor(x_new)
+        x_cond, x_uncond = self.reset_partial_pcd(x_cond, x_uncond)
+        return x_t, x_cond, x_uncond
+
+    # pipeline:155-169
+    def completion_loop(self, x_init, x_t, x_cond, x_uncond, noises=None):
+        for i, t_int in enumerate(self.dpm_scheduler.host_timesteps):
+            x_t, x_cond, x_uncond = self.denoise_step(x_init, x_t, x_cond, x_uncond, t_int,
+                                                      None if noises is None else noises[i])
+        x_t.coordinate_manager.check()
+        return x_t.F.cpu().detach().numpy()
+
+
+def _merge(base, over):
+    out = {k: (dict(v) if isinstance(v, dict) else v) for k, v in base.items()}
+    for k, v in (over or {}).items():
+        if isinstance(v, dict) and isinstance(out.get(k), dict):
+            out[k].update(v)
+        else:
+            out[k] = v
+    return out
+
+
+def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
+    """open3d ``farthest_point_down_sample`` stand-in (pipeline:97-99): greedy FPS starting from
+    index 0, returns the selected indices in selection order.  Host-driven torch loop; a HIP
+    kernel for it is a SURVEY.md 8(f) 'next' row, outside the per-step hot path."""
+    n = points.shape[0]
+    if n_samples >= n:
+        return torch.arange(n, device=points.device)
+    sel = torch.empty(n_samples, dtype=torch.int64, device=points.device)
+    dist = torch.full((n,), float("inf"), dtype=points.dtype, device=points.device)
+    far = torch.zeros((), dtype=torch.int64, device=points.device)
+    for i in range(n_samples):
+        sel[i] = far
+        d = ((points - points[far]) ** 2).sum(-1)
+        dist = torch.minimum(dist, d)
+        far = torch.argmax(dist)
+    return sel
+
+
+# ----------------------------------------------------------------------------------------
+# point-cloud files (pipeline:171-177); own PLY reader instead of open3d
+# ----------------------------------------------------------------------------------------
+_PLY_TYPES = {"float": "f", "float32": "f", "double": "d", "float64": "d", "uchar": "B", "uint8": "B",
+              "char": "b", "int8": "b", "short": "h", "int16": "h", "ushort": "H", "uint16": "H",
+              "int": "i", "int32": "i", "uint": "I", "uint32": "I"}
+
+
+def read_ply_points(path: str) -> np.ndarray:
+    """x, y, z of the vertex element of an ASCII or binary-little-endian PLY file (float64)."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, n_vert, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    n_vert = int(tok[2])
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    raise ValueError("list properties on vertices are not supported")
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        names = [p[0] for p in props]
+        if fmt == "ascii":
+            data = np.loadtxt(f, max_rows=n_vert, ndmin=2)
+            return np.stack([data[:, names.index(a)] for a in "xyz"], axis=1).astype(np.float64)
+        if fmt != "binary_little_endian":
+            raise ValueError(f"{path}: unsupported PLY format {fmt}")
+        dt = np.dtype([(n, "<" + t) for n, t in props])
+        data = np.frombuffer(f.read(dt.itemsize * n_vert), dtype=dt, count=n_vert)
+        return np.stack([data[a].astype(np.float64) for a in "xyz"], axis=1)
+
+
+def write_ply_points(path: str, points: np.ndarray):
+    pts = np.asarray(points, dtype="<f8")
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {pts.shape[0]}\n"
+                 "property double x\nproperty double y\nproperty double z\nend_header\n").encode())
+        f.write(pts.tobytes())
+
+
+def load_pcd(pcd_file):
+    if pcd_file.endswith(".bin"):
+        return np.fromfile(pcd_file, dtype=np.float32).reshape((-1, 4))[:, :3]
+    if pcd_file.endswith(".ply"):
+        return read_ply_points(pcd_file)
+    raise ValueError(f"Point cloud format '.{pcd_file.split('.')[-1]}' not supported. "
+                     "(supported formats: .bin (kitti format), .ply)")

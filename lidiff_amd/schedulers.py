@@ -1,0 +1,129 @@
+"""``DPMSolverMultistepScheduler`` with the constructor / ``set_timesteps`` / ``step`` surface
+and attributes LiDiff touches (tools/diff_completion_pipeline.py:38-46,58-66,163;
+models/models.py:65-73,141), restating diffusers==0.18.0 for
+``algorithm_type='sde-dpmsolver++'`` / ``'dpmsolver++'``, ``solver_order<=2``,
+``solver_type='midpoint'``, ``prediction_type='epsilon'``.
+
+Differences from the upstream object, all host-side:
+  * the step index is looked up on a host copy of ``timesteps`` -- no ``.nonzero().item()``
+    device sync per step;
+  * ``step(..., noise=z)`` lets a caller inject the Gaussian draw (parity tests share one z
+    between device and CPU oracle); without it the draw comes from torch's RNG on the
+    sample's device, as upstream.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class SchedulerOutput(dict):
+    @property
+    def prev_sample(self):
+        return self["prev_sample"]
+
+
+class DPMSolverMultistepScheduler:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 solver_order=2, prediction_type="epsilon", algorithm_type="dpmsolver++",
+                 solver_type="midpoint", lower_order_final=True):
+        if beta_schedule != "linear":
+            raise NotImplementedError("LiDiff uses beta_schedule='linear'")
+        if algorithm_type not in ("dpmsolver++", "sde-dpmsolver++") or solver_type != "midpoint":
+            raise NotImplementedError(algorithm_type)
+        if prediction_type != "epsilon" or solver_order not in (1, 2):
+            raise NotImplementedError("epsilon prediction, solver_order 1 or 2")
+        self.num_train_timesteps = num_train_timesteps
+        self.solver_order = solver_order
+        self.algorithm_type = algorithm_type
+        self.lower_order_final = lower_order_final
+        self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.alpha_t = torch.sqrt(self.alphas_cumprod)
+        self.sigma_t = torch.sqrt(1 - self.alphas_cumprod)
+        self.lambda_t = torch.log(self.alpha_t) - torch.log(self.sigma_t)
+        self.sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.init_noise_sigma = 1.0
+        self.timesteps = torch.from_numpy(
+            np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32)[::-1].copy())
+        self._host_timesteps = [int(v) for v in self.timesteps.tolist()]
+        self.num_inference_steps = None
+        self.model_outputs = [None] * solver_order
+        self.lower_order_nums = 0
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        ts = (np.linspace(0, self.num_train_timesteps - 1, num_inference_steps + 1)
+              .round()[::-1][:-1].copy().astype(np.int64))
+        _, first = np.unique(ts, return_index=True)
+        ts = ts[np.sort(first)]
+        self._host_timesteps = [int(v) for v in ts]
+        self.timesteps = torch.from_numpy(ts).to(device)
+        self.num_inference_steps = len(ts)
+        self.model_outputs = [None] * self.solver_order
+        self.lower_order_nums = 0
+
+    def to(self, device):
+        """What DiffCompletion.scheduler_to_cuda does attribute by attribute (pipeline:58-66)."""
+        for name in ("timesteps", "betas", "alphas", "alphas_cumprod", "alpha_t", "sigma_t", "lambda_t", "sigmas"):
+            setattr(self, name, getattr(self, name).to(device))
+        return self
+
+    # -- one-step updates; coefficients are 0-dim fp32 tensors exactly as upstream ------------
+    def _coeffs(self, t, t_prev):
+        lam_p, lam_t = self.lambda_t[t_prev], self.lambda_t[t]
+        h = lam_p - lam_t
+        return h, self.alpha_t[t_prev], self.sigma_t[t_prev], self.sigma_t[t]
+
+    def _first_order(self, x0, t, t_prev, sample, noise):
+        h, a_p, s_p, s_t = self._coeffs(t, t_prev)
+        if self.algorithm_type == "dpmsolver++":
+            return (s_p / s_t) * sample - (a_p * (torch.exp(-h) - 1.0)) * x0
+        return ((s_p / s_t * torch.exp(-h)) * sample + (a_p * (1 - torch.exp(-2.0 * h))) * x0
+                + s_p * torch.sqrt(1.0 - torch.exp(-2.0 * h)) * noise)
+
+    def _second_order(self, t_prev_call, t, t_prev, sample, noise):
+        m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+        h, a_p, s_p, s_t = self._coeffs(t, t_prev)
+        h_0 = self.lambda_t[t] - self.lambda_t[t_prev_call]
+        r0 = h_0 / h
+        d0, d1 = m0, (1.0 / r0) * (m0 - m1)
+        if self.algorithm_type == "dpmsolver++":
+            return ((s_p / s_t) * sample - (a_p * (torch.exp(-h) - 1.0)) * d0
+                    - 0.5 * (a_p * (torch.exp(-h) - 1.0)) * d1)
+        return ((s_p / s_t * torch.exp(-h)) * sample + (a_p * (1 - torch.exp(-2.0 * h))) * d0
+                + 0.5 * (a_p * (1 - torch.exp(-2.0 * h))) * d1
+                + s_p * torch.sqrt(1.0 - torch.exp(-2.0 * h)) * noise)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True, noise=None):
+        if self.num_inference_steps is None:
+            raise ValueError("call set_timesteps first")
+        t = int(timestep) if not isinstance(timestep, torch.Tensor) else self._host_value(timestep)
+        n = len(self._host_timesteps)
+        step_index = self._host_timesteps.index(t) if t in self._host_timesteps else n - 1
+        t_prev = 0 if step_index == n - 1 else self._host_timesteps[step_index + 1]
+        lower_final = step_index == n - 1 and self.lower_order_final and n < 15
+        # epsilon -> data prediction
+        x0 = (sample - self.sigma_t[t] * model_output) / self.alpha_t[t]
+        for i in range(self.solver_order - 1):
+            self.model_outputs[i] = self.model_outputs[i + 1]
+        self.model_outputs[-1] = x0
+        if self.algorithm_type == "sde-dpmsolver++" and noise is None:
+            noise = torch.randn(x0.shape, generator=generator, device=x0.device, dtype=x0.dtype)
+        if self.solver_order == 1 or self.lower_order_nums < 1 or lower_final:
+            prev = self._first_order(x0, t, t_prev, sample, noise)
+        else:
+            prev = self._second_order(self._host_timesteps[step_index - 1], t, t_prev, sample, noise)
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        return SchedulerOutput(prev_sample=prev) if return_dict else (prev,)
+
+    @staticmethod
+    def _host_value(timestep: torch.Tensor) -> int:
+        """A tensor timestep is accepted as upstream does (one device read if it lives on the
+        GPU); lidiff_amd's own loops pass Python ints from ``host_timesteps`` and never sync."""
+        return int(timestep.reshape(-1)[0].item())
+
+    @property
+    def host_timesteps(self):
+        return list(self._host_timesteps)

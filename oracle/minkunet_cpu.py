@@ -1,0 +1,164 @@
+"""CPU oracle for LiDiff's three sparse networks, evaluated from a ``state_dict``.
+
+TEST INFRASTRUCTURE ONLY, PARITY UNPINNED (see oracle/me_cpu.py).  Each function
+follows /root/reference/lidiff/models/minkunet.py (line ranges cited) with the
+MinkowskiEngine ops restated in oracle/me_cpu.py.  Eval-mode semantics only (BatchNorm
+uses running statistics) -- this is the inference path of
+diff_completion_pipeline.py:134-153.
+
+The state-dict keys are the reference's (SURVEY.md 8b 'Checkpoint compatibility'), so a
+``diff_net.ckpt`` / ``refine_net.ckpt`` state dict can be evaluated directly.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+from . import me_cpu as me
+
+
+def _bn(sd, p, x):
+    return me.batch_norm_eval(x, sd[p + ".bn.weight"], sd[p + ".bn.bias"],
+                              sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"])
+
+
+def _conv_bn_relu(sd, p, x, ks, stride, transpose=False):
+    """BasicConvolutionBlock minkunet.py:13-29 / BasicDeconvolutionBlock :32-46."""
+    fn = me.conv_transpose if transpose else me.conv
+    y = fn(x, sd[p + ".net.0.kernel"], ks, stride)
+    return y.replace(torch.relu(_bn(sd, p + ".net.1", y.F)))
+
+
+def _residual(sd, p, x):
+    """ResidualBlock minkunet.py:49-80."""
+    y = me.conv(x, sd[p + ".net.0.kernel"], 3, 1)
+    y = y.replace(torch.relu(_bn(sd, p + ".net.1", y.F)))
+    y = me.conv(y, sd[p + ".net.3.kernel"], 3, 1)
+    main = _bn(sd, p + ".net.4", y.F)
+    if p + ".downsample.0.kernel" in sd:
+        short = _bn(sd, p + ".downsample.1", x.F @ sd[p + ".downsample.0.kernel"])
+    else:
+        short = x.F
+    return y.replace(torch.relu(main + short))
+
+
+def _stem(sd, p, x):
+    """stem minkunet.py:93-100 / 155-162 / 511-518."""
+    y = me.conv(x, sd[p + ".0.kernel"], 3, 1)
+    y = y.replace(torch.relu(_bn(sd, p + ".1", y.F)))
+    y = me.conv(y, sd[p + ".3.kernel"], 3, 1)
+    return y.replace(torch.relu(_bn(sd, p + ".4", y.F)))
+
+
+def _stage(sd, p, x):
+    """stageN = conv2s2 block + 2 residual blocks (minkunet.py:102-124, 183-263, 520-542)."""
+    y = _conv_bn_relu(sd, p + ".0", x, 2, 2)
+    return _residual(sd, p + ".2", _residual(sd, p + ".1", y))
+
+
+def _up(sd, p, x, skip):
+    """upN = deconv2s2 block, ME.cat(skip), 2 residual blocks (minkunet.py:283-292,
+    463-465; 544-572, 603-605)."""
+    y = _conv_bn_relu(sd, p + ".0", x, 2, 2, transpose=True)
+    assert y.ts == skip.ts
+    y = y.replace(torch.cat([y.F, skip.F], dim=1))
+    return _residual(sd, p + ".1.1", _residual(sd, p + ".1.0", y))
+
+
+def _mlp(sd, p, x, act=lambda v: TF.leaky_relu(v, 0.1)):
+    h = act(TF.linear(x, sd[p + ".0.weight"], sd[p + ".0.bias"]))
+    return TF.linear(h, sd[p + ".2.weight"], sd[p + ".2.bias"])
+
+
+def sub_dict(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def global_enc_forward(sd, field: me.CpuTensorField) -> me.CpuSparseTensor:
+    """MinkGlobalEnc.forward minkunet.py:134-141."""
+    x = _stem(sd, "stem", field.sparse())
+    for n in (1, 2, 3, 4):
+        x = _stage(sd, f"stage{n}", x)
+    return x
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """MinkUNetDiff.get_timestep_embedding minkunet.py:390-401."""
+    half = dim // 2
+    freq = np.exp(np.arange(0, half) * -(np.log(10000) / (half - 1)))
+    ang = t[:, None] * torch.from_numpy(freq).float()[None, :]
+    emb = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    return TF.pad(emb, (0, 1)) if dim % 2 == 1 else emb
+
+
+def _condition(sd, name, x, part, temp_emb, order_tp=False):
+    """One conditioning block of MinkUNetDiff.forward (e.g. minkunet.py:424-431):
+    nearest part latent -> latent MLP; timestep MLP repeated per batch; fused MLP -> w;
+    returns x * w."""
+    idx = me.argmin_match(x.C, part.C)                      # :403-418
+    p = _mlp(sd, f"latent_{name}", part.F[torch.from_numpy(idx)])
+    t = _mlp(sd, f"{name}_temp", temp_emb)
+    counts = np.unique(x.C[:, 0], return_counts=True)[1]    # :427 (rows are batch-grouped)
+    t = torch.repeat_interleave(t, torch.from_numpy(counts), dim=0)
+    w = _mlp(sd, f"latemp_{name}", torch.cat((t, p) if order_tp else (p, t), dim=-1))
+    return x.replace(x.F * w)
+
+
+def unet_diff_forward(sd, field: me.CpuTensorField, x_sparse: me.CpuSparseTensor,
+                      part: me.CpuSparseTensor, t: torch.Tensor) -> torch.Tensor:
+    """MinkUNetDiff.forward minkunet.py:420-497."""
+    emb = timestep_embedding(t.float(), 96)
+    x0 = _stem(sd, "stem", x_sparse)
+    x1 = _stage(sd, "stage1", _condition(sd, "stage1", x0, part, emb))
+    x2 = _stage(sd, "stage2", _condition(sd, "stage2", x1, part, emb))
+    x3 = _stage(sd, "stage3", _condition(sd, "stage3", x2, part, emb))
+    x4 = _stage(sd, "stage4", _condition(sd, "stage4", x3, part, emb))
+    y1 = _up(sd, "up1", _condition(sd, "up1", x4, part, emb, order_tp=True), x3)   # :461
+    y2 = _up(sd, "up2", _condition(sd, "up2", y1, part, emb), x2)
+    y3 = _up(sd, "up3", _condition(sd, "up3", y2, part, emb), x1)
+    y4 = _up(sd, "up4", _condition(sd, "up4", y3, part, emb), x0)
+    sliced = y4.F[torch.from_numpy(field.inverse)]          # y4.slice(x).F  :497
+    return _mlp(sd, "last", sliced)
+
+
+def unet_refine_forward(sd, field: me.CpuTensorField) -> torch.Tensor:
+    """MinkUNet.forward minkunet.py:596-619 (Tanh head :574-579)."""
+    x0 = _stem(sd, "stem", field.sparse())
+    x1 = _stage(sd, "stage1", x0)
+    x2 = _stage(sd, "stage2", x1)
+    x3 = _stage(sd, "stage3", x2)
+    x4 = _stage(sd, "stage4", x3)
+    y1 = _up(sd, "up1", x4, x3)
+    y2 = _up(sd, "up2", y1, x2)
+    y3 = _up(sd, "up3", y2, x1)
+    y4 = _up(sd, "up4", y3, x0)
+    return torch.tanh(_mlp(sd, "last", y4.F[torch.from_numpy(field.inverse)]))
+
+
+def points_to_field(points: torch.Tensor, resolution=0.05, divide_batch_col=True) -> me.CpuTensorField:
+    """DiffCompletion.points_to_tensor pipeline:68-84 (divides the batch column too,
+    App. D.2) or DiffusionPoints.points_to_tensor models.py:162-178 (does not)."""
+    feats = me.batched_coordinates(list(points), dtype=torch.float32)
+    coord = feats.clone()
+    if divide_batch_col:
+        coord = torch.round(coord / resolution)
+    else:
+        coord[:, 1:] = torch.round(coord[:, 1:] / resolution)
+    return me.CpuTensorField(feats[:, 1:].contiguous(), coord)
+
+
+def denoise_forward(sd, x_field, x_sparse, cond_field, t):
+    """DiffCompletion.forward pipeline:140-146: partial_enc(x_part) then model(...)."""
+    part = global_enc_forward(sub_dict(sd, "partial_enc."), cond_field)
+    out = unet_diff_forward(sub_dict(sd, "model."), x_field, x_sparse, part, t)
+    return out.reshape(t.shape[0], -1, 3)
+
+
+def classfree_forward(sd, x_field, cond_field, uncond_field, t, w=6.0):
+    """DiffCompletion.classfree_forward pipeline:148-153."""
+    xs = x_field.sparse()
+    e_c = denoise_forward(sd, x_field, xs, cond_field, t)
+    e_u = denoise_forward(sd, x_field, xs, uncond_field, t)
+    return e_u + w * (e_c - e_u)

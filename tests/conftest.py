@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu() -> bool:
+    return torch.cuda.is_available()
+
+
+@pytest.fixture(scope="session")
+def device():
+    if not has_gpu():
+        pytest.skip("no GPU visible")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def fps_scan():
+    """18 000 farthest-point samples of the reference's bundled scan (tests/golden/make_golden.py)."""
+    return np.load(os.path.join(GOLDEN, "scan_000123_fps18000.npy"))
+
+
+def random_cloud(n, extent, seed, batch=1, dup=0.3):
+    """Integer voxel coordinates [n,4] with duplicates, negative values and `batch` batches
+    (rows grouped by ascending batch as LiDiff produces them)."""
+    rng = np.random.default_rng(seed)
+    c = rng.integers(-extent, extent + 1, size=(n, 3))
+    ndup = int(n * dup)
+    if ndup:
+        c[rng.integers(0, n, ndup)] = c[rng.integers(0, n, ndup)]
+    b = np.sort(rng.integers(0, batch, size=n))
+    return np.concatenate([b[:, None], c], axis=1).astype(np.int32)
+
+
+def noisy_scan_points(fps_scan, sigma, seed, n_rep=10):
+    """The bench/parity workload of BASELINE.md section 2: tile the 18k scan x10 and add
+    sigma * N(0, I) offsets (float32, metres)."""
+    rng = np.random.default_rng(seed)
+    base = np.tile(fps_scan.astype(np.float32), (n_rep, 1))
+    return (base + sigma * rng.standard_normal(base.shape).astype(np.float32)).astype(np.float32)

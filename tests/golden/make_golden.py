@@ -1,0 +1,151 @@
+"""Generates the committed fixtures under tests/golden/ (run from the repo root, in the build
+container, where /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+The reference ships no golden vectors and none of its native dependencies can be imported
+(SURVEY.md 4, 8c), so these vectors come from the CPU oracle under oracle/ -- PARITY UNPINNED.
+They pin the oracle against regressions and give the GPU parity tests fixed inputs/outputs.
+  scan_000123_fps18000.npy : bundled scan lidiff/Datasets/test/000123.ply -> 3.5 m < |p| < 50 m
+                             -> greedy farthest-point sampling of 18 000 points (index 0 first),
+                             float32 [18000,3]  (the preprocessing of pipeline:92-99)
+  coords_small.npz         : voxelize / stride maps / kernel maps / rulebook of a seeded cloud
+  conv_small.npz           : sparse conv forward (ks 3, 2/stride 2, transposed, ks 1) on it
+  dpm_trajectory.npz       : DPM-Solver++ (sde, 2nd order) trajectory with injected noise
+  unet_small.npz           : MinkGlobalEnc + MinkUNetDiff CFG output and MinkUNet output on a
+                             2 000-point cloud, weights from torch.manual_seed(42)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from conftest import random_cloud  # noqa: E402
+from oracle import me_cpu as me  # noqa: E402
+from oracle import minkunet_cpu as net  # noqa: E402
+from oracle.dpm_solver import DpmSolverSdeOracle  # noqa: E402
+
+
+def fps_numpy(pts, n):
+    sel = np.empty(n, np.int64)
+    dist = np.full(pts.shape[0], np.inf)
+    far = 0
+    for i in range(n):
+        sel[i] = far
+        dist = np.minimum(dist, ((pts - pts[far]) ** 2).sum(-1))
+        far = int(np.argmax(dist))
+    return sel
+
+
+def make_scan():
+    from lidiff_amd.pipeline import read_ply_points
+    pts = read_ply_points("/root/reference/lidiff/Datasets/test/000123.ply")
+    d = np.sqrt((pts ** 2).sum(-1))
+    pts = pts[(d < 50.0) & (d > 3.5)]
+    keep = fps_numpy(pts, 18000)
+    np.save(os.path.join(HERE, "scan_000123_fps18000.npy"), pts[keep].astype(np.float32))
+    print("scan:", pts.shape, "->", keep.shape)
+
+
+def make_coords():
+    c = random_cloud(4000, 12, seed=1, batch=2)
+    uniq, inv, first = me.voxelize(c)
+    out = {"coords": c, "uniq": uniq, "inverse": inv, "first_idx": first}
+    cur, ts = uniq, 1
+    for lvl in range(1, 5):
+        coarse, parent = me.stride_map(cur, ts * 2)
+        out[f"coarse{lvl}"], out[f"parent{lvl}"] = coarse, parent
+        out[f"nbr_down{lvl}"] = me.kernel_map(cur, coarse, 2, ts)
+        cur, ts = coarse, ts * 2
+    out["nbr3_l0"] = me.kernel_map(uniq, uniq, 3, 1)
+    out["nbr3_l2"] = me.kernel_map(out["coarse2"], out["coarse2"], 3, 4)
+    pin, pout, ptr = me.rulebook_from_nbr(out["nbr3_l0"])
+    out.update(rb_in=pin, rb_out=pout, rb_ptr=ptr)
+    np.savez_compressed(os.path.join(HERE, "coords_small.npz"), **out)
+    return out
+
+
+def make_conv(cm):
+    g = torch.Generator().manual_seed(7)
+    m0, m1 = cm["uniq"].shape[0], cm["coarse1"].shape[0]
+    x0 = torch.randn(m0, 32, generator=g)
+    w3 = torch.randn(27, 32, 64, generator=g) * 0.1
+    w2 = torch.randn(8, 32, 32, generator=g) * 0.1
+    wt = torch.randn(8, 32, 96, generator=g) * 0.1
+    w1 = torch.randn(32, 64, generator=g) * 0.1
+    y3 = me.conv_forward(x0, w3, cm["nbr3_l0"])
+    yd = me.conv_forward(x0, w2, cm["nbr_down1"])
+    up = me.transpose_kernel_map(cm["nbr_down1"], m0)
+    yu = me.conv_forward(yd, wt, up)
+    y1 = me.conv_forward(x0, w1, None)
+    np.savez_compressed(os.path.join(HERE, "conv_small.npz"), x0=x0.numpy(), w3=w3.numpy(), w2=w2.numpy(),
+                        wt=wt.numpy(), w1=w1.numpy(), y3=y3.numpy(), yd=yd.numpy(), yu=yu.numpy(),
+                        y1=y1.numpy(), nbr_up1=up)
+    assert yd.shape[0] == m1
+
+
+def make_dpm():
+    rng = np.random.default_rng(3)
+    out = {}
+    for n in (50, 8, 1):
+        o = DpmSolverSdeOracle()
+        ts = o.set_timesteps(n)
+        x = rng.standard_normal((1, 64, 3))
+        eps = rng.standard_normal((len(ts), 1, 64, 3))
+        z = rng.standard_normal((len(ts), 1, 64, 3))
+        traj = [x]
+        for i, t in enumerate(ts):
+            traj.append(o.step(eps[i], t, traj[-1], z[i]))
+        out[f"ts{n}"], out[f"eps{n}"], out[f"z{n}"], out[f"traj{n}"] = ts, eps, z, np.stack(traj)
+    np.savez_compressed(os.path.join(HERE, "dpm_trajectory.npz"), **out)
+
+
+def small_scene(seed=5, n=2000):
+    rng = np.random.default_rng(seed)
+    part = (rng.standard_normal((n // 10, 3)) * np.array([4.0, 4.0, 0.5])).astype(np.float32)
+    scan = np.tile(part, (10, 1))
+    noisy = (scan + 0.3 * rng.standard_normal(scan.shape)).astype(np.float32)
+    return scan, noisy
+
+
+def make_unet():
+    from lidiff_amd import minkunet as product
+    torch.manual_seed(42)
+    enc, unet, refine = product.MinkGlobalEnc(in_channels=3), product.MinkUNetDiff(in_channels=3), \
+        product.MinkUNet(in_channels=3, out_channels=18)
+    for mod in (enc, unet, refine):           # non-trivial BN statistics
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.8, 1.2)
+                m.bias.data.normal_(0, 0.1)
+    sd = {"partial_enc." + k: v for k, v in enc.state_dict().items()}
+    sd.update({"model." + k: v for k, v in unet.state_dict().items()})
+    scan, noisy = small_scene()
+    with torch.no_grad():
+        xf = net.points_to_field(torch.from_numpy(noisy)[None])
+        cf = net.points_to_field(torch.from_numpy(scan)[None])
+        uf = net.points_to_field(torch.zeros(1, scan.shape[0], 3))
+        t = torch.tensor([500])
+        eps = net.classfree_forward(sd, xf, cf, uf, t, w=6.0)
+        rf = net.points_to_field(torch.from_numpy(noisy)[None])
+        off = net.unet_refine_forward(refine.state_dict(), rf)
+    np.savez_compressed(os.path.join(HERE, "unet_small.npz"), scan=scan, noisy=noisy, eps=eps.numpy(),
+                        refine=off.numpy())
+    print("unet eps", eps.shape, float(eps.abs().mean()), "refine", off.shape)
+
+
+if __name__ == "__main__":
+    if os.path.exists("/root/reference/lidiff/Datasets/test/000123.ply") and "--no-scan" not in sys.argv:
+        make_scan()
+    cm = make_coords()
+    make_conv(cm)
+    make_dpm()
+    make_unet()

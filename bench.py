@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- denoising steps/sec on a 180k-point scan (BASELINE.json metric), MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] ("single scan, T=50 DPM-Solver++ steps, fp32, 1x MI355X"):
+the reference's bundled scan (lidiff/Datasets/test/000123.ply -> range filter -> FPS 18 000,
+committed as tests/golden/scan_000123_fps18000.npy) tiled x10 = 180 000 points, voxel 0.05 m,
+CFG weight 6.0, seeded random-init weights of the reference architecture (no checkpoints exist
+offline).  One STEP = one iteration of completion_loop
+(/root/reference/lidiff/tools/diff_completion_pipeline.py:158-167): voxelise x_t, x_cond and
+x_uncond, two MinkGlobalEnc + MinkUNetDiff forwards, the DPM-Solver++ update, re-voxelisation.
+Because trained weights are unavailable, the point offsets entering step i are sigma_i * N(0, I)
+with sigma_i the scheduler's sigma_t at the T=50 trajectory's timestep i
+-- the sparsity trajectory a trained model sees; K < 50 steps sample that trajectory evenly.
+Inputs are resident in HBM before the timed region.  N > 1: every rank denoises its own scan
+(different noise seed), no collective on the data path ("scaling": "weak").
+
+Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+N_POINTS = 180000
+T_STEPS = 50
+
+
+def load_scan():
+    path = os.path.join(ROOT, "tests", "golden", "scan_000123_fps18000.npy")
+    return np.load(path).astype(np.float32)
+
+
+def trajectory_index(j: int, k: int) -> int:
+    """Which of the 50 trajectory positions step j of a K-step run uses."""
+    return (j * T_STEPS // k) % T_STEPS if k < T_STEPS else j % T_STEPS
+
+
+def build_pipeline(device, seed=42):
+    from lidiff_amd.pipeline import DiffCompletion
+    torch.manual_seed(seed)
+    pipe = DiffCompletion(denoising_steps=T_STEPS, cond_weight=6.0, device=device)
+    for m in pipe.modules():        # non-trivial eval-mode BatchNorm statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    return pipe
+
+
+def make_inputs(pipe, scan_np, steps, seed, device):
+    """x_init [1,N,3] (float64 like the reference, App. D.1) and, per step, the noisy points."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    scan = torch.from_numpy(np.tile(scan_np, (10, 1))).double()[None]
+    sig = pipe.dpm_scheduler.sigma_t.cpu()
+    ts = pipe.dpm_scheduler.host_timesteps
+    xs, tvals = [], []
+    for j in range(steps):
+        t = ts[trajectory_index(j, steps)]
+        xs.append((scan + float(sig[t]) * torch.randn(scan.shape, generator=g, dtype=torch.float64)).to(device))
+        tvals.append(t)
+    return scan.to(device), xs, tvals
+
+
+def run_steps(pipe, x_init, xs, tvals, first, count):
+    """`count` denoising steps starting at schedule position `first`."""
+    x_t = pipe.points_to_tensor(xs[first])
+    x_cond = pipe.points_to_tensor(x_init)
+    x_uncond = pipe.points_to_tensor(torch.zeros_like(x_init))
+    for j in range(first, first + count):
+        t = torch.full((1,), tvals[j], dtype=torch.int64, device=x_init.device)
+        noise_t = pipe.classfree_forward(x_t, x_cond, x_uncond, t)
+        input_noise = x_t.F.reshape(1, -1, 3) - x_init
+        if j == first or tvals[j] >= tvals[j - 1]:
+            pipe.new_scheduler()                       # a new scan's trajectory starts
+        _ = x_init + pipe.dpm_scheduler.step(noise_t, tvals[j], input_noise)["prev_sample"]
+        nxt = xs[j + 1] if j + 1 < len(xs) else xs[j]
+        x_t = pipe.points_to_tensor(nxt)               # open loop: next sigma's points (see docstring)
+        x_cond, x_uncond = pipe.reset_partial_pcd(x_cond, x_uncond)
+        from lidiff_amd import ops
+        if ops.PROFILER is not None:
+            ops.PROFILER._pairs.clear()
+    return x_t
+
+
+def cpu_baseline(scan_np, seed=42):
+    """The oracle (CPU restatement of the MinkowskiEngine/KeOps/diffusers CPU path) timed on this
+    box's host cores: ONE full denoising step at the LAST trajectory position (t=20, sigma=0.047,
+    the cheapest step) of the same 180k-point workload -- a bounded sample, not extrapolated."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import build_seeded_models, diffusion_state_dict
+    from oracle import minkunet_cpu as net
+    from oracle.dpm_solver import DpmSolverSdeOracle
+    enc, unet, _ = build_seeded_models(seed)
+    sd = diffusion_state_dict(enc, unet)
+    o = DpmSolverSdeOracle()
+    ts = o.set_timesteps(T_STEPS)
+    t = int(ts[-1])
+    rng = np.random.default_rng(seed)
+    scan = np.tile(scan_np, (10, 1)).astype(np.float64)[None]
+    x = scan + o.sigma_t[t] * rng.standard_normal(scan.shape)
+    z = rng.standard_normal(scan.shape)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        xf = net.points_to_field(torch.from_numpy(x).float())
+        cf = net.points_to_field(torch.from_numpy(scan).float())
+        uf = net.points_to_field(torch.zeros(1, scan.shape[1], 3))
+        eps = net.classfree_forward(sd, xf, cf, uf, torch.tensor([t]), w=6.0).numpy()
+        x_new = scan + o.step(eps, t, xf.F.numpy().reshape(1, -1, 3) - scan, z)
+        net.points_to_field(torch.from_numpy(x_new).float())
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 full denoising step (CFG pair + DPM-Solver++ update + re-voxelisation) of the same "
+                      f"180k-point scan at trajectory position 50/50 (t={t}, sigma={o.sigma_t[t]:.3f}), "
+                      f"{dt:.1f} s wall, torch-CPU/MKL GEMMs on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline leg)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from lidiff_amd import dist as ldist
+    from lidiff_amd import ops
+    rank, world, local = ldist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    scan_np = load_scan()
+    pipe = build_pipeline(device)
+    total = args.warmup + args.steps
+    x_init, xs, tvals = make_inputs(pipe, scan_np, args.steps, seed=1000 + rank, device=device)
+    # warmup steps reuse the first positions of the schedule
+    wx, wt = xs[:max(1, min(args.warmup, len(xs)))], tvals[:max(1, min(args.warmup, len(xs)))]
+
+    with torch.no_grad():
+        for w in range(args.warmup):
+            run_steps(pipe, x_init, wx, wt, w % len(wx), 1)
+        torch.cuda.synchronize()
+        prof = None if args.no_kernel_events else ops.ConvProfiler()
+        ops.PROFILER = prof
+        ldist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x_last = run_steps(pipe, x_init, xs, tvals, 0, args.steps)
+        torch.cuda.synchronize()
+        ldist.barrier()
+        elapsed = time.perf_counter() - t0
+        ops.PROFILER = None
+        x_last.coordinate_manager.check()
+    elapsed = ldist.max_over_ranks(elapsed, device=device)
+
+    if rank != 0:
+        return
+    out = {
+        "metric": "denoising steps/sec on 180k-pt scan", "value": world * args.steps / elapsed, "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: one 180000-point scan (bundled scan FPS 18000 x10), voxel 0.05 m, "
+                               "T=50 sde-dpmsolver++ trajectory, CFG w=6 (2 forwards/step), fp32, "
+                               "random-init weights, offsets sigma_t*N(0,I) per step",
+                   "points": N_POINTS, "trajectory_positions": [trajectory_index(j, args.steps) for j in range(args.steps)],
+                   "scans_per_gpu": 1, "parallelism": f"scan-sharded x{world}, no data-path collective"},
+    }
+    if prof is not None:
+        summ = prof.summary()
+        dom = max(summ, key=lambda v: summ[v]["ms"])
+        d = summ[dom]
+        tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": f"spconv_fwd_kernel<128,{dom[2:]},32> ({dom})", "bound": "mfma",
+            "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
+            "traffic": None, "launches": d["launches"], "avg_us": 1e3 * d["ms"] / d["launches"],
+            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+            "algorithmic_gbytes_per_launch": d["bytes"] / d["launches"] / 1e9,
+            "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
+            "conv_ms_per_step_all_variants": sum(v["ms"] for v in summ.values()) / args.steps,
+            "variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                             "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                             "alg_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in summ.items()},
+        }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scan_np)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,7 @@ unchanged), same forward semantics:
   BasicDeconvolutionBlock minkunet.py:32-46      MinkUNetDiff    minkunet.py:144-497
   ResidualBlock           minkunet.py:49-80      MinkUNet        minkunet.py:500-619
 
-What is different is the execution plan in eval mode (``fused=True``, the default):
+What is different is the execution plan in eval mode under ``torch.no_grad()`` (the default):
   * eval-mode BatchNorm, ReLU and the residual add are folded into the sparse-conv epilogue
     (one HBM round trip per conv instead of four);
   * ``ME.cat(y, skip)`` is never materialised: the following convs read two sources;
@@ -18,7 +18,8 @@ What is different is the execution plan in eval mode (``fused=True``, the defaul
     only the h x C_l projection;
   * the part->full nearest-voxel indices are computed once per coordinate map (decoder levels
     share the encoder's maps).
-``fused=False`` (or training mode) runs the reference's op order through the ME-API shim.
+``with minkunet.fusion(False)`` (or training mode / grad enabled) runs the reference's op order
+through the ME-API shim.
 """
 from __future__ import annotations
 
@@ -55,8 +56,27 @@ def _bn_affine(bn_mod: ME.MinkowskiBatchNorm):
     return cache[1], cache[2]
 
 
+_FUSION = True
+
+
+class fusion:
+    """``with minkunet.fusion(False):`` runs the reference's op order (every ME op its own launch)
+    even in eval mode; the default fused plan is used only under ``torch.no_grad()`` in eval mode."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _FUSION
+        self.prev, _FUSION = _FUSION, self.enabled
+
+    def __exit__(self, *exc):
+        global _FUSION
+        _FUSION = self.prev
+
+
 def _fusable(*mods) -> bool:
-    return not torch.is_grad_enabled() and not any(m.training for m in mods)
+    return _FUSION and not torch.is_grad_enabled() and not any(m.training for m in mods)
 
 
 def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=None) -> ME.SparseTensor:
@@ -180,7 +200,6 @@ class _Base(nn.Module):
         self.cs = [int(cr * c) for c in CS]
         self.run_up = kwargs.get("run_up", True)
         self.D = kwargs.get("D", 3)
-        self.fused = kwargs.get("fused", True)
         return kwargs.get("in_channels", 3)
 
     def weight_initialization(self):
@@ -279,7 +298,7 @@ class MinkUNetDiff(_Base):
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"                      # minkunet.py:461: cat((t4, p4))
-        if self.fused and _fusable(self):
+        if _fusable(self):
             idx = self.match_index(x, part)
             lat = latent(part.F)                                     # [M_p, 256] instead of [M_l, 256]
             lin1, lin2 = latemp[0], latemp[2]
@@ -305,7 +324,7 @@ class MinkUNetDiff(_Base):
         y = feats[4]
         for j, name in enumerate(_LEVELS[4:]):
             y = _run_up(getattr(self, name), self._condition(name, y, part_feats, temp_emb), feats[3 - j])
-        if self.fused and _fusable(self):
+        if _fusable(self):
             return ops.gather_rows(self.last(y.F), x.inverse_mapping)
         return self.last(y.slice(x).F)
 
@@ -331,6 +350,6 @@ class MinkUNet(_Base):
         y = feats[4]
         for j in range(4):
             y = _run_up(getattr(self, f"up{j + 1}"), y, feats[3 - j])
-        if self.fused and _fusable(self):
+        if _fusable(self):
             return ops.gather_rows(self.last(y.F), x.inverse_mapping)
         return self.last(y.slice(x).F)

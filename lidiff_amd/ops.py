@@ -129,6 +129,47 @@ def rulebook_compact(nbr: torch.Tensor):
     return pin, pout, off
 
 
+class ConvProfiler:
+    """Optional per-launch HIP-event timing of the sparse-conv kernel (bench.py's roofline leg).
+    Events are recorded on the stream the kernel is launched on (torch's current stream).
+    Algorithmic work per launch: flops = 2*P*C_in*C_out,
+    bytes = 4*(M_in*C_in + M_out*C_out) + 4*K*C_in*C_out + 8*P, P = valid pairs of the map."""
+
+    def __init__(self):
+        self.launches = []          # (variant, start, end, m_in, m_out, c_in, c_out, k, pairs_tensor|int)
+        self._pairs = {}
+
+    def pairs(self, nbr, m_out):
+        if nbr is None:
+            return m_out
+        hit = self._pairs.get(id(nbr))
+        if hit is None or hit[0] is not nbr:
+            hit = (nbr, (nbr >= 0).sum())
+            self._pairs[id(nbr)] = hit
+        return hit[1]
+
+    def summary(self):
+        """{variant: dict(launches, ms, flops, bytes)} -- synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for variant, start, end, m_in, m_out, c_in, c_out, k, pairs in self.launches:
+            p = int(pairs) if not isinstance(pairs, torch.Tensor) else int(pairs.item())
+            d = out.setdefault(variant, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += start.elapsed_time(end)
+            d["flops"] += 2.0 * p * c_in * c_out
+            d["bytes"] += 4.0 * (m_in * c_in + m_out * c_out) + 4.0 * k * c_in * c_out + 8.0 * p
+        return out
+
+
+PROFILER: ConvProfiler | None = None
+
+
+def conv_variant(c_out: int) -> str:
+    """Which template instantiation lidiff_spconv_fwd dispatches to (BN = output-channel tile)."""
+    return "bn128" if c_out % 128 == 0 else "bn96" if c_out % 96 == 0 else "bn64" if c_out % 64 == 0 else "bn32"
+
+
 def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
                relu: bool = False) -> torch.Tensor:
@@ -153,8 +194,16 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         residual = residual.contiguous()
         assert residual.shape == (m_out, c_out)
     out = torch.empty((m_out, c_out), dtype=torch.float32, device=in_a.device)
+    prof = PROFILER
+    if prof is not None:
+        pairs = prof.pairs(nbr, m_out)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(w), ptr(nbr), k, in_a.shape[0], m_out,
          c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), stream_ptr())
+    if prof is not None:
+        end.record()
+        prof.launches.append((conv_variant(c_out), start, end, in_a.shape[0], m_out, c_in, c_out, k, pairs))
     return out
 
 

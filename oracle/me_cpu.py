@@ -200,12 +200,19 @@ def argmin_match(full_c: np.ndarray, part_c: np.ndarray) -> np.ndarray:
     scale = int(f.max()) * 2
     f[:, 0] *= scale
     p[:, 0] *= scale
-    idx = np.empty(f.shape[0], np.int64)
-    step = max(1, (1 << 24) // max(1, p.shape[0]))
-    for s in range(0, f.shape[0], step):
-        d = ((f[s:s + step, None, :] - p[None, :, :]) ** 2).sum(-1)
-        idx[s:s + step] = d.argmin(1)           # numpy argmin returns the first minimum
-    return idx
+    # brute force as one GEMM per chunk: |f|^2 + |p|^2 - 2 f.p is exact in floating point while
+    # every intermediate integer stays below the mantissa range (checked, float64 otherwise); torch.argmin returns the FIRST minimum, i.e. the lowest index on ties.
+    bound = 4 * (int(np.abs(f).max()) + int(np.abs(p).max())) ** 2     # every intermediate below this
+    dt = torch.float32 if bound < (1 << 24) else torch.float64           # float32 is exact below 2^24
+    ft, pt = torch.from_numpy(f).to(dt), torch.from_numpy(p).to(dt)
+    p2 = (pt * pt).sum(1)[None, :]
+    idx = torch.empty(ft.shape[0], dtype=torch.int64)
+    step = max(1, (1 << 25) // max(1, pt.shape[0]))
+    for s in range(0, ft.shape[0], step):
+        fc = ft[s:s + step]
+        d = (fc * fc).sum(1)[:, None] + p2 - 2.0 * (fc @ pt.t())
+        idx[s:s + step] = torch.argmin(d, dim=1)
+    return idx.numpy()
 
 
 # --------------------------------------------------------------------------------------

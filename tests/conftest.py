@@ -51,3 +51,36 @@ def noisy_scan_points(fps_scan, sigma, seed, n_rep=10):
     rng = np.random.default_rng(seed)
     base = np.tile(fps_scan.astype(np.float32), (n_rep, 1))
     return (base + sigma * rng.standard_normal(base.shape).astype(np.float32)).astype(np.float32)
+
+
+def small_scene(seed=5, n=2000):
+    """Tiny stand-in for a scan: n/10 'partial' points tiled x10 plus noise (float32 metres)."""
+    rng = np.random.default_rng(seed)
+    part = (rng.standard_normal((n // 10, 3)) * np.array([4.0, 4.0, 0.5])).astype(np.float32)
+    scan = np.tile(part, (10, 1))
+    noisy = (scan + 0.3 * rng.standard_normal(scan.shape)).astype(np.float32)
+    return scan, noisy
+
+
+def build_seeded_models(seed=42):
+    """MinkGlobalEnc, MinkUNetDiff, MinkUNet(18) with seeded weights and non-trivial BatchNorm
+    statistics (CPU tensors).  Shared by make_golden.py and the parity tests."""
+    from lidiff_amd import minkunet as product
+    torch.manual_seed(seed)
+    enc = product.MinkGlobalEnc(in_channels=3)
+    unet = product.MinkUNetDiff(in_channels=3)
+    refine = product.MinkUNet(in_channels=3, out_channels=18)
+    for mod in (enc, unet, refine):
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.8, 1.2)
+                m.bias.data.normal_(0, 0.1)
+    return enc.eval(), unet.eval(), refine.eval()
+
+
+def diffusion_state_dict(enc, unet):
+    sd = {"partial_enc." + k: v for k, v in enc.state_dict().items()}
+    sd.update({"model." + k: v for k, v in unet.state_dict().items()})
+    return sd

@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-from conftest import random_cloud  # noqa: E402
+from conftest import build_seeded_models, diffusion_state_dict, random_cloud, small_scene  # noqa: E402
 from oracle import me_cpu as me  # noqa: E402
 from oracle import minkunet_cpu as net  # noqa: E402
 from oracle.dpm_solver import DpmSolverSdeOracle  # noqa: E402
@@ -106,28 +106,9 @@ def make_dpm():
     np.savez_compressed(os.path.join(HERE, "dpm_trajectory.npz"), **out)
 
 
-def small_scene(seed=5, n=2000):
-    rng = np.random.default_rng(seed)
-    part = (rng.standard_normal((n // 10, 3)) * np.array([4.0, 4.0, 0.5])).astype(np.float32)
-    scan = np.tile(part, (10, 1))
-    noisy = (scan + 0.3 * rng.standard_normal(scan.shape)).astype(np.float32)
-    return scan, noisy
-
-
 def make_unet():
-    from lidiff_amd import minkunet as product
-    torch.manual_seed(42)
-    enc, unet, refine = product.MinkGlobalEnc(in_channels=3), product.MinkUNetDiff(in_channels=3), \
-        product.MinkUNet(in_channels=3, out_channels=18)
-    for mod in (enc, unet, refine):           # non-trivial BN statistics
-        for m in mod.modules():
-            if isinstance(m, torch.nn.BatchNorm1d):
-                m.running_mean.normal_(0, 0.1)
-                m.running_var.uniform_(0.5, 1.5)
-                m.weight.data.uniform_(0.8, 1.2)
-                m.bias.data.normal_(0, 0.1)
-    sd = {"partial_enc." + k: v for k, v in enc.state_dict().items()}
-    sd.update({"model." + k: v for k, v in unet.state_dict().items()})
+    enc, unet, refine = build_seeded_models(42)
+    sd = diffusion_state_dict(enc, unet)
     scan, noisy = small_scene()
     with torch.no_grad():
         xf = net.points_to_field(torch.from_numpy(noisy)[None])

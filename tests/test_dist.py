@@ -1,0 +1,80 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: scan sharding (no collective on the data path),
+the bench's max-over-ranks timing reduction, and the data-parallel gradient all-reduce."""
+import os
+import socket
+
+import torch
+import torch.distributed as tdist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, result_q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from lidiff_amd import dist as ldist
+    r, w, _ = ldist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    out = {"shard": ldist.shard_items(7, r, w)}
+    out["max"] = ldist.max_over_ranks(1.0 + rank)
+    out["sum"] = ldist.sum_over_ranks(10.0 * (rank + 1))
+    # data-parallel step: same init everywhere after broadcast, different data per rank
+    torch.manual_seed(100 + rank)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    ldist.broadcast_parameters(model)
+    out["w0"] = model[0].weight.detach().clone()
+    x = torch.randn(4, 6)
+    model(x).pow(2).sum().backward()
+    local = [p.grad.clone() for p in model.parameters()]
+    ldist.GradAllReducer(model.parameters(), bucket_bytes=64).all_reduce()      # tiny buckets: several collectives
+    out["avg"] = [p.grad.clone() for p in model.parameters()]
+    gathered = [None] * world
+    tdist.all_gather_object(gathered, local)
+    out["want"] = [sum(g[i] for g in gathered) / world for i in range(len(local))]
+    # bf16 transport path
+    model.zero_grad()
+    model(x).pow(2).sum().backward()
+    ldist.GradAllReducer(model.parameters(), transport_dtype=torch.bfloat16).all_reduce()
+    out["avg_bf16"] = [p.grad.clone() for p in model.parameters()]
+    ldist.barrier()
+    plain = lambda v: v.tolist() if isinstance(v, torch.Tensor) else ([plain(e) for e in v] if isinstance(v, list) else v)
+    result_q.put((rank, {k: plain(v) for k, v in out.items()}))   # plain lists: no shared-memory handles
+    tdist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0]["shard"] == [0, 2, 4, 6] and results[1]["shard"] == [1, 3, 5]
+    assert sorted(results[0]["shard"] + results[1]["shard"]) == list(range(7))
+    for r in range(world):
+        assert results[r]["max"] == 2.0 and results[r]["sum"] == 30.0
+        assert results[r]["w0"] == results[0]["w0"]
+        for got, want, got16 in zip(results[r]["avg"], results[r]["want"], results[r]["avg_bf16"]):
+            assert torch.allclose(torch.tensor(got), torch.tensor(want), atol=1e-6)
+            assert torch.allclose(torch.tensor(got16), torch.tensor(want), rtol=2e-2, atol=2e-2)
+    assert results[0]["avg"] == results[1]["avg"]
+
+
+def test_single_process_is_a_noop():
+    from lidiff_amd import dist as ldist
+    assert ldist.shard_items(3, 0, 1) == [0, 1, 2]
+    assert ldist.max_over_ranks(3.5) == 3.5
+    m = torch.nn.Linear(2, 2)
+    m(torch.ones(1, 2)).sum().backward()
+    g = m.weight.grad.clone()
+    ldist.GradAllReducer(m.parameters()).all_reduce()
+    assert torch.equal(m.weight.grad, g)

@@ -1,0 +1,243 @@
+"""GPU parity tests (pytest -m gpu): every HIP kernel, called through the C ABI, against the CPU
+oracle on the same seeded inputs and against the committed golden vectors.
+Integer / index outputs are compared BIT-EXACT; fp32 feature outputs within rtol 1e-4 / atol 1e-4
+(sum order differs: the oracle adds offsets in ascending k with MKL dot products, the device
+accumulates an fma chain per offset).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, noisy_scan_points, random_cloud
+from oracle import me_cpu as me
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-4
+
+
+def dev_i32(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+
+def status(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def check_maps(coords_np, device):
+    """voxelize + 4 stride levels + kernel maps on device vs oracle, all bit-exact."""
+    from lidiff_amd import ops
+    st = status(device)
+    uniq, inv, first, table = ops.vox_unique(dev_i32(coords_np, device), st)
+    o_uniq, o_inv, o_first = me.voxelize(coords_np)
+    assert np.array_equal(uniq.cpu().numpy(), o_uniq)
+    assert np.array_equal(inv.cpu().numpy(), o_inv)
+    assert np.array_equal(first.cpu().numpy(), o_first)
+    nbr3 = ops.kernel_map(uniq, table, 3, 1)
+    assert np.array_equal(nbr3.cpu().numpy(), me.kernel_map(o_uniq, o_uniq, 3, 1))
+    cur, cur_t, o_cur, ts = uniq, table, o_uniq, 1
+    for _ in range(4):
+        coarse, parent, ctable = ops.map_stride(cur, ts * 2, st)
+        o_coarse, o_parent = me.stride_map(o_cur, ts * 2)
+        assert np.array_equal(coarse.cpu().numpy(), o_coarse)
+        assert np.array_equal(parent.cpu().numpy(), o_parent)
+        down = ops.kernel_map(coarse, cur_t, 2, ts)
+        o_down = me.kernel_map(o_cur, o_coarse, 2, ts)
+        assert np.array_equal(down.cpu().numpy(), o_down)
+        up = ops.kernel_map_up(cur, parent, ts)
+        assert np.array_equal(up.cpu().numpy(), me.transpose_kernel_map(o_down, o_cur.shape[0]))
+        k3 = ops.kernel_map(coarse, ctable, 3, ts * 2)
+        assert np.array_equal(k3.cpu().numpy(), me.kernel_map(o_coarse, o_coarse, 3, ts * 2))
+        cur, cur_t, o_cur, ts = coarse, ctable, o_coarse, ts * 2
+    assert int(st.item()) == 0
+    return nbr3
+
+
+@pytest.mark.parametrize("n,extent,batch,seed", [(1, 3, 1, 0), (77, 2, 1, 1), (5000, 12, 2, 2), (40000, 40, 3, 3)])
+def test_voxel_hash_maps_random(device, n, extent, batch, seed):
+    check_maps(random_cloud(n, extent, seed, batch=batch), device)
+
+
+def test_voxel_hash_degenerate(device):
+    from lidiff_amd import ops
+    check_maps(np.zeros((180, 4), np.int32), device)                      # x_uncond: one voxel
+    c = random_cloud(3000, 30, 5)
+    c[:, 1:] -= 500                                                        # all-negative coordinates
+    check_maps(c, device)
+    two = np.concatenate([random_cloud(500, 4, 6), random_cloud(500, 4, 6)])   # identical clouds, 2 batches
+    two[500:, 0] = 1
+    check_maps(two, device)
+    st = status(device)
+    uniq, inv, first, _ = ops.vox_unique(torch.zeros((0, 4), dtype=torch.int32, device=device), st)
+    assert uniq.shape[0] == 0 and inv.shape[0] == 0
+    bad = np.array([[0, 40000, 0, 0], [0, 1, 2, 3]], np.int32)            # outside the 16-bit key range
+    ops.vox_unique(dev_i32(bad, device), st)
+    assert int(st.item()) & ops.STATUS_KEY_RANGE
+
+
+def test_golden_coords(device):
+    from lidiff_amd import ops
+    g = np.load(os.path.join(GOLDEN, "coords_small.npz"))
+    st = status(device)
+    uniq, inv, first, table = ops.vox_unique(dev_i32(g["coords"], device), st)
+    assert np.array_equal(uniq.cpu().numpy(), g["uniq"])
+    assert np.array_equal(inv.cpu().numpy(), g["inverse"])
+    assert np.array_equal(first.cpu().numpy(), g["first_idx"])
+    nbr = ops.kernel_map(uniq, table, 3, 1)
+    assert np.array_equal(nbr.cpu().numpy(), g["nbr3_l0"])
+    pin, pout, ptr = ops.rulebook_compact(nbr)
+    assert np.array_equal(ptr.cpu().numpy(), g["rb_ptr"])
+    assert np.array_equal(pin.cpu().numpy(), g["rb_in"]) and np.array_equal(pout.cpu().numpy(), g["rb_out"])
+    cur, cur_t, ts = uniq, table, 1
+    for lvl in range(1, 5):
+        coarse, parent, ctable = ops.map_stride(cur, ts * 2, st)
+        assert np.array_equal(coarse.cpu().numpy(), g[f"coarse{lvl}"])
+        assert np.array_equal(parent.cpu().numpy(), g[f"parent{lvl}"])
+        assert np.array_equal(ops.kernel_map(coarse, cur_t, 2, ts).cpu().numpy(), g[f"nbr_down{lvl}"])
+        cur, cur_t, ts = coarse, ctable, ts * 2
+
+
+def test_floor_and_mean(device, fps_scan):
+    from lidiff_amd import ops
+    pts = noisy_scan_points(fps_scan, 0.05, 0, n_rep=3)
+    feats = torch.from_numpy(pts)
+    cf = torch.cat([torch.zeros(pts.shape[0], 1), torch.round(feats / 0.05)], 1) - 0.25   # non-integral on purpose
+    ci = ops.coords_floor(cf.to(device))
+    assert np.array_equal(ci.cpu().numpy(), me.quantize_floor(cf.numpy()))
+    uniq, inv, _, _ = ops.vox_unique(ci, status(device))
+    out, counts = ops.vox_mean(feats.to(device), inv, uniq.shape[0])
+    want = me.voxel_mean(feats, inv.cpu().numpy(), uniq.shape[0])
+    assert torch.allclose(out.cpu(), want, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(inv.cpu().numpy(), minlength=uniq.shape[0]))
+
+
+def conv_case(device, coords_np, cin, cout, kind, seed, epilogue=False, split=0):
+    """kind: 'k3' | 'down' | 'up' | 'k1'."""
+    from lidiff_amd import ops
+    uniq, _, _ = me.voxelize(coords_np)
+    coarse, parent = me.stride_map(uniq, 2)
+    if kind == "k3":
+        nbr, m_in, m_out, K = me.kernel_map(uniq, uniq, 3, 1), uniq.shape[0], uniq.shape[0], 27
+    elif kind == "down":
+        nbr, m_in, m_out, K = me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0], coarse.shape[0], 8
+    elif kind == "up":
+        nbr = me.transpose_kernel_map(me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0])
+        m_in, m_out, K = coarse.shape[0], uniq.shape[0], 8
+    else:
+        nbr, m_in, m_out, K = None, uniq.shape[0], uniq.shape[0], 1
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(m_in, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) / np.sqrt(cin * max(1, K // 3))
+    want = me.conv_forward(x.double(), w.double() if K > 1 else w[0].double(), nbr)
+    scale = shift = res = None
+    relu = False
+    if epilogue:
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        res = torch.randn(m_out, cout, generator=g)
+        relu = True
+        want = torch.relu(want * scale.double() + shift.double() + res.double())
+    d = lambda t: None if t is None else t.to(device)
+    nbr_d = None if nbr is None else dev_i32(nbr, device)
+    if split:
+        got = ops.spconv_fwd(d(x[:, :split].contiguous()), d(w), nbr_d, m_out, in_b=d(x[:, split:].contiguous()),
+                             scale=d(scale), shift=d(shift), residual=d(res), relu=relu)
+    else:
+        got = ops.spconv_fwd(d(x), d(w), nbr_d, m_out, scale=d(scale), shift=d(shift), residual=d(res), relu=relu)
+    torch.cuda.synchronize()
+    err = (got.cpu().double() - want).abs().max().item()
+    assert torch.allclose(got.cpu().double(), want, rtol=RTOL, atol=ATOL), f"{kind} {cin}->{cout}: max err {err}"
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 32), (32, 32), (32, 64), (64, 128), (96, 96), (128, 256), (384, 256)])
+def test_spconv_k3_channels(device, cin, cout):
+    conv_case(device, random_cloud(3000, 6, cin + cout, batch=2), cin, cout, "k3", seed=cin)
+
+
+@pytest.mark.parametrize("kind,cin,cout", [("down", 32, 32), ("down", 128, 128), ("up", 256, 256), ("up", 128, 96),
+                                           ("k1", 32, 64), ("k1", 384, 256), ("k1", 128, 96)])
+def test_spconv_other_kinds(device, kind, cin, cout):
+    conv_case(device, random_cloud(2500, 7, 17), cin, cout, kind, seed=3)
+
+
+def test_spconv_epilogue_and_split_input(device):
+    c = random_cloud(2000, 5, 23)
+    conv_case(device, c, 64, 64, "k3", seed=1, epilogue=True)
+    conv_case(device, c, 192, 128, "k3", seed=2, epilogue=True, split=128)      # fused ME.cat (128 | 64)
+    conv_case(device, c, 128, 96, "k1", seed=3, epilogue=True, split=96)         # downsample conv on cat
+    conv_case(device, c, 3, 32, "k3", seed=4, epilogue=True)                      # scalar (non-float4) path
+
+
+def test_spconv_degenerate_shapes(device):
+    conv_case(device, np.zeros((5, 4), np.int32), 32, 32, "k3", seed=0)          # a single voxel
+    conv_case(device, random_cloud(129, 50, 1, dup=0.0), 32, 32, "k3", seed=0)  # isolated voxels, ragged tile
+    conv_case(device, random_cloud(4000, 2, 2), 64, 64, "k3", seed=0)            # dense 5^3 block: all 27 neighbours
+
+
+def test_golden_conv(device):
+    from lidiff_amd import ops
+    g = np.load(os.path.join(GOLDEN, "coords_small.npz"))
+    cv = np.load(os.path.join(GOLDEN, "conv_small.npz"))
+    d = lambda a: torch.from_numpy(a).to(device)
+    m0, m1 = g["uniq"].shape[0], g["coarse1"].shape[0]
+    y3 = ops.spconv_fwd(d(cv["x0"]), d(cv["w3"]), dev_i32(g["nbr3_l0"], device), m0)
+    yd = ops.spconv_fwd(d(cv["x0"]), d(cv["w2"]), dev_i32(g["nbr_down1"], device), m1)
+    yu = ops.spconv_fwd(yd, d(cv["wt"]), dev_i32(cv["nbr_up1"], device), m0)
+    y1 = ops.spconv_fwd(d(cv["x0"]), d(cv["w1"]), None, m0)
+    for got, name in ((y3, "y3"), (yd, "yd"), (yu, "yu"), (y1, "y1")):
+        assert torch.allclose(got.cpu(), torch.from_numpy(cv[name]), rtol=RTOL, atol=ATOL), name
+
+
+def test_spconv_linearity_full_size(device, fps_scan):
+    """Size-independent property at BASELINE's full size (180k points): conv(a*x + y) ==
+    a*conv(x) + conv(y), and a one-hot centre kernel is the identity."""
+    from lidiff_amd import ops
+    pts = noisy_scan_points(fps_scan, 0.2, 1)
+    cf = torch.cat([torch.zeros(pts.shape[0], 1), torch.round(torch.from_numpy(pts) / 0.05)], 1)
+    ci = ops.coords_floor(cf.to(device))
+    uniq, _, _, table = ops.vox_unique(ci, status(device))
+    m = uniq.shape[0]
+    assert 150000 < m <= 180000
+    nbr = ops.kernel_map(uniq, table, 3, 1)
+    # symmetry of the kernel map: nbr[k][o] = i  <=>  nbr[26-k][i] = o
+    k = 5
+    o = torch.nonzero(nbr[k] >= 0).squeeze(1)
+    assert torch.equal(nbr[26 - k][nbr[k][o].long()].long(), o)
+    assert torch.equal(nbr[13], torch.arange(m, dtype=torch.int32, device=device))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x, y = torch.randn(m, 32, generator=g).to(device), torch.randn(m, 32, generator=g).to(device)
+    w = (torch.randn(27, 32, 32, generator=g) * 0.1).to(device)
+    lhs = ops.spconv_fwd(2.5 * x + y, w, nbr, m)
+    rhs = 2.5 * ops.spconv_fwd(x, w, nbr, m) + ops.spconv_fwd(y, w, nbr, m)
+    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-4)
+    w_id = torch.zeros(27, 32, 32, device=device)
+    w_id[13] = torch.eye(32, device=device)
+    assert torch.equal(ops.spconv_fwd(x, w_id, nbr, m), x)
+    # determinism: no atomics in the conv path
+    assert torch.equal(ops.spconv_fwd(x, w, nbr, m), ops.spconv_fwd(x, w, nbr, m))
+
+
+def test_gather_scatter_rows(device):
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for c in (3, 96):
+        src = torch.randn(500, c, generator=g)
+        idx = torch.randint(0, 500, (2000,), generator=g)
+        assert torch.equal(ops.gather_rows(src.to(device), idx.to(device)).cpu(), src[idx])
+        vals = torch.randn(2000, c, generator=g)
+        want = torch.zeros(500, c).index_add_(0, idx, vals)
+        assert torch.allclose(ops.scatter_add_rows(vals.to(device), idx.to(device), 500).cpu(), want, atol=1e-4)
+
+
+def test_nn_match(device):
+    from lidiff_amd import ops
+    full = random_cloud(5000, 60, 3, batch=2)
+    part = me.voxelize(me.floor_to_stride(random_cloud(1500, 60, 4, batch=2), 16))[0]
+    got = ops.nn_match(dev_i32(full, device), dev_i32(part, device)).cpu().numpy()
+    assert np.array_equal(got, me.argmin_match(full, part))
+    one = np.zeros((1, 4), np.int32)                                   # x_uncond: a single part voxel
+    assert np.all(ops.nn_match(dev_i32(full, device), dev_i32(one, device)).cpu().numpy() == 0)
+    f = np.array([[0, 0, 0, 0]], np.int32)                             # exact tie -> lowest index
+    p = np.array([[0, 2, 0, 0], [0, -2, 0, 0], [0, 0, 2, 0]], np.int32)
+    assert ops.nn_match(dev_i32(f, device), dev_i32(p, device)).item() == 0

@@ -1,0 +1,186 @@
+"""CPU tests (no GPU): host logic of the product package and the C-ABI library's surface.
+No compute kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from lidiff_amd import _lib
+    from lidiff_amd.csrc import build
+    path = build.build()
+    assert os.path.exists(path)
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "lidiff_amd.h")).read()
+    declared = set(re.findall(r"\b(lidiff_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+    assert lib.lidiff_abi_version() == 1
+    assert lib.lidiff_hash_capacity(180000) == 524288 and lib.lidiff_hash_capacity(1) == 1024
+    assert lib.lidiff_unique_workspace_bytes(1000) >= 1000 * 4
+    # host-side argument validation reaches the error string without touching a device
+    rc = lib.lidiff_spconv_fwd(None, 0, None, 0, None, None, 1, 0, 0, 32, None, None, None, None, 0, None)
+    assert rc != 0 and b"lidiff_spconv_fwd" in lib.lidiff_last_error()
+
+
+def test_operators_refuse_cpu_tensors():
+    import lidiff_amd.MinkowskiEngine as ME
+    from lidiff_amd import ops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.coords_floor(torch.zeros(4, 4))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ME.TensorField(features=torch.zeros(4, 3), coordinates=torch.zeros(4, 4))
+
+
+def test_no_product_import_of_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lidiff_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def expected_keys_unet(with_cond: bool, out_channels: int):
+    cs = [32, 32, 64, 128, 256, 256, 128, 96, 96]
+    exp = {}
+
+    def bn(p, c):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            exp[f"{p}.bn.{k}"] = (c,)
+        exp[f"{p}.bn.num_batches_tracked"] = ()
+
+    def res(p, a, b):
+        exp[f"{p}.net.0.kernel"] = (27, a, b); bn(f"{p}.net.1", b)
+        exp[f"{p}.net.3.kernel"] = (27, b, b); bn(f"{p}.net.4", b)
+        if a != b:
+            exp[f"{p}.downsample.0.kernel"] = (a, b); bn(f"{p}.downsample.1", b)
+
+    def lin(p, a, b):
+        exp[f"{p}.weight"] = (b, a); exp[f"{p}.bias"] = (b,)
+
+    exp["stem.0.kernel"] = (27, 3, 32); bn("stem.1", 32); exp["stem.3.kernel"] = (27, 32, 32); bn("stem.4", 32)
+    for n in range(4):
+        p = f"stage{n + 1}"
+        exp[f"{p}.0.net.0.kernel"] = (8, cs[n], cs[n]); bn(f"{p}.0.net.1", cs[n])
+        res(f"{p}.1", cs[n], cs[n + 1]); res(f"{p}.2", cs[n + 1], cs[n + 1])
+    for j in range(4):
+        p = f"up{j + 1}"
+        exp[f"{p}.0.net.0.kernel"] = (8, cs[4 + j], cs[5 + j]); bn(f"{p}.0.net.1", cs[5 + j])
+        res(f"{p}.1.0", cs[5 + j] + cs[3 - j], cs[5 + j]); res(f"{p}.1.1", cs[5 + j], cs[5 + j])
+    lin("last.0", 96, 20); lin("last.2", 20, out_channels)
+    if with_cond:
+        hid = {"stage1": (32, 256), "stage2": (32, 256), "stage3": (64, 256), "stage4": (128, 256),
+               "up1": (256, 256), "up2": (256, 256), "up3": (128, 128), "up4": (96, 96)}
+        for name, (cx, h) in hid.items():
+            lin(f"latent_{name}.0", 256, 256); lin(f"latent_{name}.2", 256, 256)
+            lin(f"latemp_{name}.0", 512, h); lin(f"latemp_{name}.2", h, cx)
+            lin(f"{name}_temp.0", 96, 96); lin(f"{name}_temp.2", 96, 256)
+    return exp
+
+
+def test_state_dict_is_checkpoint_compatible():
+    """Key names and shapes of the reference's module tree (SURVEY.md 8b, Appendix C counts)."""
+    from lidiff_amd import minkunet
+    unet = minkunet.MinkUNetDiff(in_channels=3, out_channels=96)
+    sd = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
+    assert sd == expected_keys_unet(True, 3)
+    assert sd["stage2.1.downsample.0.kernel"] == (32, 64) and sd["up1.0.net.0.kernel"] == (8, 256, 256)
+    assert sd["latemp_up1.0.weight"] == (256, 512) and sd["stem.1.bn.running_mean"] == (32,)
+    refine = minkunet.MinkUNet(in_channels=3, out_channels=18)
+    assert {k: tuple(v.shape) for k, v in refine.state_dict().items()} == expected_keys_unet(False, 18)
+    enc = minkunet.MinkGlobalEnc(in_channels=3, out_channels=96)
+    enc_keys = {k for k in expected_keys_unet(False, 3) if k.startswith(("stem", "stage"))}
+    assert set(enc.state_dict()) == enc_keys
+    n = lambda m: sum(p.numel() for p in m.parameters())
+    assert n(unet) + n(enc) == 32_672_467 and n(refine) == 21_722_926
+    # BatchNorm init of weight_initialization (minkunet.py:128-132)
+    assert torch.all(unet.stem[1].bn.weight == 1) and torch.all(unet.stem[1].bn.bias == 0)
+    # a reference-format checkpoint round-trips through the pipeline's loading convention
+    ck = {"model." + k: v for k, v in unet.state_dict().items()}
+    holder = torch.nn.Module()
+    holder.model = minkunet.MinkUNetDiff(in_channels=3)
+    missing = holder.load_state_dict(ck, strict=False)
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def test_sync_batchnorm_conversion():
+    import lidiff_amd.MinkowskiEngine as ME
+    from lidiff_amd import minkunet
+    net = minkunet.MinkGlobalEnc(in_channels=3)
+    net.stem[1].bn.running_mean.fill_(0.25)
+    net = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(net)
+    bns = [m for m in net.modules() if isinstance(m, ME.MinkowskiBatchNorm)]
+    assert bns and all(isinstance(m, ME.MinkowskiSyncBatchNorm) and isinstance(m.bn, torch.nn.SyncBatchNorm) for m in bns)
+    assert torch.all(net.stem[1].bn.running_mean == 0.25)
+    assert "stem.1.bn.weight" in net.state_dict()
+
+
+def test_scheduler_matches_oracle_on_cpu():
+    from lidiff_amd.schedulers import DPMSolverMultistepScheduler
+    g = np.load(os.path.join(GOLDEN, "dpm_trajectory.npz"))
+    for n in (50, 8, 1):
+        s = DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_start=3.5e-5, beta_end=0.007,
+                                        beta_schedule="linear", algorithm_type="sde-dpmsolver++", solver_order=2)
+        s.set_timesteps(n)
+        assert s.timesteps.tolist() == g[f"ts{n}"].tolist()
+        x = torch.from_numpy(g[f"traj{n}"][0])
+        for i, t in enumerate(s.host_timesteps):
+            x = s.step(torch.from_numpy(g[f"eps{n}"][i]), torch.tensor(t), x, noise=torch.from_numpy(g[f"z{n}"][i]))["prev_sample"]
+            assert x.dtype == torch.float64
+            assert torch.allclose(x, torch.from_numpy(g[f"traj{n}"][i + 1]), rtol=1e-5, atol=1e-5)
+    for name in ("timesteps", "betas", "alphas", "alphas_cumprod", "alpha_t", "sigma_t", "lambda_t", "sigmas"):
+        assert isinstance(getattr(s, name), torch.Tensor)          # pipeline:58-66 moves exactly these
+    # without injected noise the draw comes from torch's RNG
+    s.set_timesteps(4)
+    torch.manual_seed(0)
+    a = s.step(torch.zeros(1, 8, 3), 999, torch.ones(1, 8, 3))["prev_sample"]
+    assert a.shape == (1, 8, 3) and torch.isfinite(a).all()
+
+
+def test_batched_coordinates_and_ply_io(tmp_path):
+    import lidiff_amd.MinkowskiEngine as ME
+    from lidiff_amd.pipeline import load_pcd, read_ply_points, write_ply_points
+    a, b = torch.rand(5, 3), torch.rand(7, 3)
+    bc = ME.utils.batched_coordinates([a, b], dtype=torch.float32)
+    assert bc.shape == (12, 4) and bc[:5, 0].eq(0).all() and bc[5:, 0].eq(1).all() and torch.equal(bc[5:, 1:], b)
+    pts = np.random.default_rng(0).standard_normal((100, 3))
+    write_ply_points(str(tmp_path / "a.ply"), pts)
+    assert np.array_equal(read_ply_points(str(tmp_path / "a.ply")), pts)
+    with open(tmp_path / "b.ply", "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\n"
+                "property uchar red\nend_header\n1 2 3 9\n4 5 6 9\n")
+    assert read_ply_points(str(tmp_path / "b.ply")).tolist() == [[1, 2, 3], [4, 5, 6]]
+    np.arange(8, dtype=np.float32).tofile(tmp_path / "c.bin")
+    assert load_pcd(str(tmp_path / "c.bin")).tolist() == [[0, 1, 2], [4, 5, 6]]
+    with pytest.raises(ValueError):
+        load_pcd("x.pcd")
+    ref_ply = "/root/reference/lidiff/Datasets/test/000123.ply"
+    if os.path.exists(ref_ply):                        # build container only
+        assert read_ply_points(ref_ply).shape == (125773, 3)
+
+
+def test_farthest_point_sample_and_golden_scan(fps_scan):
+    from lidiff_amd.pipeline import farthest_point_sample
+    pts = torch.from_numpy(np.random.default_rng(1).standard_normal((300, 3)))
+    sel = farthest_point_sample(pts, 20).numpy()
+    assert sel[0] == 0 and len(set(sel.tolist())) == 20
+    d = ((pts[:, None] - pts[sel[:1]][None]) ** 2).sum(-1).squeeze(1)
+    assert sel[1] == int(d.argmax())
+    assert fps_scan.shape == (18000, 3) and fps_scan.dtype == np.float32
+    r = np.sqrt((fps_scan ** 2).sum(1))
+    assert r.min() > 3.5 and r.max() < 50.0
+
+
+def test_q_sample_schedule_constants():
+    from lidiff_amd.diffusion import linear_beta_schedule
+    b = linear_beta_schedule(1000, 3.5e-5, 0.007)
+    acp = torch.cumprod(1 - b, 0)
+    assert abs(float(torch.sqrt(1 - acp[999])) - 0.985) < 2e-3

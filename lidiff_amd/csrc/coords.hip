@@ -48,16 +48,26 @@ __global__ void insert_kernel(const int32_t* __restrict__ coords, int64_t n, int
     bool ok;
     const uint64_t key = pack_key(c.x, c.y, c.z, c.w, ok);
     if (!ok) atomicOr(d_status, LIDIFF_STATUS_KEY_RANGE);
+    // Wave-uniform key (x_uncond: every point in ONE voxel; heavy duplicates): only the first
+    // active lane -- the smallest row index of the wave -- touches the table, the rest reuse its
+    // slot.  Avoids 64-way same-address CAS/min serialisation.
+    const uint32_t k_lo = __builtin_amdgcn_readfirstlane((uint32_t)key);
+    const uint32_t k_hi = __builtin_amdgcn_readfirstlane((uint32_t)(key >> 32));
+    const bool uni = __all(key == (((uint64_t)k_hi << 32) | k_lo));
+    const bool do_insert = !uni || (int32_t)i == __builtin_amdgcn_readfirstlane((int32_t)i);
     uint32_t slot = hash_key(key) & mask;
-    bool placed = false;
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
-        const uint64_t prev = atomicCAS((unsigned long long*)&hkeys[slot],
-                                        (unsigned long long)kEmptyKey, (unsigned long long)key);
-        if (prev == kEmptyKey || prev == key) { placed = true; break; }
-        slot = (slot + 1) & mask;
+    if (do_insert) {
+        bool placed = false;
+        for (uint32_t probe = 0; probe <= mask; ++probe) {
+            const uint64_t prev = atomicCAS((unsigned long long*)&hkeys[slot],
+                                            (unsigned long long)kEmptyKey, (unsigned long long)key);
+            if (prev == kEmptyKey || prev == key) { placed = true; break; }
+            slot = (slot + 1) & mask;
+        }
+        if (!placed) { atomicOr(d_status, LIDIFF_STATUS_HASH_FULL); slot = 0; }
+        atomicMin(&hvals[slot], (int32_t)i);
     }
-    if (!placed) { atomicOr(d_status, LIDIFF_STATUS_HASH_FULL); slot = 0; }
-    atomicMin(&hvals[slot], (int32_t)i);
+    if (uni) slot = __builtin_amdgcn_readfirstlane(slot);
     slot_of[i] = (int32_t)slot;
 }
 
@@ -174,9 +184,24 @@ static int run_unique(const int32_t* coords, int64_t n, int s, uint64_t* hkeys, 
 __global__ void mean_accum_kernel(const float* __restrict__ feats, const int64_t* __restrict__ inverse,
                                   int64_t n, int c, float* __restrict__ out, float* __restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t row = inverse[i];
-    for (int j = 0; j < c; ++j) atomicAdd(&out[row * c + j], feats[i * c + j]);
+    const bool valid = i < n;
+    const int row = valid ? (int)inverse[i] : -1;
+    // all valid lanes of the wave fall in one voxel (x_uncond, heavy duplicates): reduce in the
+    // wave and issue ONE atomic per channel instead of 64 serialised same-address atomics.
+    const int r0 = __shfl(row, __ffsll((long long)__ballot(valid)) - 1);
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0) return;
+    if (__all(!valid || row == r0)) {
+        for (int j = 0; j < c; ++j) {
+            float v = valid ? feats[i * c + j] : 0.f;
+            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane_id() == 0) atomicAdd(&out[(int64_t)r0 * c + j], v);
+        }
+        if (lane_id() == 0) atomicAdd(&counts[r0], (float)__popcll(vm));
+        return;
+    }
+    if (!valid) return;
+    for (int j = 0; j < c; ++j) atomicAdd(&out[(int64_t)row * c + j], feats[i * c + j]);
     atomicAdd(&counts[row], 1.0f);
 }
 

@@ -17,9 +17,11 @@
 // plain LDS read-modify-write is race free).
 //
 // Data movement per K-slab (KS input channels): gathered A rows (coalesced float4, a full
-// 128-byte line per row for KS = 32) and the W[k] slab are prefetched global->registers while
-// the previous slab is being multiplied, then stored to LDS (A padded to KS+1 floats per row:
-// conflict-free ds_read_b32 for the MFMA A operand; B rows are read lane-contiguously).
+// 128-byte line per row for KS = 32) and the W[k] slab are prefetched global->registers TWO
+// slabs ahead (two register sets) so the gather latency overlaps two slabs of MFMA work, then
+// stored to LDS (A rows padded to KS+4 floats: conflict-free ds_read_b128 of 4 consecutive k
+// per lane -- K is consumed in a permuted order shared by both operands; B rows are read
+// lane-contiguously).  Eight waves per workgroup (two per SIMD) share the MFMA pipe.
 //
 // Replaces ME's ConvolutionForwardGPU (gather -> GEMM -> atomic scatter per offset) behind
 // MinkowskiConvolution / MinkowskiConvolutionTranspose; call sites in include/lidiff_amd.h.
@@ -45,21 +47,19 @@ struct ConvParams {
 
 template <int BM, int BN, int KS>
 struct ConvCfg {
-    static constexpr int kThreads = 256;
-    static constexpr int NCB = BN / 32;                                   // 32-col blocks in the tile
-    static constexpr int WC = (NCB % 4 == 0) ? 4 : ((NCB % 2 == 0) ? 2 : 1);  // waves across columns
-    static constexpr int WR = 4 / WC;                                     // waves across row blocks
-    static constexpr int CPW = NCB / WC;                                  // col blocks per wave
-    static constexpr int NRB = BM / 32;
-    static constexpr int RPW = (NRB + WR - 1) / WR;                       // row blocks per wave
-    static constexpr int LDA = KS + 1;
+    static constexpr int kThreads = 512;                 // 8 waves: two per SIMD share the MFMA pipe
+    static constexpr int kWaves = kThreads / 64;
+    static constexpr int NCB = BN / 32;                  // 32-col blocks in the tile
+    static constexpr int NRB = BM / 32;                  // 32-pair row blocks (upper bound)
+    static constexpr int MAXB = (NRB * NCB + kWaves - 1) / kWaves;   // MFMA blocks per wave
+    static constexpr int LDA = KS + 4;                   // 16-B aligned rows, conflict-free b128 reads
     static constexpr int A_VEC = (BM * KS / 4 + kThreads - 1) / kThreads;   // float4 per thread
     static constexpr int B_VEC = (KS * BN / 4 + kThreads - 1) / kThreads;
-    static constexpr int A_SCL = BM * KS / kThreads;
+    static constexpr int A_SCL = (BM * KS + kThreads - 1) / kThreads;
     static constexpr int B_SCL = (KS * BN + kThreads - 1) / kThreads;
     static_assert(BM % 64 == 0 && BM <= 256, "BM");
     static_assert(BN % 32 == 0, "BN");
-    static_assert(KS % 4 == 0 && (BM * KS) % (4 * kThreads) == 0, "KS");
+    static_assert(KS % 8 == 0, "KS");
 
     static size_t lds_bytes(int k_vol) {
         size_t b = (size_t)BM * BN * 4 + (size_t)KS * BN * 4 + (size_t)BM * LDA * 4;
@@ -71,13 +71,14 @@ struct ConvCfg {
 };
 
 template <int BM, int BN, int KS, bool VEC>
-__global__ __launch_bounds__(256) void spconv_fwd_kernel(const ConvParams p) {
+__global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     using Cfg = ConvCfg<BM, BN, KS>;
     constexpr int LDA = Cfg::LDA;
+    constexpr int NT = Cfg::kThreads;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc_lds = reinterpret_cast<float*>(smem);
-    float* Bs = acc_lds + BM * BN;
-    float* As = Bs + KS * BN;
+    float* Bs = acc_lds + BM * BN;                       // [KS][BN]
+    float* As = Bs + KS * BN;                            // [BM][LDA]
     int32_t* in_list = reinterpret_cast<int32_t*>(As + BM * LDA);
     int32_t* cnt = in_list + p.k_vol * BM;
     int32_t* klist = cnt + 64;
@@ -100,13 +101,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const ConvParams p) {
 
     // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
     if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
-        for (int r = tid; r < BM; r += 256) {
+        for (int r = tid; r < BM; r += NT) {
             in_list[r] = (int32_t)(row0 + r);
             out_list[r] = (uint8_t)r;
         }
         if (tid == 0) cnt[0] = rows_here;
     } else {
-        for (int k = wave; k < p.k_vol; k += 4) {
+        for (int k = wave; k < p.k_vol; k += Cfg::kWaves) {
             int pos = 0;
             for (int c = 0; c < BM; c += 64) {
                 const int r = c + lane;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const ConvParams p) {
         }
     }
     // ---- zero the accumulator tile -----------------------------------------------------------
-    for (int e = tid; e < BM * BN / 4; e += 256)
+    for (int e = tid; e < BM * BN / 4; e += NT)
         reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     int nact;
@@ -140,19 +141,22 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const ConvParams p) {
     const int nslab = (p.c_in + KS - 1) / KS;
     const int nit = nact * nslab;
 
-    float4 a_v[Cfg::A_VEC];
-    float4 b_v[Cfg::B_VEC];
-    float a_s[VEC ? 1 : Cfg::A_SCL];
-    float b_s[VEC ? 1 : Cfg::B_SCL];
+    struct Regs {
+        float4 a_v[VEC ? Cfg::A_VEC : 1];
+        float4 b_v[VEC ? Cfg::B_VEC : 1];
+        float a_s[VEC ? 1 : Cfg::A_SCL];
+        float b_s[VEC ? 1 : Cfg::B_SCL];
+    };
 
-    auto prefetch = [&](int it) {
+    // global -> registers for slab `it` (zero-filled beyond n_k rows / c_in channels)
+    auto prefetch = [&](int it, Regs& rg) {
         const int k = klist[it / nslab];
         const int k0 = (it % nslab) * KS;
         const int n_k = cnt[k];
         if constexpr (VEC) {
 #pragma unroll
             for (int j = 0; j < Cfg::A_VEC; ++j) {
-                const int e = tid + j * 256;
+                const int e = tid + j * NT;
                 const int pos = e / (KS / 4), col = k0 + 4 * (e % (KS / 4));
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (pos < n_k && col < p.c_in) {
@@ -161,138 +165,144 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(const ConvParams p) {
                                                         : p.in_b + row * p.c_in_b + (col - p.c_in_a);
                     v = *reinterpret_cast<const float4*>(src);
                 }
-                a_v[j] = v;
+                rg.a_v[j] = v;
             }
 #pragma unroll
             for (int j = 0; j < Cfg::B_VEC; ++j) {
-                const int e = tid + j * 256;
+                const int e = tid + j * NT;
                 const int kr = e / (BN / 4), cq = e % (BN / 4);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < KS * BN / 4 && k0 + kr < p.c_in)
                     v = *reinterpret_cast<const float4*>(
                         p.w + ((int64_t)k * p.c_in + k0 + kr) * p.c_out + n0 + 4 * cq);
-                b_v[j] = v;
+                rg.b_v[j] = v;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < Cfg::A_SCL; ++j) {
-                const int e = tid + j * 256;
+                const int e = tid + j * NT;
                 const int pos = e / KS, col = k0 + e % KS;
                 float v = 0.f;
-                if (pos < n_k && col < p.c_in) {
+                if (e < BM * KS && pos < n_k && col < p.c_in) {
                     const int64_t row = in_list[k * BM + pos];
                     v = (col < p.c_in_a) ? p.in_a[row * p.c_in_a + col]
                                          : p.in_b[row * p.c_in_b + (col - p.c_in_a)];
                 }
-                a_s[j] = v;
+                rg.a_s[j] = v;
             }
 #pragma unroll
             for (int j = 0; j < Cfg::B_SCL; ++j) {
-                const int e = tid + j * 256;
+                const int e = tid + j * NT;
                 const int kr = e / BN, cc = e % BN;
                 float v = 0.f;
                 if (e < KS * BN && k0 + kr < p.c_in)
                     v = p.w[((int64_t)k * p.c_in + k0 + kr) * p.c_out + n0 + cc];
-                b_s[j] = v;
+                rg.b_s[j] = v;
             }
         }
     };
 
-    auto store_slab = [&]() {
+    auto store_slab = [&](const Regs& rg) {
         if constexpr (VEC) {
 #pragma unroll
             for (int j = 0; j < Cfg::A_VEC; ++j) {
-                const int e = tid + j * 256;
-                float* dst = As + (e / (KS / 4)) * LDA + 4 * (e % (KS / 4));
-                dst[0] = a_v[j].x; dst[1] = a_v[j].y; dst[2] = a_v[j].z; dst[3] = a_v[j].w;
+                const int e = tid + j * NT;
+                if (e < BM * KS / 4)
+                    *reinterpret_cast<float4*>(As + (e / (KS / 4)) * LDA + 4 * (e % (KS / 4))) = rg.a_v[j];
             }
 #pragma unroll
             for (int j = 0; j < Cfg::B_VEC; ++j) {
-                const int e = tid + j * 256;
-                if (e < KS * BN / 4) reinterpret_cast<float4*>(Bs)[e] = b_v[j];
+                const int e = tid + j * NT;
+                if (e < KS * BN / 4) reinterpret_cast<float4*>(Bs)[e] = rg.b_v[j];
             }
         } else {
 #pragma unroll
             for (int j = 0; j < Cfg::A_SCL; ++j) {
-                const int e = tid + j * 256;
-                As[(e / KS) * LDA + e % KS] = a_s[j];
+                const int e = tid + j * NT;
+                if (e < BM * KS) As[(e / KS) * LDA + e % KS] = rg.a_s[j];
             }
 #pragma unroll
             for (int j = 0; j < Cfg::B_SCL; ++j) {
-                const int e = tid + j * 256;
-                if (e < KS * BN) Bs[e] = b_s[j];
+                const int e = tid + j * NT;
+                if (e < KS * BN) Bs[e] = rg.b_s[j];
             }
         }
     };
 
-    const int wc = wave % Cfg::WC, wr = wave / Cfg::WC;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    floatx16 acc[Cfg::RPW][Cfg::CPW];
+    floatx16 acc[Cfg::MAXB];
 #pragma unroll
-    for (int ri = 0; ri < Cfg::RPW; ++ri)
+    for (int s = 0; s < Cfg::MAXB; ++s)
 #pragma unroll
-        for (int ci = 0; ci < Cfg::CPW; ++ci)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ri][ci][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
-    if (nit > 0) prefetch(0);
-    for (int it = 0; it < nit; ++it) {
+    // One pipeline stage: LDS <- registers of slab `it`, refill the registers with slab it+2
+    // (two slabs of global-load latency in flight), multiply slab `it`, flush at the offset's end.
+    // MFMA blocks (row block, col block) of the offset are dealt round-robin to the 8 waves.
+    // K is consumed in a permuted order: step (j, e) takes k = 8j + 4*(lane>>5) + e from BOTH
+    // operands, so A fragments are one ds_read_b128 per 4 MFMAs.
+    auto stage = [&](int it, Regs& rg) {
         __syncthreads();                 // previous slab fully consumed
-        store_slab();
+        store_slab(rg);
         __syncthreads();
-        if (it + 1 < nit) prefetch(it + 1);   // global loads fly during the MFMAs below
+        if (it + 2 < nit) prefetch(it + 2, rg);
 
         const int k = klist[it / nslab];
         const int slab = it % nslab;
         const int n_k = cnt[k];
         const int nrb = (n_k + 31) >> 5;
-        const int klen = min(KS, p.c_in - slab * KS);
-        const int ksteps = (klen + 1) >> 1;
-
-        for (int kk = 0; kk < ksteps; ++kk) {
-            float bfrag[Cfg::CPW];
+        const int nblk = nrb * Cfg::NCB;
 #pragma unroll
-            for (int ci = 0; ci < Cfg::CPW; ++ci)
-                bfrag[ci] = Bs[(2 * kk + lhi) * BN + (wc * Cfg::CPW + ci) * 32 + l31];
+        for (int j = 0; j < KS / 8; ++j) {
 #pragma unroll
-            for (int ri = 0; ri < Cfg::RPW; ++ri) {
-                const int rb = wr + ri * Cfg::WR;
-                if (rb < nrb) {
-                    const float afrag = As[(rb * 32 + l31) * LDA + 2 * kk + lhi];
-#pragma unroll
-                    for (int ci = 0; ci < Cfg::CPW; ++ci)
-                        acc[ri][ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag[ci], acc[ri][ci], 0, 0, 0);
+            for (int s = 0; s < Cfg::MAXB; ++s) {
+                const int b = wave + s * Cfg::kWaves;
+                if (b < nblk) {
+                    const int rb = b / Cfg::NCB, cb = b % Cfg::NCB;
+                    const float4 a4 = *reinterpret_cast<const float4*>(As + (rb * 32 + l31) * LDA + 8 * j + 4 * lhi);
+                    const float* bp = Bs + (8 * j + 4 * lhi) * BN + cb * 32 + l31;
+                    const float b0 = bp[0], b1 = bp[BN], b2 = bp[2 * BN], b3 = bp[3 * BN];
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc[s], 0, 0, 0);
                 }
             }
         }
 
         if (slab == nslab - 1) {         // offset finished: flush registers into the LDS tile
 #pragma unroll
-            for (int ri = 0; ri < Cfg::RPW; ++ri) {
-                const int rb = wr + ri * Cfg::WR;
-                if (rb < nrb) {
+            for (int s = 0; s < Cfg::MAXB; ++s) {
+                const int b = wave + s * Cfg::kWaves;
+                if (b < nblk) {
+                    const int rb = b / Cfg::NCB, cb = b % Cfg::NCB;
+                    const int col = cb * 32 + l31;
 #pragma unroll
-                    for (int ci = 0; ci < Cfg::CPW; ++ci) {
-                        const int col = (wc * Cfg::CPW + ci) * 32 + l31;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int prow = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                            if (prow < n_k) {
-                                const int orow = out_list[k * BM + prow];
-                                acc_lds[orow * BN + col] += acc[ri][ci][r];
-                            }
-                            acc[ri][ci][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int prow = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        if (prow < n_k) {
+                            const int orow = out_list[k * BM + prow];
+                            acc_lds[orow * BN + col] += acc[s][r];
                         }
+                        acc[s][r] = 0.f;
                     }
                 }
             }
         }
+    };
+
+    Regs r0, r1;
+    if (nit > 0) prefetch(0, r0);
+    if (nit > 1) prefetch(1, r1);
+    for (int it = 0; it < nit; it += 2) {
+        stage(it, r0);
+        if (it + 1 < nit) stage(it + 1, r1);
     }
     __syncthreads();
 
     // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
-    for (int e = tid; e < rows_here * (BN / 4); e += 256) {
+    for (int e = tid; e < rows_here * (BN / 4); e += NT) {
         const int r = e / (BN / 4), cq = e % (BN / 4);
         const int col = n0 + 4 * cq;
         float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + cq];
@@ -332,7 +342,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     q.tiles_m = (int)ceil_div(p.m_out, BM);
     q.tiles_n = p.c_out / BN;
     const unsigned grid = (unsigned)(ceil_div(q.tiles_m, 8) * 8 * q.tiles_n);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::kThreads), lds, st, q);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

@@ -158,6 +158,10 @@ def test_fused_equals_unfused_realistic_sparsity(device, models, fps_scan):
 
 
 def test_scheduler_on_device_vs_oracle(device):
+    """Device scheduler vs the oracle evaluated LIVE on this machine (tight: both read the same
+    fp32 schedule tables), and vs the committed golden trajectory (loose: the fp32 tables
+    themselves -- torch.linspace/cumprod/log on the CPU -- differ by an ulp between the machine
+    that generated the fixture and this one, which a 50-step trajectory amplifies to ~1e-5)."""
     from lidiff_amd.schedulers import DPMSolverMultistepScheduler
     g = np.load(os.path.join(GOLDEN, "dpm_trajectory.npz"))
     for n in (50, 8, 1):
@@ -165,12 +169,17 @@ def test_scheduler_on_device_vs_oracle(device):
                                         beta_schedule="linear", algorithm_type="sde-dpmsolver++", solver_order=2)
         s.set_timesteps(n)
         s.to(device)
-        assert s.host_timesteps == g[f"ts{n}"].tolist()
+        o = DpmSolverSdeOracle()
+        o.set_timesteps(n)
+        assert s.host_timesteps == g[f"ts{n}"].tolist() == o.timesteps.tolist()
         x = torch.from_numpy(g[f"traj{n}"][0]).to(device)
+        xo = g[f"traj{n}"][0]
         for i, t in enumerate(s.host_timesteps):
             x = s.step(torch.from_numpy(g[f"eps{n}"][i]).to(device), t, x,
                        noise=torch.from_numpy(g[f"z{n}"][i]).to(device))["prev_sample"]
-            assert torch.allclose(x.cpu(), torch.from_numpy(g[f"traj{n}"][i + 1]), rtol=1e-5, atol=1e-5)
+            xo = o.step(g[f"eps{n}"][i], t, xo, g[f"z{n}"][i])
+            assert torch.allclose(x.cpu(), torch.from_numpy(xo), rtol=1e-10, atol=1e-10)
+            assert torch.allclose(x.cpu(), torch.from_numpy(g[f"traj{n}"][i + 1]), rtol=1e-4, atol=1e-4)
 
 
 def test_completion_loop_vs_oracle(device, models):

@@ -61,8 +61,10 @@ struct ConvCfg {
     static_assert(BN % 32 == 0, "BN");
     static_assert(KS % 8 == 0, "KS");
 
+    static constexpr int SLAB = KS * BN + BM * LDA;      // floats per (B slab + A slab) buffer
+
     static size_t lds_bytes(int k_vol) {
-        size_t b = (size_t)BM * BN * 4 + (size_t)KS * BN * 4 + (size_t)BM * LDA * 4;
+        size_t b = (size_t)BM * BN * 4 + 2 * (size_t)SLAB * 4;   // acc tile + double-buffered slabs
         b += (size_t)k_vol * BM * 4;      // in_list
         b += (size_t)64 * 4 * 2;          // cnt, klist (k_vol <= 64)
         b += (size_t)k_vol * BM;          // out_list (uint8)
@@ -77,9 +79,8 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     constexpr int NT = Cfg::kThreads;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc_lds = reinterpret_cast<float*>(smem);
-    float* Bs = acc_lds + BM * BN;                       // [KS][BN]
-    float* As = Bs + KS * BN;                            // [BM][LDA]
-    int32_t* in_list = reinterpret_cast<int32_t*>(As + BM * LDA);
+    float* slab0 = acc_lds + BM * BN;                    // 2 x { Bs [KS][BN], As [BM][LDA] }
+    int32_t* in_list = reinterpret_cast<int32_t*>(slab0 + 2 * Cfg::SLAB);
     int32_t* cnt = in_list + p.k_vol * BM;
     int32_t* klist = cnt + 64;
     uint8_t* out_list = reinterpret_cast<uint8_t*>(klist + 64);
@@ -202,7 +203,9 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
         }
     };
 
-    auto store_slab = [&](const Regs& rg) {
+    auto store_slab = [&](const Regs& rg, int buf) {
+        float* Bs = slab0 + buf * Cfg::SLAB;
+        float* As = Bs + KS * BN;
         if constexpr (VEC) {
 #pragma unroll
             for (int j = 0; j < Cfg::A_VEC; ++j) {
@@ -237,17 +240,19 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
-    // One pipeline stage: LDS <- registers of slab `it`, refill the registers with slab it+2
-    // (two slabs of global-load latency in flight), multiply slab `it`, flush at the offset's end.
-    // MFMA blocks (row block, col block) of the offset are dealt round-robin to the 8 waves.
-    // K is consumed in a permuted order: step (j, e) takes k = 8j + 4*(lane>>5) + e from BOTH
-    // operands, so A fragments are one ds_read_b128 per 4 MFMAs.
+    // One pipeline stage.  On entry LDS buffer (it & 1) holds slab `it` (published by the
+    // previous barrier) and `rg` holds slab it+1, loaded two stages ago.  The stage writes slab
+    // it+1 into the OTHER buffer, refills `rg` with slab it+3, multiplies slab `it`, and ends with
+    // the single barrier of the iteration -- LDS stores and global loads issue in the shadow of
+    // the 64-cycle MFMAs.  MFMA blocks (row block, col block) of the offset are dealt round-robin
+    // to the 8 waves.  K is consumed in a permuted order: step (j, e) takes
+    // k = 8j + 4*(lane>>5) + e from BOTH operands, so an A fragment is one ds_read_b128 per 4 MFMAs.
     auto stage = [&](int it, Regs& rg) {
-        __syncthreads();                 // previous slab fully consumed
-        store_slab(rg);
-        __syncthreads();
-        if (it + 2 < nit) prefetch(it + 2, rg);
+        if (it + 1 < nit) store_slab(rg, (it + 1) & 1);
+        if (it + 3 < nit) prefetch(it + 3, rg);
 
+        const float* Bs = slab0 + (it & 1) * Cfg::SLAB;
+        const float* As = Bs + KS * BN;
         const int k = klist[it / nslab];
         const int slab = it % nslab;
         const int n_k = cnt[k];
@@ -290,14 +295,20 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
                 }
             }
         }
+        __syncthreads();                 // slab it+1 visible, buffer (it & 1) free again
     };
 
     Regs r0, r1;
-    if (nit > 0) prefetch(0, r0);
-    if (nit > 1) prefetch(1, r1);
-    for (int it = 0; it < nit; it += 2) {
-        stage(it, r0);
-        if (it + 1 < nit) stage(it + 1, r1);
+    if (nit > 0) {
+        prefetch(0, r0);
+        if (nit > 1) prefetch(1, r1);
+        store_slab(r0, 0);
+        if (nit > 2) prefetch(2, r0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; it += 2) {     // stage(it) consumes the register set holding slab it+1
+        stage(it, r1);
+        if (it + 1 < nit) stage(it + 1, r0);
     }
     __syncthreads();
 

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Micro-benchmark of lidiff_spconv_fwd on the real sparsity of the bench workload: builds the
+coordinate maps of the 180k-point scan at a given sigma, then times one conv shape on one level.
+
+    python tools/conv_probe.py --sigma 1.0 --level 3 --cin 256 --cout 256 [--iters 20] [--kind k3|down|up|k1]
+Prints pairs, avg us, TFLOP/s (algorithmic: 2*P*Cin*Cout) for the level (0 = stride 1 ... 4 = stride 16).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--cin", type=int, default=256)
+    ap.add_argument("--cout", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--kind", default="k3")
+    ap.add_argument("--sweep", action="store_true", help="all levels x the network's channel pairs")
+    args = ap.parse_args()
+    from lidiff_amd import ops
+    import lidiff_amd.MinkowskiEngine as ME
+    dev = torch.device("cuda:0")
+    scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_fps18000.npy"))
+    rng = np.random.default_rng(0)
+    pts = np.tile(scan, (10, 1)) + args.sigma * rng.standard_normal((180000, 3)).astype(np.float32)
+    feats = torch.from_numpy(pts.astype(np.float32)).to(dev)
+    coord = torch.cat([torch.zeros(180000, 1, device=dev), torch.round(feats / 0.05)], 1)
+    field = ME.TensorField(features=feats, coordinates=coord, device=dev)
+    field.sparse()
+    mgr = field.coordinate_manager
+    ts = 1
+    for _ in range(4):
+        ts = mgr.stride(ts, 2)
+
+    def run(level, cin, cout, kind):
+        ts = 1 << level
+        if kind == "k3":
+            nbr, m_in = mgr.kernel_map(ts, ts, 3), mgr.maps[ts].coords.shape[0]
+        elif kind == "down":
+            nbr, m_in = mgr.kernel_map(ts, ts * 2, 2), mgr.maps[ts].coords.shape[0]
+        elif kind == "up":
+            nbr, m_in = mgr.kernel_map(ts * 2, ts, 2, True), mgr.maps[ts * 2].coords.shape[0]
+        else:
+            nbr, m_in = None, mgr.maps[ts].coords.shape[0]
+        m_out = nbr.shape[1] if nbr is not None else m_in
+        k = nbr.shape[0] if nbr is not None else 1
+        pairs = int((nbr >= 0).sum()) if nbr is not None else m_in
+        x = torch.randn(m_in, cin, device=dev)
+        w = torch.randn(k, cin, cout, device=dev) * 0.05
+        for _ in range(3):
+            ops.spconv_fwd(x, w, nbr, m_out)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.iters):
+            ops.spconv_fwd(x, w, nbr, m_out)
+        e.record()
+        torch.cuda.synchronize()
+        us = 1e3 * s.elapsed_time(e) / args.iters
+        tf = 2.0 * pairs * cin * cout / (us * 1e-6) / 1e12
+        print(f"sigma={args.sigma} level={level} kind={kind} {cin}->{cout} m_in={m_in} m_out={m_out} pairs={pairs} "
+              f"nbrs/row={pairs / m_out:.2f} avg_us={us:.1f} TFLOP/s={tf:.2f}", flush=True)
+
+    if args.sweep:
+        shapes = [(0, 32, 32), (1, 32, 32), (1, 32, 64), (2, 64, 64), (2, 64, 128), (3, 128, 128), (3, 128, 256),
+                  (3, 256, 256), (3, 384, 256), (4, 256, 256), (2, 192, 128), (2, 128, 128), (1, 128, 96), (1, 96, 96),
+                  (0, 128, 96), (0, 96, 96)]
+        for lv, ci, co in shapes:
+            run(lv, ci, co, "k3")
+        run(3, 256, 256, "up"); run(2, 128, 128, "down"); run(3, 384, 256, "k1")
+    else:
+        run(args.level, args.cin, args.cout, args.kind)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,11 +25,35 @@
 //
 // Replaces ME's ConvolutionForwardGPU (gather -> GEMM -> atomic scatter per offset) behind
 // MinkowskiConvolution / MinkowskiConvolutionTranspose; call sites in include/lidiff_amd.h.
+#include <type_traits>
+
 #include "common.h"
 
 namespace lidiff {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor (V#) over [p, p+bytes): stride 0, 32-bit data format.  Out-of-range
+// offsets return zeros, which is how lanes with nothing to load get their zero fill.
+__device__ __forceinline__ u32x4 make_rsrc(const void* p, unsigned bytes) {
+    const uint64_t a = (uint64_t)p;
+    u32x4 r;
+    r.x = (unsigned)a;
+    r.y = (unsigned)(a >> 32) & 0xffffu;
+    r.z = bytes;
+    r.w = 0x00020000u;
+    return r;
+}
+
+// 16-byte buffer load the COMPILER DOES NOT TRACK: hipcc (ROCm 7.2) waits vmcnt(0) in front of
+// the LDS stores of the older register set, which also drains the younger set issued one stage
+// ago.  The loads are issued from inline asm and retired by the counted waits below instead
+// (cdna_hip_programming.md 5.7: '=v' loads + a wait statement naming every destination).
+__device__ __forceinline__ void buffer_load_x4(f32x4& dst, unsigned voff, u32x4 rsrc) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
 
 struct ConvParams {
     const float* in_a;
@@ -58,6 +82,7 @@ struct ConvCfg {
     static constexpr int A_SCL = (BM * KS + kThreads - 1) / kThreads;
     static constexpr int B_SCL = (KS * BN + kThreads - 1) / kThreads;
     static_assert(BM % 64 == 0 && BM <= 256, "BM");
+    static_assert(MAXB <= 2, "at most two MFMA blocks per wave");
     static_assert(BN % 32 == 0, "BN");
     static_assert(KS % 8 == 0, "KS");
 
@@ -98,7 +123,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar branches
 
     // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
     if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
@@ -143,40 +168,67 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     const int nit = nact * nslab;
 
     struct Regs {
-        float4 a_v[VEC ? Cfg::A_VEC : 1];
-        float4 b_v[VEC ? Cfg::B_VEC : 1];
+        f32x4 a_v[VEC ? Cfg::A_VEC : 1];
+        f32x4 b_v[VEC ? Cfg::B_VEC : 1];
         float a_s[VEC ? 1 : Cfg::A_SCL];
         float b_s[VEC ? 1 : Cfg::B_SCL];
     };
 
-    // global -> registers for slab `it` (zero-filled beyond n_k rows / c_in channels)
-    auto prefetch = [&](int it, Regs& rg) {
-        const int k = klist[it / nslab];
-        const int k0 = (it % nslab) * KS;
-        const int n_k = cnt[k];
+    // buffer descriptors (built from kernel arguments only: wave-uniform, live in SGPRs)
+    const u32x4 rsrc_a = make_rsrc(p.in_a, (unsigned)(p.m_in * p.c_in_a * 4));
+    const u32x4 rsrc_b = make_rsrc(p.in_b ? p.in_b : p.in_a, (unsigned)(p.m_in * p.c_in_b * 4));
+    const u32x4 rsrc_w = make_rsrc(p.w, (unsigned)(p.k_vol * p.c_in * p.c_out * 4));
+
+    // counted retirement of the asm loads: wait until at most `keep` vector-memory operations are
+    // outstanding; naming every register of the set keeps the compiler from touching them earlier
+    auto retire = [&](Regs& rg) {
         if constexpr (VEC) {
+            constexpr int NL = Cfg::A_VEC + Cfg::B_VEC;      // loads of the younger set stay in flight
+            static_assert(Cfg::A_VEC == 2 && (Cfg::B_VEC == 1 || Cfg::B_VEC == 2), "register-set shape");
+            if constexpr (Cfg::B_VEC == 2)
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rg.a_v[0]), "+v"(rg.a_v[1]), "+v"(rg.b_v[0]), "+v"(rg.b_v[1]) : "n"(NL) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(rg.a_v[0]), "+v"(rg.a_v[1]), "+v"(rg.b_v[0]) : "n"(NL) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // global -> registers for slab `it` (zero-filled beyond n_k rows / c_in channels)
+    // `it` past the end issues the same loads with out-of-range offsets (zeros, no traffic): every
+    // stage then has exactly one younger register set in flight and ONE counted wait fits all.
+    auto prefetch = [&](int it_raw, Regs& rg) {
+        const bool live = it_raw < nit;
+        const int it = live ? it_raw : 0;
+        const int k = __builtin_amdgcn_readfirstlane(klist[it / nslab]);
+        const int k0 = (it % nslab) * KS;
+        const int n_k = live ? __builtin_amdgcn_readfirstlane(cnt[k]) : 0;
+        if constexpr (VEC) {
+            // Buffer loads through wave-uniform descriptors: a lane that has nothing to load
+            // (row >= n_k, channel >= c_in) passes an out-of-range offset and the hardware
+            // bounds check returns zeros -- no branches around the loads.
+            const bool from_a = k0 < p.c_in_a;             // uniform: slabs never straddle a|b
+            const u32x4 rs = from_a ? rsrc_a : rsrc_b;
+            const int cw = from_a ? p.c_in_a : p.c_in_b;
+            const int cbase = from_a ? k0 : k0 - p.c_in_a;
 #pragma unroll
             for (int j = 0; j < Cfg::A_VEC; ++j) {
                 const int e = tid + j * NT;
-                const int pos = e / (KS / 4), col = k0 + 4 * (e % (KS / 4));
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pos < n_k && col < p.c_in) {
-                    const int64_t row = in_list[k * BM + pos];
-                    const float* src = (col < p.c_in_a) ? p.in_a + row * p.c_in_a + col
-                                                        : p.in_b + row * p.c_in_b + (col - p.c_in_a);
-                    v = *reinterpret_cast<const float4*>(src);
-                }
-                rg.a_v[j] = v;
+                const int pos = e / (KS / 4), cl = 4 * (e % (KS / 4));
+                bool ok = pos < n_k && k0 + cl < p.c_in;
+                if constexpr ((Cfg::A_VEC) * NT > BM * KS / 4) ok = ok && e < BM * KS / 4;
+                const unsigned row = (unsigned)in_list[k * BM + min(pos, BM - 1)];
+                const unsigned off = ok ? (row * (unsigned)cw + (unsigned)(cbase + cl)) * 4u : 0xFFFFFFF0u;
+                buffer_load_x4(rg.a_v[j], off, rs);
             }
 #pragma unroll
             for (int j = 0; j < Cfg::B_VEC; ++j) {
                 const int e = tid + j * NT;
                 const int kr = e / (BN / 4), cq = e % (BN / 4);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < KS * BN / 4 && k0 + kr < p.c_in)
-                    v = *reinterpret_cast<const float4*>(
-                        p.w + ((int64_t)k * p.c_in + k0 + kr) * p.c_out + n0 + 4 * cq);
-                rg.b_v[j] = v;
+                bool ok = live && k0 + kr < p.c_in;
+                if constexpr ((Cfg::B_VEC) * NT > KS * BN / 4) ok = ok && e < KS * BN / 4;
+                const unsigned off = ok ? (((unsigned)k * p.c_in + k0 + kr) * (unsigned)p.c_out + n0 + 4 * cq) * 4u
+                                        : 0xFFFFFFF0u;
+                buffer_load_x4(rg.b_v[j], off, rsrc_w);
             }
         } else {
 #pragma unroll
@@ -184,7 +236,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
                 const int e = tid + j * NT;
                 const int pos = e / KS, col = k0 + e % KS;
                 float v = 0.f;
-                if (e < BM * KS && pos < n_k && col < p.c_in) {
+                if (live && e < BM * KS && pos < n_k && col < p.c_in) {
                     const int64_t row = in_list[k * BM + pos];
                     v = (col < p.c_in_a) ? p.in_a[row * p.c_in_a + col]
                                          : p.in_b[row * p.c_in_b + (col - p.c_in_a)];
@@ -196,7 +248,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
                 const int e = tid + j * NT;
                 const int kr = e / BN, cc = e % BN;
                 float v = 0.f;
-                if (e < KS * BN && k0 + kr < p.c_in)
+                if (live && e < KS * BN && k0 + kr < p.c_in)
                     v = p.w[((int64_t)k * p.c_in + k0 + kr) * p.c_out + n0 + cc];
                 rg.b_s[j] = v;
             }
@@ -210,13 +262,13 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < Cfg::A_VEC; ++j) {
                 const int e = tid + j * NT;
-                if (e < BM * KS / 4)
-                    *reinterpret_cast<float4*>(As + (e / (KS / 4)) * LDA + 4 * (e % (KS / 4))) = rg.a_v[j];
+                if ((j + 1) * NT <= BM * KS / 4 || e < BM * KS / 4)
+                    *reinterpret_cast<f32x4*>(As + (e / (KS / 4)) * LDA + 4 * (e % (KS / 4))) = rg.a_v[j];
             }
 #pragma unroll
             for (int j = 0; j < Cfg::B_VEC; ++j) {
                 const int e = tid + j * NT;
-                if (e < KS * BN / 4) reinterpret_cast<float4*>(Bs)[e] = rg.b_v[j];
+                if ((j + 1) * NT <= KS * BN / 4 || e < KS * BN / 4) reinterpret_cast<f32x4*>(Bs)[e] = rg.b_v[j];
             }
         } else {
 #pragma unroll
@@ -248,32 +300,50 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     // to the 8 waves.  K is consumed in a permuted order: step (j, e) takes
     // k = 8j + 4*(lane>>5) + e from BOTH operands, so an A fragment is one ds_read_b128 per 4 MFMAs.
     auto stage = [&](int it, Regs& rg) {
-        if (it + 1 < nit) store_slab(rg, (it + 1) & 1);
-        if (it + 3 < nit) prefetch(it + 3, rg);
+        retire(rg);                       // the other set (slab it+2, maybe a dummy) stays in flight
+        store_slab(rg, (it + 1) & 1);     // past the end: zeros into the free buffer, harmless
+        prefetch(it + 3, rg);
 
         const float* Bs = slab0 + (it & 1) * Cfg::SLAB;
         const float* As = Bs + KS * BN;
-        const int k = klist[it / nslab];
+        const int k = __builtin_amdgcn_readfirstlane(klist[it / nslab]);
         const int slab = it % nslab;
-        const int n_k = cnt[k];
+        const int n_k = __builtin_amdgcn_readfirstlane(cnt[k]);
         const int nrb = (n_k + 31) >> 5;
         const int nblk = nrb * Cfg::NCB;
+        // this wave's active blocks are s = 0 .. nb_w-1 (scalar); straight-line code per count so
+        // the fragment reads of step j+1 can be scheduled under the MFMAs of step j
+        const int nb_w = (nblk > wave) ? (nblk - wave + Cfg::kWaves - 1) / Cfg::kWaves : 0;
+        auto mma = [&](auto nb_tag) {
+            constexpr int NB = decltype(nb_tag)::value;
+            const float* ap[NB];
+            const float* bp[NB];
 #pragma unroll
-        for (int j = 0; j < KS / 8; ++j) {
-#pragma unroll
-            for (int s = 0; s < Cfg::MAXB; ++s) {
+            for (int s = 0; s < NB; ++s) {
                 const int b = wave + s * Cfg::kWaves;
-                if (b < nblk) {
-                    const int rb = b / Cfg::NCB, cb = b % Cfg::NCB;
-                    const float4 a4 = *reinterpret_cast<const float4*>(As + (rb * 32 + l31) * LDA + 8 * j + 4 * lhi);
-                    const float* bp = Bs + (8 * j + 4 * lhi) * BN + cb * 32 + l31;
-                    const float b0 = bp[0], b1 = bp[BN], b2 = bp[2 * BN], b3 = bp[3 * BN];
+                const int rb = b / Cfg::NCB, cb = b % Cfg::NCB;
+                ap[s] = As + (rb * 32 + l31) * LDA + 4 * lhi;
+                bp[s] = Bs + (4 * lhi) * BN + cb * 32 + l31;
+            }
+#pragma unroll
+            for (int j = 0; j < KS / 8; ++j) {
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ap[s] + 8 * j);
+                    const float* q = bp[s] + 8 * j * BN;
+                    const float b0 = q[0], b1 = q[BN], b2 = q[2 * BN], b3 = q[3 * BN];
                     acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc[s], 0, 0, 0);
                     acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc[s], 0, 0, 0);
                     acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc[s], 0, 0, 0);
                     acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc[s], 0, 0, 0);
                 }
             }
+        };
+        if constexpr (Cfg::MAXB >= 2) {
+            if (nb_w >= 2) mma(std::integral_constant<int, 2>{});
+            else if (nb_w == 1) mma(std::integral_constant<int, 1>{});
+        } else {
+            if (nb_w >= 1) mma(std::integral_constant<int, 1>{});
         }
 
         if (slab == nslab - 1) {         // offset finished: flush registers into the LDS tile
@@ -301,15 +371,17 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     Regs r0, r1;
     if (nit > 0) {
         prefetch(0, r0);
-        if (nit > 1) prefetch(1, r1);
+        prefetch(1, r1);
+        retire(r0);
         store_slab(r0, 0);
-        if (nit > 2) prefetch(2, r0);
+        prefetch(2, r0);
     }
     __syncthreads();
     for (int it = 0; it < nit; it += 2) {     // stage(it) consumes the register set holding slab it+1
         stage(it, r1);
         if (it + 1 < nit) stage(it + 1, r0);
     }
+    if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing dummy loads
     __syncthreads();
 
     // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
@@ -389,6 +461,10 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(w) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
                      "w/out/epilogue pointers must be 16-byte aligned");
+    const bool fits32 = m_in * (int64_t)c_in_a * 4 < (1ll << 31) && m_in * (int64_t)c_in_b * 4 < (1ll << 31) &&
+                        (int64_t)k_vol * (c_in_a + c_in_b) * c_out * 4 < (1ll << 31);
+    LIDIFF_CHECK_ARG(fits32, "a feature or weight matrix exceeds the 2 GiB buffer-descriptor range");
+    LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % 32 == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
     const bool vec = c_in_a % 4 == 0 && c_in_b % 4 == 0 && al16(in_a) && al16(in_b);
     hipStream_t st = (hipStream_t)stream;
     if (c_out % 128 == 0) return dispatch_fwd<128>(p, vec, st);

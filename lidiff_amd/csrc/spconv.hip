@@ -189,7 +189,6 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
                 asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rg.a_v[0]), "+v"(rg.a_v[1]), "+v"(rg.b_v[0]), "+v"(rg.b_v[1]) : "n"(NL) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(%3)" : "+v"(rg.a_v[0]), "+v"(rg.a_v[1]), "+v"(rg.b_v[0]) : "n"(NL) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -300,10 +299,6 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     // to the 8 waves.  K is consumed in a permuted order: step (j, e) takes
     // k = 8j + 4*(lane>>5) + e from BOTH operands, so an A fragment is one ds_read_b128 per 4 MFMAs.
     auto stage = [&](int it, Regs& rg) {
-        retire(rg);                       // the other set (slab it+2, maybe a dummy) stays in flight
-        store_slab(rg, (it + 1) & 1);     // past the end: zeros into the free buffer, harmless
-        prefetch(it + 3, rg);
-
         const float* Bs = slab0 + (it & 1) * Cfg::SLAB;
         const float* As = Bs + KS * BN;
         const int k = __builtin_amdgcn_readfirstlane(klist[it / nslab]);
@@ -311,8 +306,17 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
         const int n_k = __builtin_amdgcn_readfirstlane(cnt[k]);
         const int nrb = (n_k + 31) >> 5;
         const int nblk = nrb * Cfg::NCB;
-        // this wave's active blocks are s = 0 .. nb_w-1 (scalar); straight-line code per count so
-        // the fragment reads of step j+1 can be scheduled under the MFMAs of step j
+
+        // staging half of the stage: slab it+1 registers -> the other LDS buffer, refill with it+3
+        auto stage_io = [&]() {
+            retire(rg);                       // the other set (slab it+2, maybe a dummy) stays in flight
+            store_slab(rg, (it + 1) & 1);     // past the end: zeros into the free buffer, harmless
+            prefetch(it + 3, rg);
+        };
+
+        // MFMA half: this wave's active blocks are s = 0 .. nb_w-1 (scalar).  Fragments are
+        // double-buffered in registers: the ds_reads of step j+1 are issued before the MFMAs of
+        // step j (sched_barrier keeps them there), so LDS latency hides under 4*NB MFMAs.
         const int nb_w = (nblk > wave) ? (nblk - wave + Cfg::kWaves - 1) / Cfg::kWaves : 0;
         auto mma = [&](auto nb_tag) {
             constexpr int NB = decltype(nb_tag)::value;
@@ -325,26 +329,59 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
                 ap[s] = As + (rb * 32 + l31) * LDA + 4 * lhi;
                 bp[s] = Bs + (4 * lhi) * BN + cb * 32 + l31;
             }
-#pragma unroll
-            for (int j = 0; j < KS / 8; ++j) {
+            struct Frag { float4 a[NB]; float b[NB][4]; };
+            auto load_frag = [&](int j, Frag& f) {
 #pragma unroll
                 for (int s = 0; s < NB; ++s) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ap[s] + 8 * j);
+                    f.a[s] = *reinterpret_cast<const float4*>(ap[s] + 8 * j);
                     const float* q = bp[s] + 8 * j * BN;
-                    const float b0 = q[0], b1 = q[BN], b2 = q[2 * BN], b3 = q[3 * BN];
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc[s], 0, 0, 0);
+                    f.b[s][0] = q[0]; f.b[s][1] = q[BN]; f.b[s][2] = q[2 * BN]; f.b[s][3] = q[3 * BN];
                 }
+            };
+            auto issue = [&](const Frag& f) {
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s].x, f.b[s][0], acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s].y, f.b[s][1], acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s].z, f.b[s][2], acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s].w, f.b[s][3], acc[s], 0, 0, 0);
+                }
+            };
+            static_assert(KS / 8 == 4, "fragment pipeline written for 4 steps per slab");
+            Frag f0, f1;
+            load_frag(0, f0);
+            load_frag(1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag(2, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(f1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag(3, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(f1);
+        };
+        auto mma_any = [&]() {
+            if constexpr (Cfg::MAXB >= 2) {
+                if (nb_w >= 2) mma(std::integral_constant<int, 2>{});
+                else if (nb_w == 1) mma(std::integral_constant<int, 1>{});
+            } else {
+                if (nb_w >= 1) mma(std::integral_constant<int, 1>{});
             }
         };
-        if constexpr (Cfg::MAXB >= 2) {
-            if (nb_w >= 2) mma(std::integral_constant<int, 2>{});
-            else if (nb_w == 1) mma(std::integral_constant<int, 1>{});
-        } else {
-            if (nb_w >= 1) mma(std::integral_constant<int, 1>{});
-        }
+
+        // The two waves of a SIMD (w and w+4) run the two halves in OPPOSITE order, so one
+        // wave's staging (LDS stores, address generation, global loads) overlaps the other
+        // wave's MFMAs instead of both leaving the matrix pipe idle at the same time.
+        // (stage_io appears ONCE in the instruction stream: its asm-loaded registers must not pass
+        // through a control-flow merge, or the compiler inserts copies ahead of the counted wait.)
+        const bool io_first = wave < Cfg::kWaves / 2;
+        if (!io_first) mma_any();
+        stage_io();
+        if (io_first) mma_any();
 
         if (slab == nslab - 1) {         // offset finished: flush registers into the LDS tile
 #pragma unroll

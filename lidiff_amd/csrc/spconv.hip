@@ -67,7 +67,16 @@ struct ConvParams {
     int64_t m_in, m_out;
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
     int tiles_m, tiles_n;
+    long long* dbg;      // LIDIFF_CONV_TIMING builds only: per-wave phase cycle sums
 };
+
+#ifdef LIDIFF_CONV_TIMING
+#define TSTAMP(x) const long long x = __builtin_readcyclecounter()
+#define TADD(slot, a, b) tsum[slot] += (b) - (a)
+#else
+#define TSTAMP(x)
+#define TADD(slot, a, b)
+#endif
 
 template <int BM, int BN, int KS>
 struct ConvCfg {
@@ -285,6 +294,9 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
 
     const int l31 = lane & 31, lhi = lane >> 5;
 
+#ifdef LIDIFF_CONV_TIMING
+    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     floatx16 acc[Cfg::MAXB];
 #pragma unroll
     for (int s = 0; s < Cfg::MAXB; ++s)
@@ -309,9 +321,14 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
 
         // staging half of the stage: slab it+1 registers -> the other LDS buffer, refill with it+3
         auto stage_io = [&]() {
+            TSTAMP(t0);
             retire(rg);                       // the other set (slab it+2, maybe a dummy) stays in flight
+            TSTAMP(t1);
             store_slab(rg, (it + 1) & 1);     // past the end: zeros into the free buffer, harmless
+            TSTAMP(t2);
             prefetch(it + 3, rg);
+            TSTAMP(t3);
+            TADD(0, t0, t1); TADD(1, t1, t2); TADD(2, t2, t3);
         };
 
         // MFMA half: this wave's active blocks are s = 0 .. nb_w-1 (scalar).  Fragments are
@@ -379,9 +396,14 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
         // (stage_io appears ONCE in the instruction stream: its asm-loaded registers must not pass
         // through a control-flow merge, or the compiler inserts copies ahead of the counted wait.)
         const bool io_first = wave < Cfg::kWaves / 2;
+        TSTAMP(m0);
         if (!io_first) mma_any();
+        TSTAMP(m1);
         stage_io();
+        TSTAMP(m2);
         if (io_first) mma_any();
+        TSTAMP(m3);
+        TADD(3, m0, m1); TADD(3, m2, m3);
 
         if (slab == nslab - 1) {         // offset finished: flush registers into the LDS tile
 #pragma unroll
@@ -402,9 +424,15 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
                 }
             }
         }
+        TSTAMP(b0);
         __syncthreads();                 // slab it+1 visible, buffer (it & 1) free again
+        TSTAMP(b1);
+        TADD(4, m3, b0); TADD(5, b0, b1); TADD(6, m0, b1);
     };
 
+#ifdef LIDIFF_CONV_TIMING
+    const long long t_begin = __builtin_readcyclecounter();
+#endif
     Regs r0, r1;
     if (nit > 0) {
         prefetch(0, r0);
@@ -419,6 +447,14 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
         if (it + 1 < nit) stage(it + 1, r0);
     }
     if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing dummy loads
+#ifdef LIDIFF_CONV_TIMING
+    if (p.dbg != nullptr && lane == 0) {
+        tsum[7] = __builtin_readcyclecounter() - t_begin;      // whole slab loop incl. pipeline fill
+        long long* d = p.dbg + ((long long)blockIdx.x * Cfg::kWaves + wave) * 9;
+        for (int q = 0; q < 8; ++q) d[q] = tsum[q];
+        d[8] = nit;
+    }
+#endif
     __syncthreads();
 
     // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
@@ -477,6 +513,11 @@ static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
 
 using namespace lidiff;
 
+static long long* g_conv_dbg = nullptr;
+#ifdef LIDIFF_CONV_TIMING
+extern "C" void lidiff_debug_set_conv_timing_buffer(long long* d_buf) { g_conv_dbg = d_buf; }
+#endif
+
 extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
                                  const float* w, const int32_t* nbr, int32_t k_vol, int64_t m_in,
                                  int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
@@ -494,7 +535,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
-    p.k_vol = k_vol; p.relu = relu;
+    p.k_vol = k_vol; p.relu = relu; p.dbg = g_conv_dbg;
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(w) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
                      "w/out/epilogue pointers must be 16-byte aligned");

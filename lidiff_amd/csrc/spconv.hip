@@ -97,12 +97,13 @@ struct ConvCfg {
 
     static constexpr int SLAB = KS * BN + BM * LDA;      // floats per (B slab + A slab) buffer
 
-    static size_t lds_bytes(int k_vol) {
+    __host__ __device__ static size_t lds_bytes(int k_vol) {
         size_t b = (size_t)BM * BN * 4 + 2 * (size_t)SLAB * 4;   // acc tile + double-buffered slabs
         b += (size_t)k_vol * BM * 4;      // in_list
         b += (size_t)64 * 4 * 2;          // cnt, klist (k_vol <= 64)
         b += (size_t)k_vol * BM;          // out_list (uint8)
-        return (b + 15) & ~(size_t)15;
+        b = (b + 15) & ~(size_t)15;
+        return b + 64 * 4;                // per-lane dummy words for the branch-free flush
     }
 };
 
@@ -118,6 +119,8 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     int32_t* cnt = in_list + p.k_vol * BM;
     int32_t* klist = cnt + 64;
     uint8_t* out_list = reinterpret_cast<uint8_t*>(klist + 64);
+    // float index (relative to acc_lds) of 64 dummy words behind everything else
+    const int dummy_off = (int)((Cfg::lds_bytes(p.k_vol) - 64 * 4) / 4);
 
     // XCD-aware tile mapping: the column blocks of one row tile share an XCD (their gathers
     // hit the same L2), consecutive row tiles round-robin over the 8 XCDs.
@@ -201,15 +204,38 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
         }
     };
 
-    // global -> registers for slab `it` (zero-filled beyond n_k rows / c_in channels)
-    // `it` past the end issues the same loads with out-of-range offsets (zeros, no traffic): every
-    // stage then has exactly one younger register set in flight and ONE counted wait fits all.
-    auto prefetch = [&](int it_raw, Regs& rg) {
-        const bool live = it_raw < nit;
-        const int it = live ? it_raw : 0;
-        const int k = __builtin_amdgcn_readfirstlane(klist[it / nslab]);
-        const int k0 = (it % nslab) * KS;
-        const int n_k = live ? __builtin_amdgcn_readfirstlane(cnt[k]) : 0;
+    // Position in the (active offset, K-slab) sequence, kept in SGPRs and advanced incrementally
+    // (no integer division, one LDS lookup per OFFSET rather than per slab).
+    struct Cursor { int ai, slab, k, nk; };
+    auto cursor_load = [&](Cursor& c) {
+        if (c.ai < nact) {
+            c.k = __builtin_amdgcn_readfirstlane(klist[c.ai]);
+            c.nk = __builtin_amdgcn_readfirstlane(cnt[c.k]);
+        } else {
+            c.k = 0;
+            c.nk = 0;                          // past the end: every lane loads nothing
+        }
+    };
+    auto cursor_next = [&](Cursor& c) {
+        if (++c.slab == nslab) {
+            c.slab = 0;
+            ++c.ai;
+            cursor_load(c);
+        }
+    };
+    Cursor pf{0, 0, 0, 0}, cur{0, 0, 0, 0};
+    cursor_load(pf);
+    cursor_load(cur);
+
+    // global -> registers for the slab at the prefetch cursor (zero-filled beyond n_k rows / c_in
+    // channels), then advance the cursor.  Past the end the same loads are issued with
+    // out-of-range offsets (zeros, no traffic): every stage then has exactly one younger register
+    // set in flight and ONE counted wait fits all.
+    auto prefetch = [&](Regs& rg) {
+        const bool live = pf.ai < nact;
+        const int k = pf.k;
+        const int k0 = pf.slab * KS;
+        const int n_k = pf.nk;
         if constexpr (VEC) {
             // Buffer loads through wave-uniform descriptors: a lane that has nothing to load
             // (row >= n_k, channel >= c_in) passes an out-of-range offset and the hardware
@@ -218,14 +244,17 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
             const u32x4 rs = from_a ? rsrc_a : rsrc_b;
             const int cw = from_a ? p.c_in_a : p.c_in_b;
             const int cbase = from_a ? k0 : k0 - p.c_in_a;
+            unsigned rowv[Cfg::A_VEC];
+#pragma unroll
+            for (int j = 0; j < Cfg::A_VEC; ++j)        // both list reads in flight, one LDS wait
+                rowv[j] = (unsigned)in_list[k * BM + min((tid + j * NT) / (KS / 4), BM - 1)];
 #pragma unroll
             for (int j = 0; j < Cfg::A_VEC; ++j) {
                 const int e = tid + j * NT;
                 const int pos = e / (KS / 4), cl = 4 * (e % (KS / 4));
                 bool ok = pos < n_k && k0 + cl < p.c_in;
                 if constexpr ((Cfg::A_VEC) * NT > BM * KS / 4) ok = ok && e < BM * KS / 4;
-                const unsigned row = (unsigned)in_list[k * BM + min(pos, BM - 1)];
-                const unsigned off = ok ? (row * (unsigned)cw + (unsigned)(cbase + cl)) * 4u : 0xFFFFFFF0u;
+                const unsigned off = ok ? (rowv[j] * (unsigned)cw + (unsigned)(cbase + cl)) * 4u : 0xFFFFFFF0u;
                 buffer_load_x4(rg.a_v[j], off, rs);
             }
 #pragma unroll
@@ -261,6 +290,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
                 rg.b_s[j] = v;
             }
         }
+        cursor_next(pf);
     };
 
     auto store_slab = [&](const Regs& rg, int buf) {
@@ -313,9 +343,9 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     auto stage = [&](int it, Regs& rg) {
         const float* Bs = slab0 + (it & 1) * Cfg::SLAB;
         const float* As = Bs + KS * BN;
-        const int k = __builtin_amdgcn_readfirstlane(klist[it / nslab]);
-        const int slab = it % nslab;
-        const int n_k = __builtin_amdgcn_readfirstlane(cnt[k]);
+        const int k = cur.k;
+        const int slab = cur.slab;
+        const int n_k = cur.nk;
         const int nrb = (n_k + 31) >> 5;
         const int nblk = nrb * Cfg::NCB;
 
@@ -326,7 +356,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
             TSTAMP(t1);
             store_slab(rg, (it + 1) & 1);     // past the end: zeros into the free buffer, harmless
             TSTAMP(t2);
-            prefetch(it + 3, rg);
+            prefetch(rg);
             TSTAMP(t3);
             TADD(0, t0, t1); TADD(1, t1, t2); TADD(2, t2, t3);
         };
@@ -406,24 +436,33 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
         TADD(3, m0, m1); TADD(3, m2, m3);
 
         if (slab == nslab - 1) {         // offset finished: flush registers into the LDS tile
+            // Batched and branch-free: 16 list lookups, then 16 tile reads, then 16 writes per
+            // block (3 LDS round trips instead of 48); rows beyond n_k go to a per-lane dummy word.
 #pragma unroll
             for (int s = 0; s < Cfg::MAXB; ++s) {
                 const int b = wave + s * Cfg::kWaves;
                 if (b < nblk) {
                     const int rb = b / Cfg::NCB, cb = b % Cfg::NCB;
                     const int col = cb * 32 + l31;
+                    int addr[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int prow = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        if (prow < n_k) {
-                            const int orow = out_list[k * BM + prow];
-                            acc_lds[orow * BN + col] += acc[s][r];
-                        }
+                        const int orow = out_list[k * BM + prow];
+                        addr[r] = prow < n_k ? orow * BN + col : dummy_off + lane;
+                    }
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = acc_lds[addr[r]];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc_lds[addr[r]] = old[r] + acc[s][r];
                         acc[s][r] = 0.f;
                     }
                 }
             }
         }
+        cursor_next(cur);
         TSTAMP(b0);
         __syncthreads();                 // slab it+1 visible, buffer (it & 1) free again
         TSTAMP(b1);
@@ -435,11 +474,11 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
 #endif
     Regs r0, r1;
     if (nit > 0) {
-        prefetch(0, r0);
-        prefetch(1, r1);
+        prefetch(r0);
+        prefetch(r1);
         retire(r0);
         store_slab(r0, 0);
-        prefetch(2, r0);
+        prefetch(r0);
     }
     __syncthreads();
     for (int it = 0; it < nit; it += 2) {     // stage(it) consumes the register set holding slab it+1

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 1
+#define LIDIFF_ABI_VERSION 2
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2   /* *d_status bit: hash table too small (cap < 2*rows)     */
 
@@ -97,6 +97,16 @@ int lidiff_rulebook_compact(const int32_t* nbr, int32_t k_vol, int64_t m_out,
                             void* workspace, void* stream);
 int64_t lidiff_rulebook_workspace_bytes(int32_t k_vol, int64_t m_out);
 
+/* Weight layout of the sparse convolution.  MinkowskiConvolution.kernel is [K, c_in, c_out] row-major
+ * (minkunet.py:17,36,53,61; [c_in, c_out] for kernel_size 1, :72).  The HIP kernel consumes it in MFMA
+ * fragment order: [K][slab = ceil(c_in/32)][c_out/16][j 0..1][lane 0..63][e 0..3] with
+ * k_in = 32*slab + 16*j + 4*(lane>>4) + e (zero beyond c_in) and col = 16*nt + (lane&15), so that every
+ * wave reads its [32 x 16] piece of W[k] as one coalesced 2 KB run straight into VGPRs.  Pack once per
+ * weight update (the Python shim caches the packed copy per Parameter version). c_out % 16 == 0. */
+int64_t lidiff_spconv_packed_weight_floats(int32_t k_vol, int32_t c_in, int32_t c_out);
+int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out,
+                               float* w_packed, void* stream);
+
 /* Sparse convolution forward -- MinkowskiConvolution / MinkowskiConvolutionTranspose
  * (ME: ConvolutionForwardGPU gather-GEMM-scatter), output-stationary, fp32 MFMA:
  *   out[o, :] = epilogue( sum_k  in[nbr[k,o], :] @ w[k] ),  in = [in_a | in_b] column-wise
@@ -105,9 +115,9 @@ int64_t lidiff_rulebook_workspace_bytes(int32_t k_vol, int64_t m_out);
  *   epilogue: v = acc*ep_scale[c] + ep_shift[c] (either may be NULL) ; v += residual[o,c]
  *   (may be NULL) ; relu if relu != 0.   (eval-mode MinkowskiBatchNorm + MinkowskiReLU +
  *   ResidualBlock add, minkunet.py:23-24,59-60,79.)
- * w is [K, c_in_a + c_in_b, c_out] row-major. */
+ * w_packed: lidiff_spconv_pack_weights of the [K, c_in_a + c_in_b, c_out] kernel. */
 int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
-                      const float* w, const int32_t* nbr, int32_t k_vol,
+                      const float* w_packed, const int32_t* nbr, int32_t k_vol,
                       int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                       const float* ep_scale, const float* ep_shift, const float* residual,
                       int32_t relu, void* stream);

@@ -1,27 +1,32 @@
-// Sparse convolution for gfx950: output-stationary, pair-compacted, fp32 MFMA.
+// Sparse convolution for gfx950: output-stationary, pair-compacted, fp32 MFMA (v_mfma_f32_16x16x4_f32).
 //
-// One workgroup (4 waves) owns a tile of BM consecutive OUTPUT rows x BN output channels and
-// keeps that tile's fp32 accumulators in LDS for the whole kernel-volume loop, so every
-// output row is written to HBM exactly once (with the BatchNorm/ReLU/residual epilogue fused)
-// and there are no global atomics -- results are deterministic.
+// One workgroup owns a tile of BM consecutive OUTPUT rows x BN = 16*WN output channels and keeps that
+// tile's fp32 accumulators in LDS for the whole kernel-volume loop, so every output row is written to
+// HBM exactly once (BatchNorm / residual / ReLU epilogue fused) and there are no global atomics:
+// results are deterministic.
 //
-// For every kernel offset k the tile's column of the neighbour table nbr[k, row0:row0+BM] is
-// compacted with a wave ballot into a dense pair list (input row, local output row).  The
-// offset's contribution is then a small dense GEMM
+// For every kernel offset k the tile's column of the neighbour table nbr[k, row0:row0+BM] is compacted
+// with a wave ballot into a dense pair list (input row, local output row).  The offset's contribution
 //        [n_k pairs x C_in] (gathered rows)  @  W[k] [C_in x BN]
-// executed with v_mfma_f32_32x32x2_f32 in 32-pair row blocks: only ceil(n_k/32) row blocks
-// are issued, so MFMA work tracks the REAL pair count (plus <32 rows of padding per offset)
-// instead of BM x 27 as a zero-padded implicit GEMM would.  The register accumulators of an
-// offset are flushed into the LDS tile through the pair list's local output row (each output
-// row occurs at most once per offset, and waves own disjoint row-block/column-block sets, so
-// plain LDS read-modify-write is race free).
+// is issued in 16-pair row blocks, so MFMA work tracks the REAL pair count (< 16 rows of padding per
+// offset) instead of BM x 27 as a zero-padded implicit GEMM would.
 //
-// Data movement per K-slab (KS input channels): gathered A rows (coalesced float4, a full
-// 128-byte line per row for KS = 32) and the W[k] slab are prefetched global->registers TWO
-// slabs ahead (two register sets) so the gather latency overlaps two slabs of MFMA work, then
-// stored to LDS (A rows padded to KS+4 floats: conflict-free ds_read_b128 of 4 consecutive k
-// per lane -- K is consumed in a permuted order shared by both operands; B rows are read
-// lane-contiguously).  Eight waves per workgroup (two per SIMD) share the MFMA pipe.
+// Decomposition: the WN*WM waves form a WN x WM grid.  Wave (wn, wm) owns output columns
+// [16 wn, 16 wn + 16) and the row blocks rb = wm (mod WM) of the stage, so with WM = 1 every wave
+// issues exactly the same MFMA stream (no block-dealing imbalance between the SIMDs).
+//   * B operand: the wave's [32 k x 16 col] piece of W[k] comes straight from HBM/L2 into 8 VGPRs in
+//     MFMA fragment order (weights are pre-packed once by lidiff_spconv_pack_weights: one fully
+//     coalesced 2 KB read per wave and stage) and is reused by all of the wave's row blocks.
+//   * A operand: the gathered rows of a stage (<= 128 pairs x 32 channels) are written by LDS-DMA
+//     (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass) into a double-buffered
+//     [128][32] image whose 16-byte chunks are XOR-swizzled THROUGH THE SOURCE ADDRESS
+//     (slot = chunk ^ ((row >> 1) & 7)), which makes the ds_read_b128 fragment reads of all eight
+//     waves bank-conflict free.  K is consumed in a permuted order shared by both operands.
+//   * A stage = (offset, chunk of <= 128 pairs, 32-channel slab); loads of stage i+1 are issued before
+//     the MFMAs of stage i; one barrier per stage.
+//   * After the last slab of an offset the register accumulators are added into the LDS tile through
+//     the pair list's local output row (each output row occurs at most once per offset and waves own
+//     disjoint column / row-block sets, so the LDS read-modify-write is race free).
 //
 // Replaces ME's ConvolutionForwardGPU (gather -> GEMM -> atomic scatter per offset) behind
 // MinkowskiConvolution / MinkowskiConvolutionTranspose; call sites in include/lidiff_amd.h.
@@ -31,34 +36,17 @@
 
 namespace lidiff {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// Raw buffer descriptor (V#) over [p, p+bytes): stride 0, 32-bit data format.  Out-of-range
-// offsets return zeros, which is how lanes with nothing to load get their zero fill.
-__device__ __forceinline__ u32x4 make_rsrc(const void* p, unsigned bytes) {
-    const uint64_t a = (uint64_t)p;
-    u32x4 r;
-    r.x = (unsigned)a;
-    r.y = (unsigned)(a >> 32) & 0xffffu;
-    r.z = bytes;
-    r.w = 0x00020000u;
-    return r;
-}
-
-// 16-byte buffer load the COMPILER DOES NOT TRACK: hipcc (ROCm 7.2) waits vmcnt(0) in front of
-// the LDS stores of the older register set, which also drains the younger set issued one stage
-// ago.  The loads are issued from inline asm and retired by the counted waits below instead
-// (cdna_hip_programming.md 5.7: '=v' loads + a wait statement naming every destination).
-__device__ __forceinline__ void buffer_load_x4(f32x4& dst, unsigned voff, u32x4 rsrc) {
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
-}
+constexpr int kSlab = 32;     // input channels per stage
+constexpr int kChunk = 128;   // pair rows per stage
+constexpr int kAFloats = kChunk * kSlab;   // one A image: 16 KB
 
 struct ConvParams {
     const float* in_a;
     const float* in_b;
-    const float* w;
+    const float* wp;          // packed weights (lidiff_spconv_pack_weights)
     const int32_t* nbr;
     float* out;
     const float* scale;
@@ -67,63 +55,48 @@ struct ConvParams {
     int64_t m_in, m_out;
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
     int tiles_m, tiles_n;
-    long long* dbg;      // LIDIFF_CONV_TIMING builds only: per-wave phase cycle sums
 };
 
-#ifdef LIDIFF_CONV_TIMING
-#define TSTAMP(x) const long long x = __builtin_readcyclecounter()
-#define TADD(slot, a, b) tsum[slot] += (b) - (a)
-#else
-#define TSTAMP(x)
-#define TADD(slot, a, b)
-#endif
-
-template <int BM, int BN, int KS>
+template <int BM, int WN, int WM>
 struct ConvCfg {
-    static constexpr int kThreads = 512;                 // 8 waves: two per SIMD share the MFMA pipe
-    static constexpr int kWaves = kThreads / 64;
-    static constexpr int NCB = BN / 32;                  // 32-col blocks in the tile
-    static constexpr int NRB = BM / 32;                  // 32-pair row blocks (upper bound)
-    static constexpr int MAXB = (NRB * NCB + kWaves - 1) / kWaves;   // MFMA blocks per wave
-    static constexpr int LDA = KS + 4;                   // 16-B aligned rows, conflict-free b128 reads
-    static constexpr int A_VEC = (BM * KS / 4 + kThreads - 1) / kThreads;   // float4 per thread
-    static constexpr int B_VEC = (KS * BN / 4 + kThreads - 1) / kThreads;
-    static constexpr int A_SCL = (BM * KS + kThreads - 1) / kThreads;
-    static constexpr int B_SCL = (KS * BN + kThreads - 1) / kThreads;
-    static_assert(BM % 64 == 0 && BM <= 256, "BM");
-    static_assert(MAXB <= 2, "at most two MFMA blocks per wave");
-    static_assert(BN % 32 == 0, "BN");
-    static_assert(KS % 8 == 0, "KS");
-
-    static constexpr int SLAB = KS * BN + BM * LDA;      // floats per (B slab + A slab) buffer
+    static constexpr int BN = 16 * WN;
+    static constexpr int NW = WN * WM;
+    static constexpr int NT = 64 * NW;
+    static constexpr int RB = kChunk / 16;       // row blocks per stage
+    static constexpr int RBW = RB / WM;          // row blocks per wave
+    static constexpr int NCH = BM / kChunk;      // chunks per offset (upper bound)
+    static_assert(BM % kChunk == 0 && BM <= 256, "BM");     // out_list is uint8
+    static_assert(RB % WM == 0, "WM must divide 8");
+    static_assert(NT <= 1024, "workgroup size");
 
     __host__ __device__ static size_t lds_bytes(int k_vol) {
-        size_t b = (size_t)BM * BN * 4 + 2 * (size_t)SLAB * 4;   // acc tile + double-buffered slabs
-        b += (size_t)k_vol * BM * 4;      // in_list
-        b += (size_t)64 * 4 * 2;          // cnt, klist (k_vol <= 64)
-        b += (size_t)k_vol * BM;          // out_list (uint8)
+        size_t b = 2 * (size_t)kAFloats * 4;              // A images (LDS-DMA targets, kept below 64 KB)
+        b += (size_t)BM * BN * 4;                         // accumulator tile
+        b += (size_t)k_vol * BM * 4;                      // in_list
+        b += 32 * 4;                                      // cnt (k_vol <= 27; cnt[31] = #work items)
+        b += (size_t)32 * NCH * 4;                        // work list
+        b += (size_t)k_vol * BM;                          // out_list (uint8)
         b = (b + 15) & ~(size_t)15;
-        return b + 64 * 4;                // per-lane dummy words for the branch-free flush
+        return b + 64 * 4;                                // per-lane dummy words for the branch-free flush
     }
 };
 
-template <int BM, int BN, int KS, bool VEC>
-__global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
-    using Cfg = ConvCfg<BM, BN, KS>;
-    constexpr int LDA = Cfg::LDA;
-    constexpr int NT = Cfg::kThreads;
+template <int BM, int WN, int WM, bool VEC>
+__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p) {
+    using Cfg = ConvCfg<BM, WN, WM>;
+    constexpr int BN = Cfg::BN, NT = Cfg::NT, NW = Cfg::NW, RBW = Cfg::RBW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* acc_lds = reinterpret_cast<float*>(smem);
-    float* slab0 = acc_lds + BM * BN;                    // 2 x { Bs [KS][BN], As [BM][LDA] }
-    int32_t* in_list = reinterpret_cast<int32_t*>(slab0 + 2 * Cfg::SLAB);
+    float* a_buf = reinterpret_cast<float*>(smem);
+    float* acc_lds = a_buf + 2 * kAFloats;
+    int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + BM * BN);
     int32_t* cnt = in_list + p.k_vol * BM;
-    int32_t* klist = cnt + 64;
-    uint8_t* out_list = reinterpret_cast<uint8_t*>(klist + 64);
+    int32_t* work = cnt + 32;
+    uint8_t* out_list = reinterpret_cast<uint8_t*>(work + 32 * Cfg::NCH);
     // float index (relative to acc_lds) of 64 dummy words behind everything else
-    const int dummy_off = (int)((Cfg::lds_bytes(p.k_vol) - 64 * 4) / 4);
+    const int dummy_off = (int)((Cfg::lds_bytes(p.k_vol) - 64 * 4 - 2 * kAFloats * 4) / 4);
 
-    // XCD-aware tile mapping: the column blocks of one row tile share an XCD (their gathers
-    // hit the same L2), consecutive row tiles round-robin over the 8 XCDs.
+    // XCD-aware tile mapping: the column tiles of one row tile share an XCD (their gathers hit the
+    // same L2), consecutive row tiles round-robin over the 8 XCDs.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, g = bid >> 3;
     const int tn = g % p.tiles_n;
@@ -135,17 +108,18 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int wn = wave % WN, wm = wave / WN;
 
     // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
     if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
         for (int r = tid; r < BM; r += NT) {
-            in_list[r] = (int32_t)(row0 + r);
+            in_list[r] = (int32_t)min(row0 + r, p.m_in - 1);
             out_list[r] = (uint8_t)r;
         }
         if (tid == 0) cnt[0] = rows_here;
     } else {
-        for (int k = wave; k < p.k_vol; k += Cfg::kWaves) {
+        for (int k = wave; k < p.k_vol; k += NW) {
             int pos = 0;
             for (int c = 0; c < BM; c += 64) {
                 const int r = c + lane;
@@ -163,338 +137,192 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
             if (lane == 0) cnt[k] = pos;
         }
     }
-    // ---- zero the accumulator tile -----------------------------------------------------------
     for (int e = tid; e < BM * BN / 4; e += NT)
         reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    int nact;
-    {   // active offsets (n_k > 0), in ascending k: every wave computes the same list
-        const bool act = lane < p.k_vol && cnt[lane] > 0;
-        const unsigned long long m = __ballot(act);
-        if (wave == 0 && act) klist[popc_below(m)] = lane;
-        nact = __popcll(m);
+    // ---- work list: (offset, chunk of <= 128 pairs), ascending k: wave 0, exclusive scan -----
+    if (wave == 0) {
+        const int c = lane < p.k_vol ? cnt[lane] : 0;
+        const int nc = (c + kChunk - 1) / kChunk;
+        int incl = nc;
+        for (int off = 1; off < 32; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        for (int j = 0; j < nc; ++j)
+            work[incl - nc + j] = lane | (j << 8) | (min(kChunk, c - j * kChunk) << 16);
+        if (lane == 31) cnt[31] = incl;
     }
     __syncthreads();
+    const int nwork = __builtin_amdgcn_readfirstlane(cnt[31]);
+    const int nslab = (p.c_in + kSlab - 1) / kSlab;
+    const int nit = nwork * nslab;
 
-    const int nslab = (p.c_in + KS - 1) / KS;
-    const int nit = nact * nslab;
-
-    struct Regs {
-        f32x4 a_v[VEC ? Cfg::A_VEC : 1];
-        f32x4 b_v[VEC ? Cfg::B_VEC : 1];
-        float a_s[VEC ? 1 : Cfg::A_SCL];
-        float b_s[VEC ? 1 : Cfg::B_SCL];
-    };
-
-    // buffer descriptors (built from kernel arguments only: wave-uniform, live in SGPRs)
-    const u32x4 rsrc_a = make_rsrc(p.in_a, (unsigned)(p.m_in * p.c_in_a * 4));
-    const u32x4 rsrc_b = make_rsrc(p.in_b ? p.in_b : p.in_a, (unsigned)(p.m_in * p.c_in_b * 4));
-    const u32x4 rsrc_w = make_rsrc(p.w, (unsigned)(p.k_vol * p.c_in * p.c_out * 4));
-
-    // counted retirement of the asm loads: wait until at most `keep` vector-memory operations are
-    // outstanding; naming every register of the set keeps the compiler from touching them earlier
-    auto retire = [&](Regs& rg) {
-        if constexpr (VEC) {
-            constexpr int NL = Cfg::A_VEC + Cfg::B_VEC;      // loads of the younger set stay in flight
-            static_assert(Cfg::A_VEC == 2 && (Cfg::B_VEC == 1 || Cfg::B_VEC == 2), "register-set shape");
-            if constexpr (Cfg::B_VEC == 2)
-                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rg.a_v[0]), "+v"(rg.a_v[1]), "+v"(rg.b_v[0]), "+v"(rg.b_v[1]) : "n"(NL) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(rg.a_v[0]), "+v"(rg.a_v[1]), "+v"(rg.b_v[0]) : "n"(NL) : "memory");
-        }
-    };
-
-    // Position in the (active offset, K-slab) sequence, kept in SGPRs and advanced incrementally
-    // (no integer division, one LDS lookup per OFFSET rather than per slab).
-    struct Cursor { int ai, slab, k, nk; };
+    // Position in the (work item, K-slab) sequence, kept in SGPRs and advanced incrementally.
+    struct Cursor { int wi, slab, k, start, n; };
     auto cursor_load = [&](Cursor& c) {
-        if (c.ai < nact) {
-            c.k = __builtin_amdgcn_readfirstlane(klist[c.ai]);
-            c.nk = __builtin_amdgcn_readfirstlane(cnt[c.k]);
+        if (c.wi < nwork) {
+            const int w = __builtin_amdgcn_readfirstlane(work[c.wi]);
+            c.k = w & 0xff;
+            c.start = ((w >> 8) & 0xff) * kChunk;
+            c.n = w >> 16;
         } else {
-            c.k = 0;
-            c.nk = 0;                          // past the end: every lane loads nothing
+            c.k = 0; c.start = 0; c.n = 0;
         }
     };
     auto cursor_next = [&](Cursor& c) {
         if (++c.slab == nslab) {
             c.slab = 0;
-            ++c.ai;
+            ++c.wi;
             cursor_load(c);
         }
     };
-    Cursor pf{0, 0, 0, 0}, cur{0, 0, 0, 0};
+    Cursor pf{0, 0, 0, 0, 0}, cur{0, 0, 0, 0, 0};
     cursor_load(pf);
-    cursor_load(cur);
+    cur = pf;
 
-    // global -> registers for the slab at the prefetch cursor (zero-filled beyond n_k rows / c_in
-    // channels), then advance the cursor.  Past the end the same loads are issued with
-    // out-of-range offsets (zeros, no traffic): every stage then has exactly one younger register
-    // set in flight and ONE counted wait fits all.
-    auto prefetch = [&](Regs& rg) {
-        const bool live = pf.ai < nact;
-        const int k = pf.k;
-        const int k0 = pf.slab * KS;
-        const int n_k = pf.nk;
+    const int nt16 = p.c_out >> 4;
+    const float* wp_wave = p.wp + ((size_t)(n0 >> 4) + wn) * 512 + lane * 4;
+
+    // global -> LDS (A, by DMA) and global -> registers (this wave's W fragment) for the stage at `pf`
+    auto issue = [&](int buf, f32x4& w0, f32x4& w1) {
+        const int k0 = pf.slab * kSlab;
+        const float* wsrc = wp_wave + (size_t)(pf.k * nslab + pf.slab) * nt16 * 512;
+        w0 = *reinterpret_cast<const f32x4*>(wsrc);
+        w1 = *reinterpret_cast<const f32x4*>(wsrc + 256);
+        const int32_t* il = in_list + pf.k * BM + pf.start;
         if constexpr (VEC) {
-            // Buffer loads through wave-uniform descriptors: a lane that has nothing to load
-            // (row >= n_k, channel >= c_in) passes an out-of-range offset and the hardware
-            // bounds check returns zeros -- no branches around the loads.
-            const bool from_a = k0 < p.c_in_a;             // uniform: slabs never straddle a|b
-            const u32x4 rs = from_a ? rsrc_a : rsrc_b;
+            const bool from_a = k0 < p.c_in_a;                 // uniform: slabs never straddle a|b
+            const float* src = from_a ? p.in_a : p.in_b;
             const int cw = from_a ? p.c_in_a : p.c_in_b;
             const int cbase = from_a ? k0 : k0 - p.c_in_a;
-            unsigned rowv[Cfg::A_VEC];
-#pragma unroll
-            for (int j = 0; j < Cfg::A_VEC; ++j)        // both list reads in flight, one LDS wait
-                rowv[j] = (unsigned)in_list[k * BM + min((tid + j * NT) / (KS / 4), BM - 1)];
-#pragma unroll
-            for (int j = 0; j < Cfg::A_VEC; ++j) {
-                const int e = tid + j * NT;
-                const int pos = e / (KS / 4), cl = 4 * (e % (KS / 4));
-                bool ok = pos < n_k && k0 + cl < p.c_in;
-                if constexpr ((Cfg::A_VEC) * NT > BM * KS / 4) ok = ok && e < BM * KS / 4;
-                const unsigned off = ok ? (rowv[j] * (unsigned)cw + (unsigned)(cbase + cl)) * 4u : 0xFFFFFFF0u;
-                buffer_load_x4(rg.a_v[j], off, rs);
-            }
-#pragma unroll
-            for (int j = 0; j < Cfg::B_VEC; ++j) {
-                const int e = tid + j * NT;
-                const int kr = e / (BN / 4), cq = e % (BN / 4);
-                bool ok = live && k0 + kr < p.c_in;
-                if constexpr ((Cfg::B_VEC) * NT > KS * BN / 4) ok = ok && e < KS * BN / 4;
-                const unsigned off = ok ? (((unsigned)k * p.c_in + k0 + kr) * (unsigned)p.c_out + n0 + 4 * cq) * 4u
-                                        : 0xFFFFFFF0u;
-                buffer_load_x4(rg.b_v[j], off, rsrc_w);
+            __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(p.m_in * cw * 4), 0x00020000);
+            char* dst = reinterpret_cast<char*>(a_buf + buf * kAFloats);
+            for (int t = wave; t < kChunk / 8; t += NW) {      // 8 rows x 128 B per wave-instruction
+                if (8 * t < pf.n) {
+                    const int r = 8 * t + (lane >> 3);
+                    const int row = il[min(r, pf.n - 1)];
+                    const int ch = (lane & 7) ^ ((r >> 1) & 7);          // source chunk for this LDS slot
+                    const bool ok = r < pf.n && cbase + 4 * ch < cw;
+                    const int voff = ok ? (row * cw + cbase + 4 * ch) * 4 : (int)0x80000000;   // OOB -> zeros
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, 0, 0, 0);
+                }
             }
         } else {
-#pragma unroll
-            for (int j = 0; j < Cfg::A_SCL; ++j) {
-                const int e = tid + j * NT;
-                const int pos = e / KS, col = k0 + e % KS;
+            float* As = a_buf + buf * kAFloats;
+            for (int e = tid; e < pf.n * kSlab; e += NT) {
+                const int r = e >> 5, c = e & 31, col = k0 + c;
                 float v = 0.f;
-                if (live && e < BM * KS && pos < n_k && col < p.c_in) {
-                    const int64_t row = in_list[k * BM + pos];
-                    v = (col < p.c_in_a) ? p.in_a[row * p.c_in_a + col]
-                                         : p.in_b[row * p.c_in_b + (col - p.c_in_a)];
+                if (col < p.c_in) {
+                    const int64_t row = il[r];
+                    v = (col < p.c_in_a) ? p.in_a[row * p.c_in_a + col] : p.in_b[row * p.c_in_b + (col - p.c_in_a)];
                 }
-                rg.a_s[j] = v;
-            }
-#pragma unroll
-            for (int j = 0; j < Cfg::B_SCL; ++j) {
-                const int e = tid + j * NT;
-                const int kr = e / BN, cc = e % BN;
-                float v = 0.f;
-                if (live && e < KS * BN && k0 + kr < p.c_in)
-                    v = p.w[((int64_t)k * p.c_in + k0 + kr) * p.c_out + n0 + cc];
-                rg.b_s[j] = v;
+                As[r * kSlab + 4 * ((c >> 2) ^ ((r >> 1) & 7)) + (c & 3)] = v;
             }
         }
         cursor_next(pf);
     };
 
-    auto store_slab = [&](const Regs& rg, int buf) {
-        float* Bs = slab0 + buf * Cfg::SLAB;
-        float* As = Bs + KS * BN;
-        if constexpr (VEC) {
+    f32x4 acc[RBW];
 #pragma unroll
-            for (int j = 0; j < Cfg::A_VEC; ++j) {
-                const int e = tid + j * NT;
-                if ((j + 1) * NT <= BM * KS / 4 || e < BM * KS / 4)
-                    *reinterpret_cast<f32x4*>(As + (e / (KS / 4)) * LDA + 4 * (e % (KS / 4))) = rg.a_v[j];
-            }
+    for (int b = 0; b < RBW; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int li = lane & 15, lq = lane >> 4;
+    const int aoff = li * kSlab + 4 * (lq ^ ((li >> 1) & 7));      // float offset of chunk lq in row li
+
+    // MFMA half of a stage: the wave's first NB row blocks are active.  MFMA step (j, e) takes
+    // k = 16 j + 4 (lane >> 4) + e from both operands; all A fragments are read up front and the
+    // MFMAs interleave the NB independent accumulators.
+    auto mma = [&](auto nb_tag, const float* As, const f32x4 w0, const f32x4 w1) {
+        constexpr int NB = decltype(nb_tag)::value;
+        f32x4 a0[NB], a1[NB];
 #pragma unroll
-            for (int j = 0; j < Cfg::B_VEC; ++j) {
-                const int e = tid + j * NT;
-                if ((j + 1) * NT <= KS * BN / 4 || e < KS * BN / 4) reinterpret_cast<f32x4*>(Bs)[e] = rg.b_v[j];
-            }
-        } else {
+        for (int b = 0; b < NB; ++b) {
+            const float* q = As + (wm + WM * b) * (16 * kSlab) + aoff;
+            a0[b] = *reinterpret_cast<const f32x4*>(q);
+            a1[b] = *reinterpret_cast<const f32x4*>(As + (wm + WM * b) * (16 * kSlab) + (aoff ^ 16));
+        }
 #pragma unroll
-            for (int j = 0; j < Cfg::A_SCL; ++j) {
-                const int e = tid + j * NT;
-                if (e < BM * KS) As[(e / KS) * LDA + e % KS] = rg.a_s[j];
-            }
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int j = 0; j < Cfg::B_SCL; ++j) {
-                const int e = tid + j * NT;
-                if (e < KS * BN) Bs[e] = rg.b_s[j];
+            for (int b = 0; b < NB; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[b][e], w0[e], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[b][e], w1[e], acc[b], 0, 0, 0);
+    };
+    // After the last slab of an offset (chunk): add the NB register blocks into the LDS tile through the
+    // pair list's local output row.  Batched and branch-free: NB list words, then 4 NB tile reads, then
+    // 4 NB writes (3 LDS round trips); rows beyond n go to a per-lane dummy word.
+    auto flush = [&](auto nb_tag) {
+        constexpr int NB = decltype(nb_tag)::value;
+        const uint8_t* ol = out_list + cur.k * BM + cur.start;
+        uint32_t o4[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            o4[b] = *reinterpret_cast<const uint32_t*>(ol + 16 * (wm + WM * b) + 4 * lq);
+        int addr[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int prow = 16 * (wm + WM * b) + 4 * lq + r;
+                const int orow = (o4[b] >> (8 * r)) & 0xff;
+                addr[b][r] = prow < cur.n ? orow * BN + 16 * wn + li : dummy_off + lane;
             }
+        float old[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) old[b][r] = acc_lds[addr[b][r]];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_lds[addr[b][r]] = old[b][r] + acc[b][r];
+            acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-
-    const int l31 = lane & 31, lhi = lane >> 5;
-
-#ifdef LIDIFF_CONV_TIMING
-    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    floatx16 acc[Cfg::MAXB];
-#pragma unroll
-    for (int s = 0; s < Cfg::MAXB; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-
-    // One pipeline stage.  On entry LDS buffer (it & 1) holds slab `it` (published by the
-    // previous barrier) and `rg` holds slab it+1, loaded two stages ago.  The stage writes slab
-    // it+1 into the OTHER buffer, refills `rg` with slab it+3, multiplies slab `it`, and ends with
-    // the single barrier of the iteration -- LDS stores and global loads issue in the shadow of
-    // the 64-cycle MFMAs.  MFMA blocks (row block, col block) of the offset are dealt round-robin
-    // to the 8 waves.  K is consumed in a permuted order: step (j, e) takes
-    // k = 8j + 4*(lane>>5) + e from BOTH operands, so an A fragment is one ds_read_b128 per 4 MFMAs.
-    auto stage = [&](int it, Regs& rg) {
-        const float* Bs = slab0 + (it & 1) * Cfg::SLAB;
-        const float* As = Bs + KS * BN;
-        const int k = cur.k;
-        const int slab = cur.slab;
-        const int n_k = cur.nk;
-        const int nrb = (n_k + 31) >> 5;
-        const int nblk = nrb * Cfg::NCB;
-
-        // staging half of the stage: slab it+1 registers -> the other LDS buffer, refill with it+3
-        auto stage_io = [&]() {
-            TSTAMP(t0);
-            retire(rg);                       // the other set (slab it+2, maybe a dummy) stays in flight
-            TSTAMP(t1);
-            store_slab(rg, (it + 1) & 1);     // past the end: zeros into the free buffer, harmless
-            TSTAMP(t2);
-            prefetch(rg);
-            TSTAMP(t3);
-            TADD(0, t0, t1); TADD(1, t1, t2); TADD(2, t2, t3);
-        };
-
-        // MFMA half: this wave's active blocks are s = 0 .. nb_w-1 (scalar).  Fragments are
-        // double-buffered in registers: the ds_reads of step j+1 are issued before the MFMAs of
-        // step j (sched_barrier keeps them there), so LDS latency hides under 4*NB MFMAs.
-        const int nb_w = (nblk > wave) ? (nblk - wave + Cfg::kWaves - 1) / Cfg::kWaves : 0;
-        auto mma = [&](auto nb_tag) {
-            constexpr int NB = decltype(nb_tag)::value;
-            const float* ap[NB];
-            const float* bp[NB];
-#pragma unroll
-            for (int s = 0; s < NB; ++s) {
-                const int b = wave + s * Cfg::kWaves;
-                const int rb = b / Cfg::NCB, cb = b % Cfg::NCB;
-                ap[s] = As + (rb * 32 + l31) * LDA + 4 * lhi;
-                bp[s] = Bs + (4 * lhi) * BN + cb * 32 + l31;
-            }
-            struct Frag { float4 a[NB]; float b[NB][4]; };
-            auto load_frag = [&](int j, Frag& f) {
-#pragma unroll
-                for (int s = 0; s < NB; ++s) {
-                    f.a[s] = *reinterpret_cast<const float4*>(ap[s] + 8 * j);
-                    const float* q = bp[s] + 8 * j * BN;
-                    f.b[s][0] = q[0]; f.b[s][1] = q[BN]; f.b[s][2] = q[2 * BN]; f.b[s][3] = q[3 * BN];
-                }
-            };
-            auto issue = [&](const Frag& f) {
-#pragma unroll
-                for (int s = 0; s < NB; ++s) {
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s].x, f.b[s][0], acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s].y, f.b[s][1], acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s].z, f.b[s][2], acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s].w, f.b[s][3], acc[s], 0, 0, 0);
-                }
-            };
-            static_assert(KS / 8 == 4, "fragment pipeline written for 4 steps per slab");
-            Frag f0, f1;
-            load_frag(0, f0);
-            load_frag(1, f1);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frag(2, f0);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(f1);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frag(3, f1);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(f1);
-        };
-        auto mma_any = [&]() {
-            if constexpr (Cfg::MAXB >= 2) {
-                if (nb_w >= 2) mma(std::integral_constant<int, 2>{});
-                else if (nb_w == 1) mma(std::integral_constant<int, 1>{});
-            } else {
-                if (nb_w >= 1) mma(std::integral_constant<int, 1>{});
-            }
-        };
-
-        // The two waves of a SIMD (w and w+4) run the two halves in OPPOSITE order, so one
-        // wave's staging (LDS stores, address generation, global loads) overlaps the other
-        // wave's MFMAs instead of both leaving the matrix pipe idle at the same time.
-        // (stage_io appears ONCE in the instruction stream: its asm-loaded registers must not pass
-        // through a control-flow merge, or the compiler inserts copies ahead of the counted wait.)
-        const bool io_first = wave < Cfg::kWaves / 2;
-        TSTAMP(m0);
-        if (!io_first) mma_any();
-        TSTAMP(m1);
-        stage_io();
-        TSTAMP(m2);
-        if (io_first) mma_any();
-        TSTAMP(m3);
-        TADD(3, m0, m1); TADD(3, m2, m3);
-
-        if (slab == nslab - 1) {         // offset finished: flush registers into the LDS tile
-            // Batched and branch-free: 16 list lookups, then 16 tile reads, then 16 writes per
-            // block (3 LDS round trips instead of 48); rows beyond n_k go to a per-lane dummy word.
-#pragma unroll
-            for (int s = 0; s < Cfg::MAXB; ++s) {
-                const int b = wave + s * Cfg::kWaves;
-                if (b < nblk) {
-                    const int rb = b / Cfg::NCB, cb = b % Cfg::NCB;
-                    const int col = cb * 32 + l31;
-                    int addr[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int prow = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        const int orow = out_list[k * BM + prow];
-                        addr[r] = prow < n_k ? orow * BN + col : dummy_off + lane;
-                    }
-                    float old[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) old[r] = acc_lds[addr[r]];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        acc_lds[addr[r]] = old[r] + acc[s][r];
-                        acc[s][r] = 0.f;
-                    }
-                }
+    auto stage_compute = [&](auto nb_tag, const float* As, const f32x4 w0, const f32x4 w1, bool last) {
+        mma(nb_tag, As, w0, w1);
+        if (last) flush(nb_tag);
+    };
+    auto compute_dispatch = [&](int nb, const float* As, const f32x4 w0, const f32x4 w1, bool last) {
+        if constexpr (RBW >= 8) {
+            if (nb > 4) {
+                if (nb == 8) return stage_compute(std::integral_constant<int, 8>{}, As, w0, w1, last);
+                if (nb == 7) return stage_compute(std::integral_constant<int, 7>{}, As, w0, w1, last);
+                if (nb == 6) return stage_compute(std::integral_constant<int, 6>{}, As, w0, w1, last);
+                return stage_compute(std::integral_constant<int, 5>{}, As, w0, w1, last);
             }
         }
+        if constexpr (RBW >= 4) {
+            if (nb > 2) {
+                if (nb == 4) return stage_compute(std::integral_constant<int, 4>{}, As, w0, w1, last);
+                return stage_compute(std::integral_constant<int, 3>{}, As, w0, w1, last);
+            }
+        }
+        if constexpr (RBW >= 2) {
+            if (nb == 2) return stage_compute(std::integral_constant<int, 2>{}, As, w0, w1, last);
+        }
+        if (nb == 1) return stage_compute(std::integral_constant<int, 1>{}, As, w0, w1, last);
+    };
+
+    f32x4 wc0, wc1, wn0, wn1;
+    if (nit > 0) issue(0, wc0, wc1);
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        if (it + 1 < nit) issue((it + 1) & 1, wn0, wn1);
+        const int nrb = (cur.n + 15) >> 4;
+        const int nb = min(RBW, max(0, (nrb - wm + WM - 1) / WM));
+        compute_dispatch(nb, a_buf + (it & 1) * kAFloats, wc0, wc1, cur.slab == nslab - 1);
         cursor_next(cur);
-        TSTAMP(b0);
-        __syncthreads();                 // slab it+1 visible, buffer (it & 1) free again
-        TSTAMP(b1);
-        TADD(4, m3, b0); TADD(5, b0, b1); TADD(6, m0, b1);
-    };
-
-#ifdef LIDIFF_CONV_TIMING
-    const long long t_begin = __builtin_readcyclecounter();
-#endif
-    Regs r0, r1;
-    if (nit > 0) {
-        prefetch(r0);
-        prefetch(r1);
-        retire(r0);
-        store_slab(r0, 0);
-        prefetch(r0);
+        __syncthreads();                  // stage it+1 landed (vmcnt) and visible; image (it & 1) free
+        wc0 = wn0;
+        wc1 = wn1;
     }
-    __syncthreads();
-    for (int it = 0; it < nit; it += 2) {     // stage(it) consumes the register set holding slab it+1
-        stage(it, r1);
-        if (it + 1 < nit) stage(it + 1, r0);
-    }
-    if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing dummy loads
-#ifdef LIDIFF_CONV_TIMING
-    if (p.dbg != nullptr && lane == 0) {
-        tsum[7] = __builtin_readcyclecounter() - t_begin;      // whole slab loop incl. pipeline fill
-        long long* d = p.dbg + ((long long)blockIdx.x * Cfg::kWaves + wave) * 9;
-        for (int q = 0; q < 8; ++q) d[q] = tsum[q];
-        d[8] = nit;
-    }
-#endif
-    __syncthreads();
 
     // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
     for (int e = tid; e < rows_here * (BN / 4); e += NT) {
@@ -521,12 +349,30 @@ __global__ __launch_bounds__(512) void spconv_fwd_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int KS, bool VEC>
+// W [K, c_in, c_out] row-major  ->  [K][slab][c_out/16][j 0..1][lane 0..63][e 0..3]  with
+// k_in = 32 slab + 16 j + 4 (lane >> 4) + e  and  col = 16 nt + (lane & 15); rows beyond c_in are zero.
+__global__ void pack_weights_kernel(const float* __restrict__ w, int k_vol, int c_in, int c_out, int nslab,
+                                    float* __restrict__ wp, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63), j = (int)((idx >> 8) & 1);
+    int64_t rest = idx >> 9;
+    const int nt16 = c_out >> 4;
+    const int nt = (int)(rest % nt16);
+    rest /= nt16;
+    const int slab = (int)(rest % nslab);
+    const int k = (int)(rest / nslab);
+    const int kin = 32 * slab + 16 * j + 4 * (lane >> 4) + e;
+    const int col = 16 * nt + (lane & 15);
+    wp[idx] = kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f;
+}
+
+template <int BM, int WN, int WM, bool VEC>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
-    using Cfg = ConvCfg<BM, BN, KS>;
+    using Cfg = ConvCfg<BM, WN, WM>;
     const size_t lds = Cfg::lds_bytes(p.k_vol);
     LIDIFF_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded");
-    auto kern = spconv_fwd_kernel<BM, BN, KS, VEC>;
+    auto kern = spconv_fwd_kernel<BM, WN, WM, VEC>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -535,30 +381,42 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     }
     ConvParams q = p;
     q.tiles_m = (int)ceil_div(p.m_out, BM);
-    q.tiles_n = p.c_out / BN;
+    q.tiles_n = p.c_out / Cfg::BN;
     const unsigned grid = (unsigned)(ceil_div(q.tiles_m, 8) * 8 * q.tiles_n);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::kThreads), lds, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), lds, st, q);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
 
-template <int BN>
+template <int BM, int WN, int WM>
 static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
-    if (vec) return launch_fwd<128, BN, 32, true>(p, st);
-    return launch_fwd<128, BN, 32, false>(p, st);
+    if (vec) return launch_fwd<BM, WN, WM, true>(p, st);
+    return launch_fwd<BM, WN, WM, false>(p, st);
 }
 
 }  // namespace lidiff
 
 using namespace lidiff;
 
-static long long* g_conv_dbg = nullptr;
-#ifdef LIDIFF_CONV_TIMING
-extern "C" void lidiff_debug_set_conv_timing_buffer(long long* d_buf) { g_conv_dbg = d_buf; }
-#endif
+extern "C" int64_t lidiff_spconv_packed_weight_floats(int32_t k_vol, int32_t c_in, int32_t c_out) {
+    return (int64_t)k_vol * ((c_in + kSlab - 1) / kSlab) * kSlab * c_out;
+}
+
+extern "C" int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out,
+                                          float* w_packed, void* stream) {
+    LIDIFF_CHECK_ARG(w != nullptr && w_packed != nullptr, "null pointer");
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && c_in > 0, "kernel volume must be 1..27, c_in > 0");
+    LIDIFF_CHECK_ARG(c_out > 0 && c_out % 16 == 0, "c_out must be a multiple of 16");
+    const int nslab = (c_in + kSlab - 1) / kSlab;
+    const int64_t total = lidiff_spconv_packed_weight_floats(k_vol, c_in, c_out);
+    pack_weights_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w, k_vol, c_in, c_out, nslab,
+                                                                                         w_packed, total);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
-                                 const float* w, const int32_t* nbr, int32_t k_vol, int64_t m_in,
+                                 const float* w_packed, const int32_t* nbr, int32_t k_vol, int64_t m_in,
                                  int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
                                  const float* ep_shift, const float* residual, int32_t relu,
                                  void* stream) {
@@ -566,28 +424,29 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
     LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
-    LIDIFF_CHECK_ARG(c_out > 0 && c_out % 32 == 0, "c_out must be a multiple of 32");
+    LIDIFF_CHECK_ARG(c_out > 0 && c_out % 16 == 0, "c_out must be a multiple of 16");
     LIDIFF_CHECK_ARG(m_out >= 0 && m_in >= 0, "negative rows");
     if (m_out == 0) return 0;
+    LIDIFF_CHECK_ARG(m_in > 0, "outputs without inputs");
     ConvParams p{};
-    p.in_a = in_a; p.in_b = in_b; p.w = w; p.nbr = nbr; p.out = out;
+    p.in_a = in_a; p.in_b = in_b; p.wp = w_packed; p.nbr = nbr; p.out = out;
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
-    p.k_vol = k_vol; p.relu = relu; p.dbg = g_conv_dbg;
+    p.k_vol = k_vol; p.relu = relu;
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
-    LIDIFF_CHECK_ARG(al16(w) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
-                     "w/out/epilogue pointers must be 16-byte aligned");
-    const bool fits32 = m_in * (int64_t)c_in_a * 4 < (1ll << 31) && m_in * (int64_t)c_in_b * 4 < (1ll << 31) &&
-                        (int64_t)k_vol * (c_in_a + c_in_b) * c_out * 4 < (1ll << 31);
-    LIDIFF_CHECK_ARG(fits32, "a feature or weight matrix exceeds the 2 GiB buffer-descriptor range");
-    LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % 32 == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
+    LIDIFF_CHECK_ARG(al16(w_packed) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
+                     "w_packed/out/epilogue pointers must be 16-byte aligned");
+    const bool fits32 = m_in * (int64_t)c_in_a * 4 < (1ll << 31) && m_in * (int64_t)c_in_b * 4 < (1ll << 31);
+    LIDIFF_CHECK_ARG(fits32, "a feature matrix exceeds the 2 GiB buffer-descriptor range");
+    LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % kSlab == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
     const bool vec = c_in_a % 4 == 0 && c_in_b % 4 == 0 && al16(in_a) && al16(in_b);
     hipStream_t st = (hipStream_t)stream;
-    if (c_out % 128 == 0) return dispatch_fwd<128>(p, vec, st);
-    if (c_out % 96 == 0) return dispatch_fwd<96>(p, vec, st);
-    if (c_out % 64 == 0) return dispatch_fwd<64>(p, vec, st);
-    return dispatch_fwd<32>(p, vec, st);
+    if (c_out % 128 == 0) return dispatch_fwd<128, 8, 1>(p, vec, st);
+    if (c_out % 96 == 0) return dispatch_fwd<128, 6, 1>(p, vec, st);
+    if (c_out % 64 == 0) return dispatch_fwd<128, 4, 2>(p, vec, st);
+    if (c_out % 32 == 0) return dispatch_fwd<128, 2, 4>(p, vec, st);
+    return dispatch_fwd<128, 1, 8>(p, vec, st);
 }
 
 extern "C" int lidiff_spconv_bwd_w(const float*, int32_t, const float*, int32_t, const float*,

@@ -167,7 +167,35 @@ PROFILER: ConvProfiler | None = None
 
 def conv_variant(c_out: int) -> str:
     """Which template instantiation lidiff_spconv_fwd dispatches to (BN = output-channel tile)."""
-    return "bn128" if c_out % 128 == 0 else "bn96" if c_out % 96 == 0 else "bn64" if c_out % 64 == 0 else "bn32"
+    return ("bn128" if c_out % 128 == 0 else "bn96" if c_out % 96 == 0 else "bn64" if c_out % 64 == 0
+            else "bn32" if c_out % 32 == 0 else "bn16")
+
+
+def pack_weights(w: torch.Tensor) -> torch.Tensor:
+    """[K, C_in, C_out] kernel -> MFMA fragment order (include/lidiff_amd.h, lidiff_spconv_pack_weights)."""
+    require_device(w)
+    w = w.detach().contiguous().float()
+    k, c_in, c_out = w.shape
+    n = _lib.load().lidiff_spconv_packed_weight_floats(k, c_in, c_out)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    call("lidiff_spconv_pack_weights", ptr(w), k, c_in, c_out, ptr(wp), stream_ptr())
+    return wp
+
+
+def packed_weights(w: torch.Tensor) -> torch.Tensor:
+    """pack_weights(w), cached on the tensor object (a module's Parameter) until it is modified in
+    place, reallocated or moved: the pack costs one pass over the weights per optimizer step, not
+    per forward."""
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    key = (w.data_ptr(), w._version, tuple(w3.shape), w.device)
+    hit = getattr(w, "_lidiff_packed", None)
+    if hit is None or hit[0] != key:
+        hit = (key, pack_weights(w3))
+        try:
+            w._lidiff_packed = hit
+        except AttributeError:      # not attachable: pack every call
+            pass
+    return hit[1]
 
 
 def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
@@ -176,11 +204,12 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     """Sparse convolution forward with fused epilogue (MinkowskiConvolution[Transpose];
     minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1)."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
+    wp = packed_weights(w)
     if w.dim() == 2:
-        w = w.unsqueeze(0)
+        k, (c_in, c_out) = 1, w.shape
+    else:
+        k, c_in, c_out = w.shape
     in_a = in_a.contiguous()
-    w = w.contiguous()
-    k, c_in, c_out = w.shape
     c_a = in_a.shape[1]
     c_b = 0
     if in_b is not None:
@@ -199,7 +228,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         pairs = prof.pairs(nbr, m_out)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
-    call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(w), ptr(nbr), k, in_a.shape[0], m_out,
+    call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, in_a.shape[0], m_out,
          c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), stream_ptr())
     if prof is not None:
         end.record()

@@ -14,16 +14,17 @@
 // Decomposition: the WN*WM waves form a WN x WM grid.  Wave (wn, wm) owns output columns
 // [16 wn, 16 wn + 16) and the row blocks rb = wm (mod WM) of the stage, so with WM = 1 every wave
 // issues exactly the same MFMA stream (no block-dealing imbalance between the SIMDs).
-//   * B operand: the wave's [32 k x 16 col] piece of W[k] comes straight from HBM/L2 into 8 VGPRs in
-//     MFMA fragment order (weights are pre-packed once by lidiff_spconv_pack_weights: one fully
-//     coalesced 2 KB read per wave and stage) and is reused by all of the wave's row blocks.
-//   * A operand: the gathered rows of a stage (<= 128 pairs x 32 channels) are written by LDS-DMA
+//   * B operand: the wave's [KS k x 16 col] piece of W[k] comes straight from HBM/L2 into VGPRs in
+//     MFMA fragment order (weights are pre-packed once by lidiff_spconv_pack_weights: fully
+//     coalesced 2 KB runs) and is reused by all of the wave's row blocks.
+//   * A operand: the gathered rows of a stage (<= 128 pairs x KS channels) are written by LDS-DMA
 //     (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass) into a double-buffered
-//     [128][32] image whose 16-byte chunks are XOR-swizzled THROUGH THE SOURCE ADDRESS
-//     (slot = chunk ^ ((row >> 1) & 7)), which makes the ds_read_b128 fragment reads of all eight
-//     waves bank-conflict free.  K is consumed in a permuted order shared by both operands.
-//   * A stage = (offset, chunk of <= 128 pairs, 32-channel slab); loads of stage i+1 are issued before
-//     the MFMAs of stage i; one barrier per stage.
+//     [128][KS] image whose 16-byte chunks are XOR-swizzled THROUGH THE SOURCE ADDRESS, which makes
+//     the ds_read_b128 fragment reads of all waves bank-conflict free.  K is consumed in a permuted
+//     order shared by both operands.
+//   * A stage = (offset, chunk of <= 128 pairs, KS-channel slab), KS = 64 when the channel counts
+//     allow it (half the barriers and half the per-stage control per MFMA), else 32.  Loads of stage
+//     i+1 are issued before the MFMAs of stage i; one barrier per stage.
 //   * After the last slab of an offset the register accumulators are added into the LDS tile through
 //     the pair list's local output row (each output row occurs at most once per offset and waves own
 //     disjoint column / row-block sets, so the LDS read-modify-write is race free).
@@ -39,9 +40,7 @@ namespace lidiff {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int kSlab = 32;     // input channels per stage
 constexpr int kChunk = 128;   // pair rows per stage
-constexpr int kAFloats = kChunk * kSlab;   // one A image: 16 KB
 
 struct ConvParams {
     const float* in_a;
@@ -55,9 +54,20 @@ struct ConvParams {
     int64_t m_in, m_out;
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
     int tiles_m, tiles_n;
+    int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
+                              // 2 = no barrier, 4 = no flush
 };
 
-template <int BM, int WN, int WM>
+#ifdef LIDIFF_CONV_PROBE
+#define PROBE(bit) (p.probe & (bit))
+#else
+#define PROBE(bit) false
+#endif
+
+template <int I>
+using ic = std::integral_constant<int, I>;
+
+template <int BM, int WN, int WM, int KS>
 struct ConvCfg {
     static constexpr int BN = 16 * WN;
     static constexpr int NW = WN * WM;
@@ -65,12 +75,14 @@ struct ConvCfg {
     static constexpr int RB = kChunk / 16;       // row blocks per stage
     static constexpr int RBW = RB / WM;          // row blocks per wave
     static constexpr int NCH = BM / kChunk;      // chunks per offset (upper bound)
+    static constexpr int A_FLOATS = kChunk * KS; // one A image (16 / 32 KB)
+    static_assert(KS == 32 || KS == 64, "KS");
     static_assert(BM % kChunk == 0 && BM <= 256, "BM");     // out_list is uint8
     static_assert(RB % WM == 0, "WM must divide 8");
     static_assert(NT <= 1024, "workgroup size");
 
     __host__ __device__ static size_t lds_bytes(int k_vol) {
-        size_t b = 2 * (size_t)kAFloats * 4;              // A images (LDS-DMA targets, kept below 64 KB)
+        size_t b = 2 * (size_t)A_FLOATS * 4;              // A images (LDS-DMA targets, kept below 64 KB)
         b += (size_t)BM * BN * 4;                         // accumulator tile
         b += (size_t)k_vol * BM * 4;                      // in_list
         b += 32 * 4;                                      // cnt (k_vol <= 27; cnt[31] = #work items)
@@ -81,19 +93,24 @@ struct ConvCfg {
     }
 };
 
-template <int BM, int WN, int WM, bool VEC>
+template <int BM, int WN, int WM, int KS, bool VEC>
 __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p) {
-    using Cfg = ConvCfg<BM, WN, WM>;
-    constexpr int BN = Cfg::BN, NT = Cfg::NT, NW = Cfg::NW, RBW = Cfg::RBW;
+    using Cfg = ConvCfg<BM, WN, WM, KS>;
+    constexpr int BN = Cfg::BN, NT = Cfg::NT, NW = Cfg::NW, RBW = Cfg::RBW, AF = Cfg::A_FLOATS;
+    constexpr int NJ = KS / 16;                  // 16-channel MFMA groups (4 MFMAs each) per stage
+    constexpr int NCHK = KS / 4;                 // 16-byte chunks per image row
+    constexpr int RPI = 64 / NCHK;               // image rows per LDS-DMA wave-instruction (1 KB)
+    constexpr int NINST = kChunk / RPI;          // DMA instructions per full stage
+    constexpr int T = (NINST + NW - 1) / NW;     // ... per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* a_buf = reinterpret_cast<float*>(smem);
-    float* acc_lds = a_buf + 2 * kAFloats;
+    float* acc_lds = a_buf + 2 * AF;
     int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + BM * BN);
     int32_t* cnt = in_list + p.k_vol * BM;
     int32_t* work = cnt + 32;
     uint8_t* out_list = reinterpret_cast<uint8_t*>(work + 32 * Cfg::NCH);
     // float index (relative to acc_lds) of 64 dummy words behind everything else
-    const int dummy_off = (int)((Cfg::lds_bytes(p.k_vol) - 64 * 4 - 2 * kAFloats * 4) / 4);
+    const int dummy_off = (int)((Cfg::lds_bytes(p.k_vol) - 64 * 4 - 2 * AF * 4) / 4);
 
     // XCD-aware tile mapping: the column tiles of one row tile share an XCD (their gathers hit the
     // same L2), consecutive row tiles round-robin over the 8 XCDs.
@@ -112,6 +129,8 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     const int wn = wave % WN, wm = wave / WN;
 
     // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
+    for (int e = tid; e < BM * BN / 4; e += NT)
+        reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
         for (int r = tid; r < BM; r += NT) {
             in_list[r] = (int32_t)min(row0 + r, p.m_in - 1);
@@ -119,12 +138,21 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         }
         if (tid == 0) cnt[0] = rows_here;
     } else {
+        // the tile's [k_vol x BM] block of the table goes through LDS first (A images are idle here):
+        // every load of the block is in flight at once -- ONE global latency instead of one per offset.
+        int32_t* raw = reinterpret_cast<int32_t*>(a_buf);
+        static_assert(27 * BM * 4 <= 2 * AF * 4, "raw neighbour block must fit in the A images");
+        for (int e = tid; e < p.k_vol * BM; e += NT) {
+            const int k = e / BM, r = e % BM;
+            raw[e] = r < rows_here ? p.nbr[(int64_t)k * p.m_out + row0 + r] : -1;
+        }
+        __syncthreads();
         for (int k = wave; k < p.k_vol; k += NW) {
             int pos = 0;
+#pragma unroll
             for (int c = 0; c < BM; c += 64) {
                 const int r = c + lane;
-                int v = -1;
-                if (r < rows_here) v = p.nbr[(int64_t)k * p.m_out + row0 + r];
+                const int v = raw[k * BM + r];
                 const bool valid = v >= 0;
                 const unsigned long long m = __ballot(valid);
                 if (valid) {
@@ -137,8 +165,6 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
             if (lane == 0) cnt[k] = pos;
         }
     }
-    for (int e = tid; e < BM * BN / 4; e += NT)
-        reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     // ---- work list: (offset, chunk of <= 128 pairs), ascending k: wave 0, exclusive scan -----
     if (wave == 0) {
@@ -155,173 +181,189 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     }
     __syncthreads();
     const int nwork = __builtin_amdgcn_readfirstlane(cnt[31]);
-    const int nslab = (p.c_in + kSlab - 1) / kSlab;
-    const int nit = nwork * nslab;
-
-    // Position in the (work item, K-slab) sequence, kept in SGPRs and advanced incrementally.
-    struct Cursor { int wi, slab, k, start, n; };
-    auto cursor_load = [&](Cursor& c) {
-        if (c.wi < nwork) {
-            const int w = __builtin_amdgcn_readfirstlane(work[c.wi]);
-            c.k = w & 0xff;
-            c.start = ((w >> 8) & 0xff) * kChunk;
-            c.n = w >> 16;
-        } else {
-            c.k = 0; c.start = 0; c.n = 0;
-        }
-    };
-    auto cursor_next = [&](Cursor& c) {
-        if (++c.slab == nslab) {
-            c.slab = 0;
-            ++c.wi;
-            cursor_load(c);
-        }
-    };
-    Cursor pf{0, 0, 0, 0, 0}, cur{0, 0, 0, 0, 0};
-    cursor_load(pf);
-    cur = pf;
-
+    const int nslab = (p.c_in + KS - 1) / KS;            // stages per work item
+    const int nslab32 = (p.c_in + 31) / 32;              // 32-channel slabs of the packed weights
     const int nt16 = p.c_out >> 4;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // ---- per-item state ---------------------------------------------------------------------
+    struct Item { int k, start, n; };
+    auto load_item = [&](int wi) {
+        const int w = __builtin_amdgcn_readfirstlane(work[min(wi, nwork - 1)]);
+        return Item{w & 0xff, ((w >> 8) & 0xff) * kChunk, w >> 16};
+    };
+    auto swz = [](int r) { return KS == 32 ? (r >> 1) & 7 : r & 15; };
+    int rowv[T];                                          // source row of this lane's 16-byte piece (-1: none)
+    int chb[T];                                           // byte offset of the source chunk inside a slab row
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int r = RPI * (wave + NW * j) + lane / NCHK;
+        chb[j] = 16 * ((lane % NCHK) ^ swz(r));
+    }
+    int list_base = 0;                                    // in_list offset of the item being gathered
+    auto load_rows = [&](const Item& it) {
+        list_base = it.k * BM + it.start;
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const int r = RPI * (wave + NW * j) + lane / NCHK;
+                rowv[j] = (r < it.n && (T * NW == NINST || wave + NW * j < NINST)) ? in_list[list_base + r] : -1;
+            }
+        }
+    };
+    const size_t w_slab_stride = (size_t)nt16 * 512;      // floats between consecutive 32-slabs of one offset
     const float* wp_wave = p.wp + ((size_t)(n0 >> 4) + wn) * 512 + lane * 4;
 
-    // global -> LDS (A, by DMA) and global -> registers (this wave's W fragment) for the stage at `pf`
-    auto issue = [&](int buf, f32x4& w0, f32x4& w1) {
-        const int k0 = pf.slab * kSlab;
-        const float* wsrc = wp_wave + (size_t)(pf.k * nslab + pf.slab) * nt16 * 512;
-        w0 = *reinterpret_cast<const f32x4*>(wsrc);
-        w1 = *reinterpret_cast<const f32x4*>(wsrc + 256);
-        const int32_t* il = in_list + pf.k * BM + pf.start;
+    // Loads of one stage: A by LDS-DMA into the image at byte offset `img`, this wave's W fragment of
+    // (offset k, slab) into w[].  `n` = pair rows of the stage's item, whose rows are in rowv[].
+    auto issue = [&](int img, int k, int slab, int n, f32x4* w) {
+        if (!PROBE(2)) {
+            const float* ws = wp_wave + ((size_t)k * nslab32 + (size_t)slab * (KS / 32)) * w_slab_stride;
+#pragma unroll
+            for (int h = 0; h < KS / 32; ++h) {
+                w[2 * h] = *reinterpret_cast<const f32x4*>(ws + h * w_slab_stride);
+                w[2 * h + 1] = *reinterpret_cast<const f32x4*>(ws + h * w_slab_stride + 256);
+            }
+        }
+        const int k0 = slab * KS;
         if constexpr (VEC) {
             const bool from_a = k0 < p.c_in_a;                 // uniform: slabs never straddle a|b
             const float* src = from_a ? p.in_a : p.in_b;
-            const int cw = from_a ? p.c_in_a : p.c_in_b;
-            const int cbase = from_a ? k0 : k0 - p.c_in_a;
-            __amdgpu_buffer_rsrc_t rs =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(p.m_in * cw * 4), 0x00020000);
-            char* dst = reinterpret_cast<char*>(a_buf + buf * kAFloats);
-            for (int t = wave; t < kChunk / 8; t += NW) {      // 8 rows x 128 B per wave-instruction
-                if (8 * t < pf.n) {
-                    const int r = 8 * t + (lane >> 3);
-                    const int row = il[min(r, pf.n - 1)];
-                    const int ch = (lane & 7) ^ ((r >> 1) & 7);          // source chunk for this LDS slot
-                    const bool ok = r < pf.n && cbase + 4 * ch < cw;
-                    const int voff = ok ? (row * cw + cbase + 4 * ch) * 4 : (int)0x80000000;   // OOB -> zeros
+            const int cw4 = (from_a ? p.c_in_a : p.c_in_b) * 4;
+            const int cb4 = (from_a ? k0 : k0 - p.c_in_a) * 4;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(src), 0, (int)(p.m_in * cw4), 0x00020000);
+            char* dst = reinterpret_cast<char*>(a_buf) + img;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {                      // RPI rows x KS*4 B per wave-instruction; no branches:
+                const int t = wave + NW * j;                   // pieces without a row pass an out-of-range offset
+                if ((T * NW == NINST || t < NINST) && !PROBE(1)) {
+                    const bool ok = rowv[j] >= 0 && cb4 + chb[j] < cw4;
+                    const int voff = ok ? rowv[j] * cw4 + cb4 + chb[j] : (int)0x80000000;      // OOB -> zeros
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, 0, 0, 0);
                 }
             }
         } else {
-            float* As = a_buf + buf * kAFloats;
-            for (int e = tid; e < pf.n * kSlab; e += NT) {
-                const int r = e >> 5, c = e & 31, col = k0 + c;
+            float* As = reinterpret_cast<float*>(reinterpret_cast<char*>(a_buf) + img);
+            for (int e = tid; e < n * KS; e += NT) {
+                const int r = e / KS, c = e % KS, col = k0 + c;
                 float v = 0.f;
                 if (col < p.c_in) {
-                    const int64_t row = il[r];
+                    const int64_t row = in_list[list_base + r];
                     v = (col < p.c_in_a) ? p.in_a[row * p.c_in_a + col] : p.in_b[row * p.c_in_b + (col - p.c_in_a)];
                 }
-                As[r * kSlab + 4 * ((c >> 2) ^ ((r >> 1) & 7)) + (c & 3)] = v;
+                As[r * KS + 4 * ((c >> 2) ^ swz(r)) + (c & 3)] = v;
             }
         }
-        cursor_next(pf);
     };
 
-    f32x4 acc[RBW];
+    // float offset of this lane's chunk (channels 16 j + 4 lq .. +3 of row li) for the 16-channel group j
+    int foff[NJ];
 #pragma unroll
-    for (int b = 0; b < RBW; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) foff[j] = li * KS + 4 * ((4 * j + lq) ^ swz(li));
 
-    const int li = lane & 15, lq = lane >> 4;
-    const int aoff = li * kSlab + 4 * (lq ^ ((li >> 1) & 7));      // float offset of chunk lq in row li
+    constexpr int IMG = AF * 4;                           // bytes per A image
+    int img = 0;                                          // byte offset of the image being multiplied
+    f32x4 wc[NJ], wnx[NJ];                                // W fragments: current stage / next stage
 
-    // MFMA half of a stage: the wave's first NB row blocks are active.  MFMA step (j, e) takes
-    // k = 16 j + 4 (lane >> 4) + e from both operands; all A fragments are read up front and the
-    // MFMAs interleave the NB independent accumulators.
-    auto mma = [&](auto nb_tag, const float* As, const f32x4 w0, const f32x4 w1) {
+    // One work item (offset, chunk) with NB active row blocks for this wave: all its slabs, straight-line
+    // per stage (the only branches are the slab loop and the barrier).  MFMA step (j, e) takes
+    // k = 16 j + 4 (lane >> 4) + e from both operands; the NB accumulators are interleaved, so
+    // dependent MFMAs are NB x 32 cycles apart.  The accumulators live only inside the item: after its
+    // last slab they are added into the LDS tile through the pair list's local output row -- batched
+    // and branch-free: NB list words, then 4 NB tile reads, then 4 NB writes (3 LDS round trips); rows
+    // beyond n go to a per-lane dummy word.
+    auto run_item = [&](auto nb_tag, const Item& item, const Item& next, bool has_next) {
         constexpr int NB = decltype(nb_tag)::value;
-        f32x4 a0[NB], a1[NB];
+        f32x4 acc[NB > 0 ? NB : 1];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float* q = As + (wm + WM * b) * (16 * kSlab) + aoff;
-            a0[b] = *reinterpret_cast<const f32x4*>(q);
-            a1[b] = *reinterpret_cast<const f32x4*>(As + (wm + WM * b) * (16 * kSlab) + (aoff ^ 16));
-        }
+        for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma = [&]() {
+            if constexpr (NB > 0) {
+                const float* As = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a_buf) + img);
+                f32x4 a[NB][NJ];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[b][e], w0[e], acc[b], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j)
+                        a[b][j] = *reinterpret_cast<const f32x4*>(As + (wm + WM * b) * (16 * KS) + foff[j]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[b][e], w1[e], acc[b], 0, 0, 0);
-    };
-    // After the last slab of an offset (chunk): add the NB register blocks into the LDS tile through the
-    // pair list's local output row.  Batched and branch-free: NB list words, then 4 NB tile reads, then
-    // 4 NB writes (3 LDS round trips); rows beyond n go to a per-lane dummy word.
-    auto flush = [&](auto nb_tag) {
-        constexpr int NB = decltype(nb_tag)::value;
-        const uint8_t* ol = out_list + cur.k * BM + cur.start;
-        uint32_t o4[NB];
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-            o4[b] = *reinterpret_cast<const uint32_t*>(ol + 16 * (wm + WM * b) + 4 * lq);
-        int addr[NB][4];
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int prow = 16 * (wm + WM * b) + 4 * lq + r;
-                const int orow = (o4[b] >> (8 * r)) & 0xff;
-                addr[b][r] = prow < cur.n ? orow * BN + 16 * wn + li : dummy_off + lane;
+                        for (int b = 0; b < NB; ++b)
+                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][j][e], wc[j][e], acc[b], 0, 0, 0);
             }
-        float old[NB][4];
+        };
+        auto stage_end = [&]() {
+            if (!PROBE(4)) __syncthreads();   // next stage landed (vmcnt) and visible; this image is free again
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) old[b][r] = acc_lds[addr[b][r]];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc_lds[addr[b][r]] = old[b][r] + acc[b][r];
-            acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < NJ; ++h) wc[h] = wnx[h];
+            img ^= IMG;
+        };
+        for (int s = 0; s + 1 < nslab; ++s) {             // not the last slab: the next stage is the same item
+            issue(img ^ IMG, item.k, s + 1, item.n, wnx);
+            mma();
+            stage_end();
         }
-    };
-    auto stage_compute = [&](auto nb_tag, const float* As, const f32x4 w0, const f32x4 w1, bool last) {
-        mma(nb_tag, As, w0, w1);
-        if (last) flush(nb_tag);
-    };
-    auto compute_dispatch = [&](int nb, const float* As, const f32x4 w0, const f32x4 w1, bool last) {
-        if constexpr (RBW >= 8) {
-            if (nb > 4) {
-                if (nb == 8) return stage_compute(std::integral_constant<int, 8>{}, As, w0, w1, last);
-                if (nb == 7) return stage_compute(std::integral_constant<int, 7>{}, As, w0, w1, last);
-                if (nb == 6) return stage_compute(std::integral_constant<int, 6>{}, As, w0, w1, last);
-                return stage_compute(std::integral_constant<int, 5>{}, As, w0, w1, last);
-            }
+        if (has_next) {                                   // last slab: the next stage opens the next item
+            load_rows(next);
+            issue(img ^ IMG, next.k, 0, next.n, wnx);
         }
-        if constexpr (RBW >= 4) {
-            if (nb > 2) {
-                if (nb == 4) return stage_compute(std::integral_constant<int, 4>{}, As, w0, w1, last);
-                return stage_compute(std::integral_constant<int, 3>{}, As, w0, w1, last);
+        mma();
+        if constexpr (NB > 0) {
+            if (!PROBE(16)) {
+                const uint8_t* ol = out_list + item.k * BM + item.start;
+                uint32_t o4[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    o4[b] = *reinterpret_cast<const uint32_t*>(ol + 16 * (wm + WM * b) + 4 * lq);
+                int addr[NB][4];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int prow = 16 * (wm + WM * b) + 4 * lq + r;
+                        const int orow = (o4[b] >> (8 * r)) & 0xff;
+                        addr[b][r] = prow < item.n ? orow * BN + 16 * wn + li : dummy_off + lane;
+                    }
+                float old[NB][4];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) old[b][r] = acc_lds[addr[b][r]];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc_lds[addr[b][r]] = old[b][r] + acc[b][r];
             }
         }
-        if constexpr (RBW >= 2) {
-            if (nb == 2) return stage_compute(std::integral_constant<int, 2>{}, As, w0, w1, last);
-        }
-        if (nb == 1) return stage_compute(std::integral_constant<int, 1>{}, As, w0, w1, last);
+        stage_end();
     };
 
-    f32x4 wc0, wc1, wn0, wn1;
-    if (nit > 0) issue(0, wc0, wc1);
+    // ---- main loop: work items, loads one stage ahead ------------------------------------------
+    Item item = load_item(0);
+    load_rows(item);
+    if (nwork > 0) issue(0, item.k, 0, item.n, wc);
     __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-        if (it + 1 < nit) issue((it + 1) & 1, wn0, wn1);
-        const int nrb = (cur.n + 15) >> 4;
+    for (int wi = 0; wi < nwork; ++wi) {
+        const Item next = load_item(wi + 1);
+        const bool has_next = wi + 1 < nwork;
+        const int nrb = (item.n + 15) >> 4;
         const int nb = min(RBW, max(0, (nrb - wm + WM - 1) / WM));
-        compute_dispatch(nb, a_buf + (it & 1) * kAFloats, wc0, wc1, cur.slab == nslab - 1);
-        cursor_next(cur);
-        __syncthreads();                  // stage it+1 landed (vmcnt) and visible; image (it & 1) free
-        wc0 = wn0;
-        wc1 = wn1;
+        switch (nb) {
+            case 0: run_item(ic<0>{}, item, next, has_next); break;
+            case 1: run_item(ic<1>{}, item, next, has_next); break;
+            case 2: if constexpr (RBW >= 2) run_item(ic<2>{}, item, next, has_next); break;
+            case 3: if constexpr (RBW >= 4) run_item(ic<3>{}, item, next, has_next); break;
+            case 4: if constexpr (RBW >= 4) run_item(ic<4>{}, item, next, has_next); break;
+            case 5: if constexpr (RBW >= 8) run_item(ic<5>{}, item, next, has_next); break;
+            case 6: if constexpr (RBW >= 8) run_item(ic<6>{}, item, next, has_next); break;
+            case 7: if constexpr (RBW >= 8) run_item(ic<7>{}, item, next, has_next); break;
+            default: if constexpr (RBW >= 8) run_item(ic<8>{}, item, next, has_next); break;
+        }
+        item = next;
     }
 
     // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
@@ -349,7 +391,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     }
 }
 
-// W [K, c_in, c_out] row-major  ->  [K][slab][c_out/16][j 0..1][lane 0..63][e 0..3]  with
+// W [K, c_in, c_out] row-major  ->  [K][slab32][c_out/16][j 0..1][lane 0..63][e 0..3]  with
 // k_in = 32 slab + 16 j + 4 (lane >> 4) + e  and  col = 16 nt + (lane & 15); rows beyond c_in are zero.
 __global__ void pack_weights_kernel(const float* __restrict__ w, int k_vol, int c_in, int c_out, int nslab,
                                     float* __restrict__ wp, int64_t total) {
@@ -367,12 +409,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int k_vol, int 
     wp[idx] = kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f;
 }
 
-template <int BM, int WN, int WM, bool VEC>
+template <int BM, int WN, int WM, int KS, bool VEC>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
-    using Cfg = ConvCfg<BM, WN, WM>;
+    using Cfg = ConvCfg<BM, WN, WM, KS>;
     const size_t lds = Cfg::lds_bytes(p.k_vol);
     LIDIFF_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded");
-    auto kern = spconv_fwd_kernel<BM, WN, WM, VEC>;
+    auto kern = spconv_fwd_kernel<BM, WN, WM, KS, VEC>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -390,16 +432,22 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
 
 template <int BM, int WN, int WM>
 static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
-    if (vec) return launch_fwd<BM, WN, WM, true>(p, st);
-    return launch_fwd<BM, WN, WM, false>(p, st);
+    if (!vec) return launch_fwd<BM, WN, WM, 32, false>(p, st);
+    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0) return launch_fwd<BM, WN, WM, 64, true>(p, st);
+    return launch_fwd<BM, WN, WM, 32, true>(p, st);
 }
 
 }  // namespace lidiff
 
 using namespace lidiff;
 
+static int g_conv_probe = 0;
+#ifdef LIDIFF_CONV_PROBE
+extern "C" void lidiff_debug_set_conv_probe(int flags) { g_conv_probe = flags; }
+#endif
+
 extern "C" int64_t lidiff_spconv_packed_weight_floats(int32_t k_vol, int32_t c_in, int32_t c_out) {
-    return (int64_t)k_vol * ((c_in + kSlab - 1) / kSlab) * kSlab * c_out;
+    return (int64_t)k_vol * ((c_in + 31) / 32) * 32 * c_out;
 }
 
 extern "C" int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out,
@@ -407,7 +455,7 @@ extern "C" int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t
     LIDIFF_CHECK_ARG(w != nullptr && w_packed != nullptr, "null pointer");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && c_in > 0, "kernel volume must be 1..27, c_in > 0");
     LIDIFF_CHECK_ARG(c_out > 0 && c_out % 16 == 0, "c_out must be a multiple of 16");
-    const int nslab = (c_in + kSlab - 1) / kSlab;
+    const int nslab = (c_in + 31) / 32;
     const int64_t total = lidiff_spconv_packed_weight_floats(k_vol, c_in, c_out);
     pack_weights_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w, k_vol, c_in, c_out, nslab,
                                                                                          w_packed, total);
@@ -433,13 +481,13 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
-    p.k_vol = k_vol; p.relu = relu;
+    p.k_vol = k_vol; p.relu = relu; p.probe = g_conv_probe;
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(w_packed) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
                      "w_packed/out/epilogue pointers must be 16-byte aligned");
     const bool fits32 = m_in * (int64_t)c_in_a * 4 < (1ll << 31) && m_in * (int64_t)c_in_b * 4 < (1ll << 31);
     LIDIFF_CHECK_ARG(fits32, "a feature matrix exceeds the 2 GiB buffer-descriptor range");
-    LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % kSlab == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
+    LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % 32 == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
     const bool vec = c_in_a % 4 == 0 && c_in_b % 4 == 0 && al16(in_a) && al16(in_b);
     hipStream_t st = (hipStream_t)stream;
     if (c_out % 128 == 0) return dispatch_fwd<128, 8, 1>(p, vec, st);

@@ -25,7 +25,20 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kind", default="k3")
     ap.add_argument("--sweep", action="store_true", help="all levels x the network's channel pairs")
+    ap.add_argument("--probe", type=int, default=None,
+                    help="diagnostic build (-DLIDIFF_CONV_PROBE): bit 0 = skip the A gather, 1 = skip the W loads, 2 = no barrier, 4 = no flush")
     args = ap.parse_args()
+    if args.probe is not None:
+        import ctypes
+        import subprocess
+        from lidiff_amd import _lib
+        csrc = os.path.join(ROOT, "lidiff_amd", "csrc")
+        lib = os.path.join(csrc, "liblidiff_amd_probe.so")
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(csrc, "spconv.hip")):
+            subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-DLIDIFF_CONV_PROBE",
+                            "-shared", os.path.join(csrc, "spconv.hip"), os.path.join(csrc, "coords.hip"), "-o", lib], check=True)
+        _lib.LIB_PATH = lib
+        _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))
     from lidiff_amd import ops
     import lidiff_amd.MinkowskiEngine as ME
     dev = torch.device("cuda:0")

@@ -193,7 +193,11 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         return Item{w & 0xff, ((w >> 8) & 0xff) * kChunk, w >> 16};
     };
     auto swz = [](int r) { return KS == 32 ? (r >> 1) & 7 : r & 15; };
+    // fp32 MFMAs monopolise the SIMD's VALU (tools/micro/mfma_valu_share.hip: a partner wave's VALU work does
+    // not overlap with them at all), so the slab loop keeps per-stage VALU work near zero: every per-lane
+    // address is computed once per work item and the per-stage part of it travels in SGPRs (soffset).
     int rowv[T];                                          // source row of this lane's 16-byte piece (-1: none)
+    int rowoff[T];                                        // its byte offset inside the current source (a or b), or OOB
     int chb[T];                                           // byte offset of the source chunk inside a slab row
 #pragma unroll
     for (int j = 0; j < T; ++j) {
@@ -201,6 +205,12 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         chb[j] = 16 * ((lane % NCHK) ^ swz(r));
     }
     int list_base = 0;                                    // in_list offset of the item being gathered
+    int rows_cw4 = 0;                                     // row pitch (bytes) rowoff[] was computed for
+    auto set_rowoff = [&](int cw4) {
+        rows_cw4 = cw4;
+#pragma unroll
+        for (int j = 0; j < T; ++j) rowoff[j] = rowv[j] >= 0 ? rowv[j] * cw4 + chb[j] : (int)0x80000000;   // OOB -> zeros
+    };
     auto load_rows = [&](const Item& it) {
         list_base = it.k * BM + it.start;
         if constexpr (VEC) {
@@ -209,20 +219,23 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                 const int r = RPI * (wave + NW * j) + lane / NCHK;
                 rowv[j] = (r < it.n && (T * NW == NINST || wave + NW * j < NINST)) ? in_list[list_base + r] : -1;
             }
+            set_rowoff(p.c_in_a * 4);
         }
     };
-    const size_t w_slab_stride = (size_t)nt16 * 512;      // floats between consecutive 32-slabs of one offset
-    const float* wp_wave = p.wp + ((size_t)(n0 >> 4) + wn) * 512 + lane * 4;
+    const int w_slab_bytes = nt16 * 512 * 4;              // bytes between consecutive 32-slabs of one offset
+    const int w_lane_off = (((n0 >> 4) + wn) * 512 + lane * 4) * 4;   // this wave's fragment piece, per lane
 
     // Loads of one stage: A by LDS-DMA into the image at byte offset `img`, this wave's W fragment of
     // (offset k, slab) into w[].  `n` = pair rows of the stage's item, whose rows are in rowv[].
     auto issue = [&](int img, int k, int slab, int n, f32x4* w) {
         if (!PROBE(2)) {
-            const float* ws = wp_wave + ((size_t)k * nslab32 + (size_t)slab * (KS / 32)) * w_slab_stride;
+            __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.wp), 0, (int)((size_t)p.k_vol * nslab32 * 32 * p.c_out * 4), 0x00020000);
+            const int ws = (k * nslab32 + slab * (KS / 32)) * w_slab_bytes;       // wave-uniform: SGPR offset
 #pragma unroll
             for (int h = 0; h < KS / 32; ++h) {
-                w[2 * h] = *reinterpret_cast<const f32x4*>(ws + h * w_slab_stride);
-                w[2 * h + 1] = *reinterpret_cast<const f32x4*>(ws + h * w_slab_stride + 256);
+                w[2 * h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_lane_off, ws + h * w_slab_bytes, 0));
+                w[2 * h + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_lane_off + 1024, ws + h * w_slab_bytes, 0));
             }
         }
         const int k0 = slab * KS;
@@ -231,16 +244,16 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
             const float* src = from_a ? p.in_a : p.in_b;
             const int cw4 = (from_a ? p.c_in_a : p.c_in_b) * 4;
             const int cb4 = (from_a ? k0 : k0 - p.c_in_a) * 4;
+            if (cw4 != rows_cw4) set_rowoff(cw4);              // source changed (a <-> b): new row pitch
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(src), 0, (int)(p.m_in * cw4), 0x00020000);
             char* dst = reinterpret_cast<char*>(a_buf) + img;
 #pragma unroll
-            for (int j = 0; j < T; ++j) {                      // RPI rows x KS*4 B per wave-instruction; no branches:
-                const int t = wave + NW * j;                   // pieces without a row pass an out-of-range offset
+            for (int j = 0; j < T; ++j) {                      // RPI rows x KS*4 B per wave-instruction; no branches,
+                const int t = wave + NW * j;                   // no per-stage VALU: the slab offset rides in soffset
                 if ((T * NW == NINST || t < NINST) && !PROBE(1)) {
-                    const bool ok = rowv[j] >= 0 && cb4 + chb[j] < cw4;
-                    const int voff = ok ? rowv[j] * cw4 + cb4 + chb[j] : (int)0x80000000;      // OOB -> zeros
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, 0, 0, 0);
+                    const int voff = rowoff[j];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, cb4, 0, 0);
                 }
             }
         } else {
@@ -488,7 +501,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     const bool fits32 = m_in * (int64_t)c_in_a * 4 < (1ll << 31) && m_in * (int64_t)c_in_b * 4 < (1ll << 31);
     LIDIFF_CHECK_ARG(fits32, "a feature matrix exceeds the 2 GiB buffer-descriptor range");
     LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % 32 == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
-    const bool vec = c_in_a % 4 == 0 && c_in_b % 4 == 0 && al16(in_a) && al16(in_b);
+    const bool vec = c_in_a % 32 == 0 && c_in_b % 32 == 0 && al16(in_a) && al16(in_b);   // else: scalar gather
     hipStream_t st = (hipStream_t)stream;
     if (c_out % 128 == 0) return dispatch_fwd<128, 8, 1>(p, vec, st);
     if (c_out % 96 == 0) return dispatch_fwd<128, 6, 1>(p, vec, st);

@@ -129,6 +129,20 @@ def cpu_baseline(scan_np, seed=42):
                       f"{dt:.1f} s wall, torch-CPU/MKL GEMMs on {cores} threads"}
 
 
+def traffic_from_profile(variant):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_bench.sh ->
+    profiles/r01_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); None if that profile
+    is absent or belongs to another kernel.  PMC counters cannot be collected from inside this process."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    js = json.load(open(path))
+    want = {"bn128": "<128, 8, 1", "bn96": "<128, 6, 1", "bn64": "<128, 4, 2", "bn32": "<128, 2, 4"}.get(variant)
+    if want is None or want not in js.get("kernel", ""):
+        return None
+    return js["traffic_bytes_per_launch"] / 1e9          # GB per launch (achieved/peak are TFLOP/s: see "traffic_unit")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,9 +205,10 @@ def main():
         d = summ[dom]
         tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
         out["roofline"] = {
-            "kernel": f"spconv_fwd_kernel<128,{dom[2:]},32> ({dom})", "bound": "mfma",
+            "kernel": f"spconv_fwd_kernel, BN={dom[2:]} output-channel tile ({dom})", "bound": "mfma",
             "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
-            "traffic": None, "launches": d["launches"], "avg_us": 1e3 * d["ms"] / d["launches"],
+            "traffic": traffic_from_profile(dom), "launches": d["launches"], "avg_us": 1e3 * d["ms"] / d["launches"],
+            "traffic_unit": "GB per launch (HBM, rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
             "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_gbytes_per_launch": d["bytes"] / d["launches"] / 1e9,
             "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,

@@ -509,9 +509,3 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     if (c_out % 32 == 0) return dispatch_fwd<128, 2, 4>(p, vec, st);
     return dispatch_fwd<128, 1, 8>(p, vec, st);
 }
-
-extern "C" int lidiff_spconv_bwd_w(const float*, int32_t, const float*, int32_t, const float*,
-                                   const int32_t*, int32_t, int64_t, int64_t, int32_t, float*, void*) {
-    set_error("lidiff_spconv_bwd_w: not built yet");
-    return 3;
-}

@@ -218,6 +218,50 @@ def test_spconv_linearity_full_size(device, fps_scan):
     assert torch.equal(ops.spconv_fwd(x, w, nbr, m), ops.spconv_fwd(x, w, nbr, m))
 
 
+@pytest.mark.parametrize("kind,ks,stride,cin,cout", [("conv", 3, 1, 32, 64), ("conv", 2, 2, 64, 64), ("tconv", 2, 2, 64, 32),
+                                                    ("conv", 1, 1, 96, 32)])
+def test_spconv_backward_vs_oracle_autograd(device, kind, ks, stride, cin, cout):
+    """Training path (models.py:180-217): dX (the same HIP kernel over the swapped map with W^T) and dW
+    (rulebook + gathers + GEMM) of the ME-shim convolutions against torch autograd through the oracle."""
+    import lidiff_amd.MinkowskiEngine as ME
+    coords = random_cloud(1500, 5, 31, batch=2)
+    g = torch.Generator().manual_seed(7)
+    uniq, _, _ = me.voxelize(coords)
+    field = ME.TensorField(features=torch.randn(coords.shape[0], 3, generator=g).to(device),
+                           coordinates=torch.from_numpy(coords).float().to(device), device=device)
+    x0 = field.sparse()
+    mgr = x0.coordinate_manager
+    ts_in = 1
+    if kind == "tconv":                                   # needs the coarse map and an input living on it
+        mgr.stride(1, 2)
+        ts_in = 2
+    m_in = mgr.maps[ts_in].coords.shape[0]
+    xf = torch.randn(m_in, cin, generator=g)
+    x = ME.SparseTensor(xf.to(device).requires_grad_(True), tensor_stride=ts_in, coordinate_manager=mgr)
+    mod = (ME.MinkowskiConvolutionTranspose if kind == "tconv" else ME.MinkowskiConvolution)(
+        cin, cout, kernel_size=ks, stride=stride, dimension=3).to(device)
+    y = mod(x)
+    r = torch.randn(y.F.shape, generator=g)
+    (y.F * r.to(device)).sum().backward()
+    # oracle: same maps on the CPU, autograd through torch ops
+    coarse, _ = me.stride_map(uniq, 2)
+    if kind == "tconv":
+        nbr = me.transpose_kernel_map(me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0])
+    elif ks == 1:
+        nbr = None
+    elif stride == 2:
+        nbr = me.kernel_map(uniq, coarse, 2, 1)
+    else:
+        nbr = me.kernel_map(uniq, uniq, 3, 1)
+    xo = xf.double().requires_grad_(True)
+    wo = mod.kernel.detach().cpu().double().requires_grad_(True)
+    yo = me.conv_forward(xo, wo, nbr)
+    assert torch.allclose(y.F.detach().cpu().double(), yo.detach(), rtol=RTOL, atol=ATOL)
+    (yo * r.double()).sum().backward()
+    assert torch.allclose(x.F.grad.cpu().double(), xo.grad, rtol=1e-4, atol=1e-4), "dX"
+    assert torch.allclose(mod.kernel.grad.cpu().double(), wo.grad, rtol=1e-4, atol=1e-3), "dW"
+
+
 def test_gather_scatter_rows(device):
     from lidiff_amd import ops
     g = torch.Generator().manual_seed(0)

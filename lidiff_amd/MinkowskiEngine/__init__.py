@@ -91,6 +91,21 @@ class CoordinateManager:
             self.kmaps[key] = nbr
         return nbr
 
+    def is_sparse_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False) -> bool:
+        """Performance hint for lidiff_spconv_fwd (LIDIFF_CONV_SPARSE_MAP), from voxel counts the host already
+        holds (no device sync): does the kernel map bring only a few pairs per offset and 128-row tile?
+        r = M(2 ts) / M(ts) close to 1 means the voxels of stride ts are isolated (each coarse voxel holds ~1 of
+        them), i.e. few neighbours.  Results do not depend on the hint."""
+        m = lambda ts: self.maps[ts].coords.shape[0] if ts in self.maps else 0
+        if ks == 1:
+            return False
+        if ks == 2:                                   # stride-2 down: 16 / r pairs per offset and tile; up: 16
+            if transposed:
+                return True
+            return m(ts_out) >= 0.67 * max(1, m(ts_in))
+        coarse = m(2 * ts_in)                         # measured on the 180k-point scan: pays for r >= ~0.85
+        return coarse > 0 and coarse >= 0.85 * m(ts_in)   # (<= ~2 neighbours per voxel), not at r = 0.69 (4.3)
+
     def check(self):
         """Raise if a kernel flagged a coordinate outside the hash-key range (host sync)."""
         s = int(self.status.item())
@@ -320,6 +335,9 @@ class _ConvBase(nn.Module):
         return (mgr.kernel_map(ts, ts_out, self.kernel_size, False),
                 mgr.kernel_map(ts_out, ts, self.kernel_size, True), ts_out, False)
 
+    def sparse_hint(self, x: SparseTensor, ts_out: int) -> bool:
+        return x.coordinate_manager.is_sparse_map(x.tensor_stride, ts_out, self.kernel_size, self.transposed)
+
     def forward(self, x: SparseTensor) -> SparseTensor:
         nbr, nbr_sw, ts_out, flip = self.maps(x)
         mgr = x.coordinate_manager
@@ -327,7 +345,7 @@ class _ConvBase(nn.Module):
         if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad):
             f = _SparseConv.apply(x.F, self.kernel, nbr, nbr_sw, m_out, flip)
         else:
-            f = ops.spconv_fwd(x.F, self.kernel, nbr, m_out)
+            f = ops.spconv_fwd(x.F, self.kernel, nbr, m_out, sparse_map=self.sparse_hint(x, ts_out))
         return SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
 
     def extra_repr(self):

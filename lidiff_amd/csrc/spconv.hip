@@ -41,6 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kChunk = 128;   // pair rows per stage
+constexpr int kWorkInts = 27 * 8 + 8;   // work list capacity: 27 offsets x up to 8 segments of 16 rows
 
 struct ConvParams {
     const float* in_a;
@@ -53,7 +54,7 @@ struct ConvParams {
     const float* residual;
     int64_t m_in, m_out;
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, flags;
     int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
                               // 2 = no barrier, 4 = no flush
 };
@@ -86,7 +87,7 @@ struct ConvCfg {
         b += (size_t)BM * BN * 4;                         // accumulator tile
         b += (size_t)k_vol * BM * 4;                      // in_list
         b += 32 * 4;                                      // cnt (k_vol <= 27; cnt[31] = #work items)
-        b += (size_t)32 * NCH * 4;                        // work list
+        b += (size_t)kWorkInts * 4;                       // work list
         b += (size_t)k_vol * BM;                          // out_list (uint8)
         b = (b + 15) & ~(size_t)15;
         return b + 64 * 4;                                // per-lane dummy words for the branch-free flush
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + BM * BN);
     int32_t* cnt = in_list + p.k_vol * BM;
     int32_t* work = cnt + 32;
-    uint8_t* out_list = reinterpret_cast<uint8_t*>(work + 32 * Cfg::NCH);
+    uint8_t* out_list = reinterpret_cast<uint8_t*>(work + kWorkInts);
     // float index (relative to acc_lds) of 64 dummy words behind everything else
     const int dummy_off = (int)((Cfg::lds_bytes(p.k_vol) - 64 * 4 - 2 * AF * 4) / 4);
 
@@ -166,17 +167,34 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         }
     }
     __syncthreads();
-    // ---- work list: (offset, chunk of <= 128 pairs), ascending k: wave 0, exclusive scan -----
+    // ---- low-density tiles pack several offsets into one stage ---------------------------------
+    // A stage multiplies up to 128 pair rows.  Where an offset brings only a handful of pairs per tile
+    // (stride-1/2 levels: ~1-2 neighbours per voxel) a stage per offset is almost empty and the tile is
+    // bound by per-stage latency, so such tiles split the stage into SEG segments of 128/SEG rows, each
+    // with its own offset (own W fragment registers).  Decided per tile from its own pair counts.
+    constexpr int SEG = (VEC && KS == 32) ? (WM == 1 ? 4 : 8) : 1;   // segments per stage in packed mode
+    constexpr int SEGR = kChunk / SEG, BPS = SEGR / 16;               // rows / row blocks per segment
+    bool packed = false;
+    if constexpr (SEG > 1) {
+        const int c = lane < p.k_vol ? cnt[lane] : 0;
+        int tot = c, act = c > 0;
+        for (int off = 32; off > 0; off >>= 1) { tot += __shfl_down(tot, off); act += __shfl_down(act, off); }
+        tot = __builtin_amdgcn_readfirstlane(tot);
+        act = __builtin_amdgcn_readfirstlane(act);
+        packed = p.nbr != nullptr && 4 * tot <= 3 * SEGR * act;       // mean pairs per active offset <= 3/4 segment
+    }
+    const int segr = packed ? SEGR : kChunk;
+    // ---- work list: (offset, segment of <= segr pairs), ascending k: wave 0, exclusive scan ------
     if (wave == 0) {
         const int c = lane < p.k_vol ? cnt[lane] : 0;
-        const int nc = (c + kChunk - 1) / kChunk;
+        const int nc = (c + segr - 1) / segr;
         int incl = nc;
         for (int off = 1; off < 32; off <<= 1) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
         for (int j = 0; j < nc; ++j)
-            work[incl - nc + j] = lane | (j << 8) | (min(kChunk, c - j * kChunk) << 16);
+            work[incl - nc + j] = lane | (j << 8) | (min(segr, c - j * segr) << 16);
         if (lane == 31) cnt[31] = incl;
     }
     __syncthreads();
@@ -355,7 +373,153 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         stage_end();
     };
 
+    // ---- packed mode: a stage = SEG segments x SEGR rows, every segment its own offset ---------------
+    auto run_packed = [&]() {
+        if constexpr (SEG > 1) {
+            constexpr int NSW = RBW < SEG ? RBW : SEG;        // distinct segments among this wave's row blocks
+            constexpr int BLQ = RBW / NSW;                    // consecutive local blocks sharing a segment
+            struct Desc { int k[NSW], start[NSW], n[NSW]; };
+            const int npack = (nwork + SEG - 1) / SEG;
+            auto load_pack = [&](int pack, Desc& d) {
+#pragma unroll
+                for (int q = 0; q < NSW; ++q) {
+                    const int sid = (wm + WM * (q * BLQ)) / BPS;
+                    const int wi = pack * SEG + sid;
+                    const int e = __builtin_amdgcn_readfirstlane(work[min(wi, kWorkInts - 1)]);
+                    const bool ok = wi < nwork;
+                    d.k[q] = ok ? (e & 0xff) : 0;
+                    d.start[q] = ok ? ((e >> 8) & 0xff) * SEGR : 0;
+                    d.n[q] = ok ? (e >> 16) : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < T; ++j) {                 // this lane's gather rows: its image row's segment
+                    const int r = RPI * (wave + NW * j) + lane / NCHK;
+                    const int wi = pack * SEG + r / SEGR, idx = r % SEGR;
+                    const int e = wi < nwork ? work[wi] : 0;
+                    const bool ok = (T * NW == NINST || wave + NW * j < NINST) && idx < (e >> 16);
+                    rowv[j] = ok ? in_list[(e & 0xff) * BM + ((e >> 8) & 0xff) * SEGR + idx] : -1;
+                }
+                set_rowoff(p.c_in_a * 4);
+            };
+            f32x4 wcs[NSW][NJ], wns[NSW][NJ];
+            auto issue_packed = [&](int img_, const Desc& d, int slab, f32x4 (*w)[NJ]) {
+                __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.wp), 0, (int)((size_t)p.k_vol * nslab32 * 32 * p.c_out * 4), 0x00020000);
+#pragma unroll
+                for (int q = 0; q < NSW; ++q) {
+                    const int ws = (d.k[q] * nslab32 + slab) * w_slab_bytes;
+                    w[q][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_lane_off, ws, 0));
+                    w[q][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_lane_off + 1024, ws, 0));
+                }
+                const int k0 = slab * KS;
+                const bool from_a = k0 < p.c_in_a;
+                const float* src = from_a ? p.in_a : p.in_b;
+                const int cw4 = (from_a ? p.c_in_a : p.c_in_b) * 4;
+                const int cb4 = (from_a ? k0 : k0 - p.c_in_a) * 4;
+                if (cw4 != rows_cw4) set_rowoff(cw4);
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(src), 0, (int)(p.m_in * cw4), 0x00020000);
+                char* dst = reinterpret_cast<char*>(a_buf) + img_;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const int t = wave + NW * j;
+                    if (T * NW == NINST || t < NINST) {
+                        const int voff = rowoff[j];
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, cb4, 0, 0);
+                    }
+                }
+            };
+            Desc dc, dn;
+            load_pack(0, dc);
+            dn = dc;
+            if (npack > 0) issue_packed(0, dc, 0, wcs);
+            __syncthreads();
+            for (int pack = 0; pack < npack; ++pack) {
+                f32x4 acc[RBW];
+#pragma unroll
+                for (int b = 0; b < RBW; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto mma = [&]() {
+                    const float* As = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a_buf) + img);
+                    f32x4 a[RBW][NJ];
+#pragma unroll
+                    for (int b = 0; b < RBW; ++b)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            a[b][j] = *reinterpret_cast<const f32x4*>(As + (wm + WM * b) * (16 * KS) + foff[j]);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int b = 0; b < RBW; ++b)
+                                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][j][e], wcs[b / BLQ][j][e], acc[b], 0, 0, 0);
+                };
+                auto stage_end = [&]() {
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < NSW; ++q)
+#pragma unroll
+                        for (int h = 0; h < NJ; ++h) wcs[q][h] = wns[q][h];
+                    img ^= IMG;
+                };
+                for (int sl = 0; sl + 1 < nslab; ++sl) {
+                    issue_packed(img ^ IMG, dc, sl + 1, wns);
+                    mma();
+                    stage_end();
+                }
+                if (pack + 1 < npack) {
+                    load_pack(pack + 1, dn);
+                    issue_packed(img ^ IMG, dn, 0, wns);
+                }
+                mma();
+                // flush: every block through its own segment's pair list.  Unlike a single-offset stage, the
+                // segments of a pack can hit the SAME output row (one row, several offsets), so the adds are
+                // ordered: the wm groups take turns (barrier in between), and inside a wave the segments go one
+                // after the other (LDS executes a wave's accesses in order).  Fixed order => deterministic.
+                for (int round = 0; round < WM; ++round) {
+                    if (wm == round) {
+#pragma unroll
+                        for (int q = 0; q < NSW; ++q) {
+                            uint32_t o4[BLQ];
+                            int base[BLQ];
+#pragma unroll
+                            for (int g = 0; g < BLQ; ++g) {
+                                const int gb = wm + WM * (q * BLQ + g);
+                                base[g] = 16 * (gb % BPS) + 4 * lq;
+                                o4[g] = *reinterpret_cast<const uint32_t*>(out_list + dc.k[q] * BM + dc.start[q] + base[g]);
+                            }
+                            int addr[BLQ][4];
+#pragma unroll
+                            for (int g = 0; g < BLQ; ++g)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int orow = (o4[g] >> (8 * r)) & 0xff;
+                                    addr[g][r] = base[g] + r < dc.n[q] ? orow * BN + 16 * wn + li : dummy_off + lane;
+                                }
+                            float old[BLQ][4];
+#pragma unroll
+                            for (int g = 0; g < BLQ; ++g)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) old[g][r] = acc_lds[addr[g][r]];
+#pragma unroll
+                            for (int g = 0; g < BLQ; ++g)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc_lds[addr[g][r]] = old[g][r] + acc[q * BLQ + g][r];
+                            asm volatile("" ::: "memory");       // keep the segments' read-modify-writes in order
+                        }
+                    }
+                    if (WM > 1) __syncthreads();
+                }
+                stage_end();
+                dc = dn;
+            }
+        }
+    };
+
     // ---- main loop: work items, loads one stage ahead ------------------------------------------
+    if (packed) {
+        run_packed();
+    } else {
     Item item = load_item(0);
     load_rows(item);
     if (nwork > 0) issue(0, item.k, 0, item.n, wc);
@@ -377,6 +541,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
             default: if constexpr (RBW >= 8) run_item(ic<8>{}, item, next, has_next); break;
         }
         item = next;
+    }
     }
 
     // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
@@ -446,7 +611,10 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
 template <int BM, int WN, int WM>
 static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
     if (!vec) return launch_fwd<BM, WN, WM, 32, false>(p, st);
-    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0) return launch_fwd<BM, WN, WM, 64, true>(p, st);
+    // 64-channel stages halve the per-stage costs of dense maps; low-density maps (hint from the caller)
+    // take the 32-channel kernel, whose tiles can pack several offsets into one stage
+    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0 && !(p.flags & LIDIFF_CONV_SPARSE_MAP))
+        return launch_fwd<BM, WN, WM, 64, true>(p, st);
     return launch_fwd<BM, WN, WM, 32, true>(p, st);
 }
 
@@ -480,7 +648,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
                                  const float* w_packed, const int32_t* nbr, int32_t k_vol, int64_t m_in,
                                  int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
                                  const float* ep_shift, const float* residual, int32_t relu,
-                                 void* stream) {
+                                 int32_t flags, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0, "in_a / c_in_a");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
@@ -494,7 +662,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
-    p.k_vol = k_vol; p.relu = relu; p.probe = g_conv_probe;
+    p.k_vol = k_vol; p.relu = relu; p.flags = flags; p.probe = g_conv_probe;
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(w_packed) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
                      "w_packed/out/epilogue pointers must be 16-byte aligned");

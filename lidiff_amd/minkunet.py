@@ -86,7 +86,7 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
     m_out = mgr.maps[ts_out].coords.shape[0]
     scale, shift = _bn_affine(bn)
     f = ops.spconv_fwd(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift,
-                       residual=residual, relu=relu)
+                       residual=residual, relu=relu, sparse_map=conv.sparse_hint(x, ts_out))
     return ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
 
 

@@ -200,9 +200,10 @@ def packed_weights(w: torch.Tensor) -> torch.Tensor:
 
 def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
-               relu: bool = False) -> torch.Tensor:
+               relu: bool = False, sparse_map: bool = False) -> torch.Tensor:
     """Sparse convolution forward with fused epilogue (MinkowskiConvolution[Transpose];
-    minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1)."""
+    minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1).  sparse_map: hint that
+    the kernel map has only a few pairs per offset and 128-row tile (CoordinateManager.is_sparse_map)."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
     wp = packed_weights(w)
     if w.dim() == 2:
@@ -229,7 +230,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, in_a.shape[0], m_out,
-         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), stream_ptr())
+         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(bool(sparse_map)), stream_ptr())
     if prof is not None:
         end.record()
         prof.launches.append((conv_variant(c_out), start, end, in_a.shape[0], m_out, c_in, c_out, k, pairs))

@@ -140,14 +140,16 @@ def conv_case(device, coords_np, cin, cout, kind, seed, epilogue=False, split=0)
         want = torch.relu(want * scale.double() + shift.double() + res.double())
     d = lambda t: None if t is None else t.to(device)
     nbr_d = None if nbr is None else dev_i32(nbr, device)
-    if split:
-        got = ops.spconv_fwd(d(x[:, :split].contiguous()), d(w), nbr_d, m_out, in_b=d(x[:, split:].contiguous()),
-                             scale=d(scale), shift=d(shift), residual=d(res), relu=relu)
-    else:
-        got = ops.spconv_fwd(d(x), d(w), nbr_d, m_out, scale=d(scale), shift=d(shift), residual=d(res), relu=relu)
-    torch.cuda.synchronize()
-    err = (got.cpu().double() - want).abs().max().item()
-    assert torch.allclose(got.cpu().double(), want, rtol=RTOL, atol=ATOL), f"{kind} {cin}->{cout}: max err {err}"
+    for hint in (False, True):          # dense-map kernel and the low-density (packed-stage) kernel: same results
+        if split:
+            got = ops.spconv_fwd(d(x[:, :split].contiguous()), d(w), nbr_d, m_out, in_b=d(x[:, split:].contiguous()),
+                                 scale=d(scale), shift=d(shift), residual=d(res), relu=relu, sparse_map=hint)
+        else:
+            got = ops.spconv_fwd(d(x), d(w), nbr_d, m_out, scale=d(scale), shift=d(shift), residual=d(res), relu=relu,
+                                 sparse_map=hint)
+        torch.cuda.synchronize()
+        err = (got.cpu().double() - want).abs().max().item()
+        assert torch.allclose(got.cpu().double(), want, rtol=RTOL, atol=ATOL), f"{kind} {cin}->{cout} hint={hint}: max err {err}"
 
 
 @pytest.mark.parametrize("cin,cout", [(3, 32), (32, 32), (32, 64), (64, 128), (96, 96), (128, 256), (384, 256)])
@@ -167,6 +169,15 @@ def test_spconv_epilogue_and_split_input(device):
     conv_case(device, c, 192, 128, "k3", seed=2, epilogue=True, split=128)      # fused ME.cat (128 | 64)
     conv_case(device, c, 128, 96, "k1", seed=3, epilogue=True, split=96)         # downsample conv on cat
     conv_case(device, c, 3, 32, "k3", seed=4, epilogue=True)                      # scalar (non-float4) path
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (96, 96), (128, 96), (64, 128), (128, 64)])
+def test_spconv_low_density_maps(device, cin, cout):
+    """Isolated voxels (about one neighbour per voxel, like the stride-1/2 levels of a noisy scan): the tiles of the
+    32-channel kernel take the packed-stage path (several offsets per 128-row stage)."""
+    conv_case(device, random_cloud(6000, 40, cin * 7 + cout, batch=2, dup=0.05), cin, cout, "k3", seed=cin + 1)
+    conv_case(device, random_cloud(3000, 20, 5, dup=0.0), cin, cout, "down", seed=2)
+    conv_case(device, random_cloud(3000, 20, 6, dup=0.0), cin, cout, "up", seed=3)
 
 
 def test_spconv_degenerate_shapes(device):

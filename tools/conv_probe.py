@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kind", default="k3")
     ap.add_argument("--sweep", action="store_true", help="all levels x the network's channel pairs")
+    ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
     ap.add_argument("--probe", type=int, default=None,
                     help="diagnostic build (-DLIDIFF_CONV_PROBE): bit 0 = skip the A gather, 1 = skip the W loads, 2 = no barrier, 4 = no flush")
     args = ap.parse_args()
@@ -69,19 +70,23 @@ def main():
         pairs = int((nbr >= 0).sum()) if nbr is not None else m_in
         x = torch.randn(m_in, cin, device=dev)
         w = torch.randn(k, cin, cout, device=dev) * 0.05
+        hint = {"k3": mgr.is_sparse_map(ts, ts, 3), "down": mgr.is_sparse_map(ts, ts * 2, 2),
+                "up": mgr.is_sparse_map(ts * 2, ts, 2, True), "k1": False}[kind]
+        if args.sparse_hint >= 0:
+            hint = bool(args.sparse_hint)
         for _ in range(3):
-            ops.spconv_fwd(x, w, nbr, m_out)
+            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(args.iters):
-            ops.spconv_fwd(x, w, nbr, m_out)
+            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint)
         e.record()
         torch.cuda.synchronize()
         us = 1e3 * s.elapsed_time(e) / args.iters
         tf = 2.0 * pairs * cin * cout / (us * 1e-6) / 1e12
         print(f"sigma={args.sigma} level={level} kind={kind} {cin}->{cout} m_in={m_in} m_out={m_out} pairs={pairs} "
-              f"nbrs/row={pairs / m_out:.2f} avg_us={us:.1f} TFLOP/s={tf:.2f}", flush=True)
+              f"nbrs/row={pairs / m_out:.2f} hint={int(hint)} avg_us={us:.1f} TFLOP/s={tf:.2f}", flush=True)
 
     if args.sweep:
         shapes = [(0, 32, 32), (1, 32, 32), (1, 32, 64), (2, 64, 64), (2, 64, 128), (3, 128, 128), (3, 128, 256),

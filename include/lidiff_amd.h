@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 3
+#define LIDIFF_ABI_VERSION 4
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */   /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -117,6 +117,9 @@ int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int3
  *   (may be NULL) ; relu if relu != 0.   (eval-mode MinkowskiBatchNorm + MinkowskiReLU +
  *   ResidualBlock add, minkunet.py:23-24,59-60,79.)
  * w_packed: lidiff_spconv_pack_weights of the [K, c_in_a + c_in_b, c_out] kernel.
+ * replicas: R >= 1 feature matrices stacked row-wise ([R*m_in, c] in, [R*m_out, c_out] out / residual) share
+ *   the kernel map and the weights -- the conditional / unconditional pair of classifier-free guidance
+ *   (pipeline:148-153) in one launch; m_in / m_out are per replica.
  * flags: LIDIFF_CONV_SPARSE_MAP = the kernel map is expected to hold only a few pairs per offset and
  *   128-row tile (a performance hint, results are identical): such tiles pack several offsets into
  *   one 128-row stage. */
@@ -124,7 +127,7 @@ int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int3
                       const float* w_packed, const int32_t* nbr, int32_t k_vol,
                       int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                       const float* ep_scale, const float* ep_shift, const float* residual,
-                      int32_t relu, int32_t flags, void* stream);
+                      int32_t relu, int32_t replicas, int32_t flags, void* stream);
 
 /* Row gather / scatter-add -- SparseTensor.slice(field).F minkunet.py:497,619 and the
  * x_part.F[idx] of match_part_to_full minkunet.py:418; scatter-add is their backward. */

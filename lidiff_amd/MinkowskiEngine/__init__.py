@@ -231,6 +231,7 @@ class SparseTensor:
         self._F = features
         self.tensor_stride = int(tensor_stride)
         self.coordinate_manager = coordinate_manager
+        self.replicas = 1          # > 1: that many feature matrices stacked row-wise on ONE coordinate map (CFG pair)
 
     @property
     def F(self):
@@ -245,7 +246,15 @@ class SparseTensor:
         return self._F.device
 
     def _like(self, features):
-        return SparseTensor(features, tensor_stride=self.tensor_stride, coordinate_manager=self.coordinate_manager)
+        out = SparseTensor(features, tensor_stride=self.tensor_stride, coordinate_manager=self.coordinate_manager)
+        out.replicas = self.replicas
+        return out
+
+    def replicate(self, n: int) -> "SparseTensor":
+        """n copies of the features stacked row-wise on the same coordinate map (fused execution only)."""
+        out = self._like(self._F.repeat(n, 1))
+        out.replicas = self.replicas * n
+        return out
 
     def __mul__(self, other):
         if isinstance(other, SparseTensor):

@@ -54,7 +54,7 @@ struct ConvParams {
     const float* residual;
     int64_t m_in, m_out;
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
-    int tiles_m, tiles_n, flags;
+    int tiles_m, tiles_n, flags, replicas;
     int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
                               // 2 = no barrier, 4 = no flush
 };
@@ -95,8 +95,9 @@ struct ConvCfg {
 };
 
 template <int BM, int WN, int WM, int KS, bool VEC>
-__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p_launch) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
+    ConvParams p = p_launch;                     // per-replica view (pointers moved below)
     constexpr int BN = Cfg::BN, NT = Cfg::NT, NW = Cfg::NW, RBW = Cfg::RBW, AF = Cfg::A_FLOATS;
     constexpr int NJ = KS / 16;                  // 16-channel MFMA groups (4 MFMAs each) per stage
     constexpr int NCHK = KS / 4;                 // 16-byte chunks per image row
@@ -118,8 +119,15 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     const int bid = blockIdx.x;
     const int xcd = bid & 7, g = bid >> 3;
     const int tn = g % p.tiles_n;
-    const int tm = (g / p.tiles_n) * 8 + xcd;
-    if (tm >= p.tiles_m) return;
+    const int tmr = (g / p.tiles_n) * 8 + xcd;  // row tile over all replicas
+    if (tmr >= p.tiles_m * p.replicas) return;
+    // Replicas: the same kernel map and weights applied to `replicas` stacked feature matrices (the
+    // conditional / unconditional pair of classifier-free guidance, pipeline:148-153): one launch, twice the tiles.
+    const int rep = tmr / p.tiles_m, tm = tmr - rep * p.tiles_m;
+    p.in_a += (int64_t)rep * p.m_in * p.c_in_a;
+    if (p.in_b) p.in_b += (int64_t)rep * p.m_in * p.c_in_b;
+    p.out += (int64_t)rep * p.m_out * p.c_out;
+    if (p.residual) p.residual += (int64_t)rep * p.m_out * p.c_out;
     const int64_t row0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
     const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
@@ -602,7 +610,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     ConvParams q = p;
     q.tiles_m = (int)ceil_div(p.m_out, BM);
     q.tiles_n = p.c_out / Cfg::BN;
-    const unsigned grid = (unsigned)(ceil_div(q.tiles_m, 8) * 8 * q.tiles_n);
+    const unsigned grid = (unsigned)(ceil_div((int64_t)q.tiles_m * q.replicas, 8) * 8 * q.tiles_n);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), lds, st, q);
     LIDIFF_CHECK_LAUNCH();
     return 0;
@@ -648,13 +656,14 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
                                  const float* w_packed, const int32_t* nbr, int32_t k_vol, int64_t m_in,
                                  int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
                                  const float* ep_shift, const float* residual, int32_t relu,
-                                 int32_t flags, void* stream) {
+                                 int32_t replicas, int32_t flags, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0, "in_a / c_in_a");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
     LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
     LIDIFF_CHECK_ARG(c_out > 0 && c_out % 16 == 0, "c_out must be a multiple of 16");
     LIDIFF_CHECK_ARG(m_out >= 0 && m_in >= 0, "negative rows");
+    LIDIFF_CHECK_ARG(replicas >= 1, "replicas must be >= 1");
     if (m_out == 0) return 0;
     LIDIFF_CHECK_ARG(m_in > 0, "outputs without inputs");
     ConvParams p{};
@@ -662,7 +671,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
-    p.k_vol = k_vol; p.relu = relu; p.flags = flags; p.probe = g_conv_probe;
+    p.k_vol = k_vol; p.relu = relu; p.flags = flags; p.replicas = replicas; p.probe = g_conv_probe;
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(w_packed) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
                      "w_packed/out/epilogue pointers must be 16-byte aligned");

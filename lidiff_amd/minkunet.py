@@ -86,8 +86,10 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
     m_out = mgr.maps[ts_out].coords.shape[0]
     scale, shift = _bn_affine(bn)
     f = ops.spconv_fwd(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift,
-                       residual=residual, relu=relu, sparse_map=conv.sparse_hint(x, ts_out))
-    return ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
+                       residual=residual, relu=relu, sparse_map=conv.sparse_hint(x, ts_out), replicas=x.replicas)
+    out = ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
+    out.replicas = x.replicas
+    return out
 
 
 # ----------------------------------------------------------------------------------------
@@ -278,12 +280,12 @@ class MinkUNetDiff(_Base):
         """argmin_j ||C_full[i] - C_part[j]||^2 (batch column scaled by 2*max coord), cached per
         (full map, part tensor): decoder levels reuse the encoder's maps."""
         cache = x_full.coordinate_manager.aux
-        key = ("match", x_full.tensor_stride)
+        key = ("match", x_full.tensor_stride, id(x_part.coordinate_manager), x_part.tensor_stride)
         hit = cache.get(key)
-        if hit is not None and hit[0] is x_part.coordinate_manager and hit[1] == x_part.tensor_stride:
-            return hit[2]
+        if hit is not None and hit[0] is x_part.coordinate_manager:
+            return hit[1]
         idx = ops.nn_match(x_full.C, x_part.C)
-        cache[key] = (x_part.coordinate_manager, x_part.tensor_stride, idx)
+        cache[key] = (x_part.coordinate_manager, idx)          # the manager reference keeps the id unique
         return idx
 
     def match_part_to_full(self, x_full, x_part):
@@ -293,23 +295,36 @@ class MinkUNetDiff(_Base):
     def _rows_per_batch(x):
         return torch.unique(x.C[:, 0], return_counts=True)[1]
 
-    def _condition(self, name, x, part, temp_emb):
-        """x * w with w = latemp(cat(latent(match), temp)) -- e.g. minkunet.py:424-431."""
+    def _condition_weight(self, name, x, part, temp_emb):
+        """w = latemp(cat(latent(match), temp)) for the rows of x's coordinate map (fused plan): the row-wise MLPs
+        run on the few part rows BEFORE the gather they commute with, the first latemp Linear is split over its
+        (p, t) inputs."""
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"                      # minkunet.py:461: cat((t4, p4))
+        idx = self.match_index(x, part)
+        lat = latent(part.F)                                     # [M_p, 256] instead of [M_l, 256]
+        lin1, lin2 = latemp[0], latemp[2]
+        c = lat.shape[1]
+        w_t, w_p = (lin1.weight[:, :c], lin1.weight[:, c:]) if t_first else (lin1.weight[:, c:], lin1.weight[:, :c])
+        h_p = lat @ w_p.t()                                      # [M_p, h]
+        h_t = TF.linear(temp(temp_emb), w_t, lin1.bias)          # [B, h]
+        if h_t.shape[0] > 1:
+            h_t = torch.repeat_interleave(h_t, self._rows_per_batch(x), dim=0)
+        hidden = TF.leaky_relu(ops.gather_rows(h_p, idx) + h_t, 0.1)
+        return lin2(hidden)
+
+    def _condition(self, name, x, part, temp_emb):
+        """x * w with w = latemp(cat(latent(match), temp)) -- e.g. minkunet.py:424-431.  `part` may be a tuple of
+        part tensors, one per replica of x (the CFG pair)."""
         if _fusable(self):
-            idx = self.match_index(x, part)
-            lat = latent(part.F)                                     # [M_p, 256] instead of [M_l, 256]
-            lin1, lin2 = latemp[0], latemp[2]
-            c = lat.shape[1]
-            w_t, w_p = (lin1.weight[:, :c], lin1.weight[:, c:]) if t_first else (lin1.weight[:, c:], lin1.weight[:, :c])
-            h_p = lat @ w_p.t()                                      # [M_p, h]
-            h_t = TF.linear(temp(temp_emb), w_t, lin1.bias)          # [B, h]
-            if h_t.shape[0] > 1:
-                h_t = torch.repeat_interleave(h_t, self._rows_per_batch(x), dim=0)
-            hidden = TF.leaky_relu(ops.gather_rows(h_p, idx) + h_t, 0.1)
-            return x * lin2(hidden)
+            parts = part if isinstance(part, (tuple, list)) else (part,)
+            assert len(parts) == x.replicas
+            w = [self._condition_weight(name, x, q, temp_emb) for q in parts]
+            return x * (w[0] if len(w) == 1 else torch.cat(w, dim=0))
+        latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
+                                getattr(self, f"latemp_{name}"))
+        t_first = name == "up1"
         p = latent(self.match_part_to_full(x, part))
         t = temp(temp_emb)
         t = torch.repeat_interleave(t, self._rows_per_batch(x), dim=0)
@@ -317,15 +332,28 @@ class MinkUNetDiff(_Base):
 
     # -- minkunet.py:420-497 --------------------------------------------------------------
     def forward(self, x, x_sparse, part_feats, t):
+        """part_feats: the partial-scan latent, or (fused plan only) a tuple of R of them -- then the R conditioned
+        forwards over the same x run as ONE stacked pass (same maps, same weights; every conv one launch with R
+        replicas) and the result is a tuple of R per-point outputs.  That is the classifier-free-guidance pair of
+        pipeline:148-153 / models.py:98-103 without running the network twice."""
+        multi = isinstance(part_feats, (tuple, list))
+        if multi and not _fusable(self):
+            return tuple(self.forward(x, x_sparse, q, t) for q in part_feats)
         temp_emb = self.get_timestep_embedding(t)
-        feats = [_run_stem(self.stem, x_sparse)]
+        f0 = _run_stem(self.stem, x_sparse)                      # the stem sees no conditioning: shared
+        feats = [f0.replicate(len(part_feats)) if multi else f0]
         for name in _LEVELS[:4]:
             feats.append(getattr(self, name)(self._condition(name, feats[-1], part_feats, temp_emb)))
         y = feats[4]
         for j, name in enumerate(_LEVELS[4:]):
             y = _run_up(getattr(self, name), self._condition(name, y, part_feats, temp_emb), feats[3 - j])
         if _fusable(self):
-            return ops.gather_rows(self.last(y.F), x.inverse_mapping)
+            inv = x.inverse_mapping
+            if multi:
+                m0 = y.F.shape[0] // y.replicas
+                inv = torch.cat([inv + r * m0 for r in range(y.replicas)])
+            out = ops.gather_rows(self.last(y.F), inv)
+            return tuple(out.chunk(y.replicas, dim=0)) if multi else out
         return self.last(y.slice(x).F)
 
 

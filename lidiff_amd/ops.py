@@ -152,8 +152,9 @@ class ConvProfiler:
         """{variant: dict(launches, ms, flops, bytes)} -- synchronises."""
         torch.cuda.synchronize()
         out = {}
-        for variant, start, end, m_in, m_out, c_in, c_out, k, pairs in self.launches:
-            p = int(pairs) if not isinstance(pairs, torch.Tensor) else int(pairs.item())
+        for variant, start, end, m_in, m_out, c_in, c_out, k, pairs, reps in self.launches:
+            p = reps * (int(pairs) if not isinstance(pairs, torch.Tensor) else int(pairs.item()))
+            m_in, m_out = reps * m_in, reps * m_out
             d = out.setdefault(variant, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += start.elapsed_time(end)
@@ -200,10 +201,12 @@ def packed_weights(w: torch.Tensor) -> torch.Tensor:
 
 def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
-               relu: bool = False, sparse_map: bool = False) -> torch.Tensor:
+               relu: bool = False, sparse_map: bool = False, replicas: int = 1) -> torch.Tensor:
     """Sparse convolution forward with fused epilogue (MinkowskiConvolution[Transpose];
     minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1).  sparse_map: hint that
-    the kernel map has only a few pairs per offset and 128-row tile (CoordinateManager.is_sparse_map)."""
+    the kernel map has only a few pairs per offset and 128-row tile (CoordinateManager.is_sparse_map).
+    replicas: R feature matrices stacked row-wise share the map and the weights (the CFG pair): in_a is
+    [R * M_in, C], the result [R * m_out, C_out]."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
     wp = packed_weights(w)
     if w.dim() == 2:
@@ -218,22 +221,25 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         c_b = in_b.shape[1]
         assert in_b.shape[0] == in_a.shape[0]
     assert c_a + c_b == c_in, f"channel mismatch {c_a}+{c_b} != {c_in}"
+    assert replicas >= 1 and in_a.shape[0] % replicas == 0
+    m_in = in_a.shape[0] // replicas
     if nbr is not None:
         assert nbr.shape == (k, m_out) and nbr.dtype == torch.int32 and nbr.is_contiguous()
     if residual is not None:
         residual = residual.contiguous()
-        assert residual.shape == (m_out, c_out)
-    out = torch.empty((m_out, c_out), dtype=torch.float32, device=in_a.device)
+        assert residual.shape == (replicas * m_out, c_out)
+    out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
     prof = PROFILER
     if prof is not None:
         pairs = prof.pairs(nbr, m_out)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
-    call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, in_a.shape[0], m_out,
-         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(bool(sparse_map)), stream_ptr())
+    call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
+         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), int(bool(sparse_map)),
+         stream_ptr())
     if prof is not None:
         end.record()
-        prof.launches.append((conv_variant(c_out), start, end, in_a.shape[0], m_out, c_in, c_out, k, pairs))
+        prof.launches.append((conv_variant(c_out), start, end, m_in, m_out, c_in, c_out, k, pairs, replicas))
     return out
 
 

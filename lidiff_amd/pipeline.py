@@ -57,6 +57,7 @@ class DiffCompletion(nn.Module):
         self.hparams["train"]["uncond_w"] = cond_weight
         self.hparams["data"]["max_range"] = 50.0
         self.w_uncond = cond_weight
+        self.pair_cfg = True       # run the CFG pair as one stacked pass (False: two forwards, as the reference does)
         self.new_scheduler()
 
     def new_scheduler(self):
@@ -130,6 +131,13 @@ class DiffCompletion(nn.Module):
     def classfree_forward(self, x_t, x_cond, x_uncond, t):
         with torch.no_grad():
             x_t_sparse = x_t.sparse()
+            if self.pair_cfg:
+                # same arithmetic as the two forwards below, but the conditional / unconditional pair shares one
+                # pass over x_t's maps: every sparse conv is ONE launch with two stacked feature matrices
+                parts = (self.partial_enc(x_cond), self.partial_enc(x_uncond))
+                e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t)
+                e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
+                return e_uncond + self.w_uncond * (e_cond - e_uncond)
         e_cond = self.forward(x_t, x_t_sparse, x_cond, t)
         e_uncond = self.forward(x_t, x_t_sparse, x_uncond, t)
         return e_uncond + self.w_uncond * (e_cond - e_uncond)

@@ -180,6 +180,24 @@ def test_spconv_low_density_maps(device, cin, cout):
     conv_case(device, random_cloud(3000, 20, 6, dup=0.0), cin, cout, "up", seed=3)
 
 
+def test_spconv_replicas(device):
+    """R stacked feature matrices over one kernel map (the CFG pair): one launch == R launches."""
+    from lidiff_amd import ops
+    coords = random_cloud(3000, 6, 41, batch=2)
+    uniq, _, _ = me.voxelize(coords)
+    nbr = dev_i32(me.kernel_map(uniq, uniq, 3, 1), device)
+    m = uniq.shape[0]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2 * m, 64, generator=g).to(device)
+    w = (torch.randn(27, 64, 128, generator=g) * 0.1).to(device)
+    res = torch.randn(2 * m, 128, generator=g).to(device)
+    sc, sh = (torch.rand(128, generator=g) + 0.5).to(device), torch.randn(128, generator=g).to(device)
+    both = ops.spconv_fwd(x, w, nbr, m, scale=sc, shift=sh, residual=res, relu=True, replicas=2)
+    for r in range(2):
+        one = ops.spconv_fwd(x[r * m:(r + 1) * m], w, nbr, m, scale=sc, shift=sh, residual=res[r * m:(r + 1) * m], relu=True)
+        assert torch.equal(both[r * m:(r + 1) * m], one)
+
+
 def test_spconv_degenerate_shapes(device):
     conv_case(device, np.zeros((5, 4), np.int32), 32, 32, "k3", seed=0)          # a single voxel
     conv_case(device, random_cloud(129, 50, 1, dup=0.0), 32, 32, "k3", seed=0)  # isolated voxels, ragged tile

@@ -247,3 +247,25 @@ def test_training_steps_run_and_learn(device):
     l0 = ref.training_step(batch)
     l0.backward()
     assert torch.isfinite(l0) and torch.isfinite(ref.model_refine.stage2[1].net[0].kernel.grad).all()
+
+
+def test_cfg_pair_equals_two_forwards(device, models, fps_scan):
+    """pipeline:148-153: the conditional / unconditional pair run as ONE stacked pass (every conv one launch with two
+    replicas) must equal two separate forwards -- on the realistic sparsity of the 180k-point workload."""
+    enc, unet, _, _ = models
+    pts = noisy_scan_points(fps_scan, 0.5, 3)
+    t = torch.tensor([500], device=device)
+    with torch.no_grad():
+        xf = to_field(pts, device)
+        xs = xf.sparse()
+        pc = enc(to_field(np.tile(fps_scan.astype(np.float32), (10, 1)), device))
+        pu = enc(to_field(np.zeros((pts.shape[0], 3), np.float32), device))
+        one_c, one_u = unet(xf, xs, pc, t), unet(xf, xs, pu, t)
+        two_c, two_u = unet(xf, xs, (pc, pu), t)
+    assert two_c.shape == one_c.shape == (pts.shape[0], 3)
+    assert torch.allclose(two_c, one_c, rtol=1e-4, atol=1e-4) and torch.allclose(two_u, one_u, rtol=1e-4, atol=1e-4)
+    gap = (one_c - one_u).abs().max().item()                      # the two conditions do differ ...
+    assert gap > 0
+    # ... and the stacked pass keeps them apart: each half matches ITS condition far better than the other one
+    assert (two_c - one_c).abs().max().item() <= max(1e-6, 0.05 * gap), ((two_c - one_c).abs().max().item(), gap)
+    assert (two_u - one_u).abs().max().item() <= max(1e-6, 0.05 * gap), ((two_u - one_u).abs().max().item(), gap)

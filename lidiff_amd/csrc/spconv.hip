@@ -681,7 +681,12 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     const bool vec = c_in_a % 32 == 0 && c_in_b % 32 == 0 && al16(in_a) && al16(in_b);   // else: scalar gather
     hipStream_t st = (hipStream_t)stream;
     if (c_out % 128 == 0) return dispatch_fwd<128, 8, 1>(p, vec, st);
-    if (c_out % 96 == 0) return dispatch_fwd<128, 6, 1>(p, vec, st);
+    if (c_out % 96 == 0) {
+        // low-density maps: two 48-column tiles of 3 x 2 waves -- their packed stages hold 8 offsets (own W
+        // registers per 16-row segment) instead of the 4 a 6 x 1 wave grid has registers for
+        if (vec && (flags & LIDIFF_CONV_SPARSE_MAP)) return dispatch_fwd<128, 3, 2>(p, vec, st);
+        return dispatch_fwd<128, 6, 1>(p, vec, st);
+    }
     if (c_out % 64 == 0) return dispatch_fwd<128, 4, 2>(p, vec, st);
     if (c_out % 32 == 0) return dispatch_fwd<128, 2, 4>(p, vec, st);
     return dispatch_fwd<128, 1, 8>(p, vec, st);

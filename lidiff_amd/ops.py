@@ -131,30 +131,34 @@ def rulebook_compact(nbr: torch.Tensor):
 
 class ConvProfiler:
     """Optional per-launch HIP-event timing of the sparse-conv kernel (bench.py's roofline leg).
-    Events are recorded on the stream the kernel is launched on (torch's current stream).
+    Events are recorded on the stream the kernel is launched on (torch's current stream).  Only launches of
+    the variants in `variants` are timed (None = all): every timed launch costs two event records in the
+    timed region, so bench.py times the dominant variant only.  Pair counts are taken AFTER the run from the
+    kept neighbour tables (no extra kernels in the timed region).
     Algorithmic work per launch: flops = 2*P*C_in*C_out,
-    bytes = 4*(M_in*C_in + M_out*C_out) + 4*K*C_in*C_out + 8*P, P = valid pairs of the map."""
+    bytes = 4*(M_in*C_in + M_out*C_out) + 4*K*C_in*C_out + 8*P, P = valid pairs of the map (x replicas)."""
 
-    def __init__(self):
-        self.launches = []          # (variant, start, end, m_in, m_out, c_in, c_out, k, pairs_tensor|int)
-        self._pairs = {}
+    def __init__(self, variants=None):
+        self.variants = None if variants is None else set(variants)
+        self.launches = []          # (variant, start, end, m_in, m_out, c_in, c_out, k, nbr|None, replicas)
 
-    def pairs(self, nbr, m_out):
-        if nbr is None:
-            return m_out
-        hit = self._pairs.get(id(nbr))
-        if hit is None or hit[0] is not nbr:
-            hit = (nbr, (nbr >= 0).sum())
-            self._pairs[id(nbr)] = hit
-        return hit[1]
+    def wants(self, variant: str) -> bool:
+        return self.variants is None or variant in self.variants
 
     def summary(self):
         """{variant: dict(launches, ms, flops, bytes)} -- synchronises."""
         torch.cuda.synchronize()
+        counts = {}
         out = {}
-        for variant, start, end, m_in, m_out, c_in, c_out, k, pairs, reps in self.launches:
-            p = reps * (int(pairs) if not isinstance(pairs, torch.Tensor) else int(pairs.item()))
-            m_in, m_out = reps * m_in, reps * m_out
+        for variant, start, end, m_in, m_out, c_in, c_out, k, nbr, reps in self.launches:
+            if nbr is None:
+                p = m_out
+            else:
+                key = nbr.data_ptr()
+                if key not in counts:
+                    counts[key] = int((nbr >= 0).sum().item())
+                p = counts[key]
+            p, m_in, m_out = reps * p, reps * m_in, reps * m_out
             d = out.setdefault(variant, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += start.elapsed_time(end)
@@ -230,8 +234,9 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert residual.shape == (replicas * m_out, c_out)
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
     prof = PROFILER
+    if prof is not None and not prof.wants(conv_variant(c_out)):
+        prof = None
     if prof is not None:
-        pairs = prof.pairs(nbr, m_out)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
@@ -239,7 +244,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
          stream_ptr())
     if prof is not None:
         end.record()
-        prof.launches.append((conv_variant(c_out), start, end, m_in, m_out, c_in, c_out, k, pairs, replicas))
+        prof.launches.append((conv_variant(c_out), start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
     return out
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 4
+#define LIDIFF_ABI_VERSION 5
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */   /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -90,6 +90,12 @@ int lidiff_kernel_map(const int32_t* out_coords, int64_t m_out,
 int lidiff_kernel_map_up(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine,
                          int32_t ts_fine, int32_t* nbr_up, void* stream);
 
+/* Morton (Z-order) key of every row of a coordinate map at tensor stride ts (batch index above 3 x 16
+ * interleaved bits of x, y, z / ts).  No reference counterpart: ME processes rows in hash order; here the
+ * argsort of these keys is handed to lidiff_spconv_fwd as `row_order`, so that a 128-row tile is a compact
+ * block of space and its gathers hit the L2 (results are independent of the order). */
+int lidiff_morton_keys(const int32_t* coords, int64_t m, int32_t ts, int64_t* keys, void* stream);
+
 /* ME-layout rulebook from a neighbour table: for every k the (in,out) pairs sorted by
  * out row, concatenated; offset_ptr[K+1] (device).  Two-phase: call with pairs_in == NULL
  * to fill offset_ptr only (count pass), then with arrays of offset_ptr[K] entries. */
@@ -117,6 +123,8 @@ int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int3
  *   (may be NULL) ; relu if relu != 0.   (eval-mode MinkowskiBatchNorm + MinkowskiReLU +
  *   ResidualBlock add, minkunet.py:23-24,59-60,79.)
  * w_packed: lidiff_spconv_pack_weights of the [K, c_in_a + c_in_b, c_out] kernel.
+ * row_order: NULL, or a permutation of the output rows: tile t covers output rows row_order[128 t ..] and
+ *   column j of `nbr` then belongs to output row row_order[j] (the caller permutes the table's columns).
  * replicas: R >= 1 feature matrices stacked row-wise ([R*m_in, c] in, [R*m_out, c_out] out / residual) share
  *   the kernel map and the weights -- the conditional / unconditional pair of classifier-free guidance
  *   (pipeline:148-153) in one launch; m_in / m_out are per replica.
@@ -127,7 +135,7 @@ int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int3
                       const float* w_packed, const int32_t* nbr, int32_t k_vol,
                       int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                       const float* ep_scale, const float* ep_shift, const float* residual,
-                      int32_t relu, int32_t replicas, int32_t flags, void* stream);
+                      int32_t relu, const int32_t* row_order, int32_t replicas, int32_t flags, void* stream);
 
 /* Row gather / scatter-add -- SparseTensor.slice(field).F minkunet.py:497,619 and the
  * x_part.F[idx] of match_part_to_full minkunet.py:418; scatter-add is their backward. */

@@ -91,6 +91,29 @@ class CoordinateManager:
             self.kmaps[key] = nbr
         return nbr
 
+    ORDER_MIN_ROWS = 30000      # smaller maps fit the L2 anyway
+
+    def tile_order(self, ts: int):
+        """Morton order of the map's rows for the sparse convolution's tiles (None for small maps); cached."""
+        key = ("order", ts)
+        if key not in self.aux:
+            c = self.maps[ts].coords
+            self.aux[key] = ops.tile_order(c, ts) if c.shape[0] >= self.ORDER_MIN_ROWS else None
+        return self.aux[key]
+
+    def kernel_map_ordered(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False):
+        """(neighbour table with its columns in tile order, the order) -- or (plain table, None)."""
+        order = self.tile_order(ts_out)
+        nbr = self.kernel_map(ts_in, ts_out, ks, transposed)
+        if order is None:
+            return nbr, None
+        key = (ts_in, ts_out, ks, transposed, "ordered")
+        hit = self.kmaps.get(key)
+        if hit is None:
+            hit = nbr.index_select(1, order.long()).contiguous()
+            self.kmaps[key] = hit
+        return hit, order
+
     def is_sparse_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False) -> bool:
         """Performance hint for lidiff_spconv_fwd (LIDIFF_CONV_SPARSE_MAP), from voxel counts the host already
         holds (no device sync): does the kernel map bring only a few pairs per offset and 128-row tile?

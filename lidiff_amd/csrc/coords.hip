@@ -254,6 +254,26 @@ __global__ void kernel_map_up_kernel(const int32_t* __restrict__ fine, const int
     for (int k = 0; k < 8; ++k) nbr_up[(int64_t)k * m + j] = (k == kj) ? p : -1;
 }
 
+// Morton (Z-order) key of every row at the map's own resolution: 3 x 16 interleaved bits of (x, y, z) / ts,
+// the batch index above them.  Sorting rows by it gives the sparse convolution spatially compact tiles.
+__device__ __forceinline__ uint64_t spread3(uint64_t v) {       // 16 bits -> every third bit
+    v &= 0xffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+__global__ void morton_kernel(const int32_t* __restrict__ coords, int64_t m, int ts, int64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const uint64_t x = (uint64_t)(floor_div(c.y, ts) + kKeyOff), y = (uint64_t)(floor_div(c.z, ts) + kKeyOff),
+                   z = (uint64_t)(floor_div(c.w, ts) + kKeyOff);
+    keys[i] = (int64_t)(((uint64_t)(c.x & 0x7fff) << 48) | spread3(x) | (spread3(y) << 1) | (spread3(z) << 2));
+}
+
 // ---------------------------------------------------------------------------------------
 // ME-layout rulebook: ordered stream compaction of every offset's column of the table.
 // grid = (blocks over rows, K).  counts[k*nblk + b] -> exclusive scan -> fill.
@@ -475,6 +495,14 @@ int lidiff_kernel_map_up(const int32_t* fine_coords, const int32_t* parent, int6
     if (m_fine == 0) return 0;
     kernel_map_up_kernel<<<(unsigned)ceil_div(m_fine, kBlock), kBlock, 0, (hipStream_t)stream>>>(
         fine_coords, parent, m_fine, ts_fine, nbr_up);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_morton_keys(const int32_t* coords, int64_t m, int32_t ts, int64_t* keys, void* stream) {
+    LIDIFF_CHECK_ARG(ts >= 1 && m >= 0, "bad shape");
+    if (m == 0) return 0;
+    morton_kernel<<<(unsigned)ceil_div(m, kBlock), kBlock, 0, (hipStream_t)stream>>>(coords, m, ts, keys);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

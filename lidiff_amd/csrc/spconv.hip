@@ -48,6 +48,7 @@ struct ConvParams {
     const float* in_b;
     const float* wp;          // packed weights (lidiff_spconv_pack_weights)
     const int32_t* nbr;
+    const int32_t* row_order;   // nullable: tile rows -> output rows
     float* out;
     const float* scale;
     const float* shift;
@@ -90,6 +91,7 @@ struct ConvCfg {
         b += (size_t)kWorkInts * 4;                       // work list
         b += (size_t)k_vol * BM;                          // out_list (uint8)
         b = (b + 15) & ~(size_t)15;
+        b += (size_t)BM * 4;                              // output row of every tile row
         return b + 64 * 4;                                // per-lane dummy words for the branch-free flush
     }
 };
@@ -113,14 +115,16 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     uint8_t* out_list = reinterpret_cast<uint8_t*>(work + kWorkInts);
     // float index (relative to acc_lds) of 64 dummy words behind everything else
     const int dummy_off = (int)((Cfg::lds_bytes(p.k_vol) - 64 * 4 - 2 * AF * 4) / 4);
+    int32_t* orow = reinterpret_cast<int32_t*>(acc_lds + dummy_off) - BM;      // output row of every tile row
 
     // XCD-aware tile mapping: the column tiles of one row tile share an XCD (their gathers hit the
     // same L2), consecutive row tiles round-robin over the 8 XCDs.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, g = bid >> 3;
     const int tn = g % p.tiles_n;
+    const int tiles_all = p.tiles_m * p.replicas;
     const int tmr = (g / p.tiles_n) * 8 + xcd;  // row tile over all replicas
-    if (tmr >= p.tiles_m * p.replicas) return;
+    if (tmr >= tiles_all) return;
     // Replicas: the same kernel map and weights applied to `replicas` stacked feature matrices (the
     // conditional / unconditional pair of classifier-free guidance, pipeline:148-153): one launch, twice the tiles.
     const int rep = tmr / p.tiles_m, tm = tmr - rep * p.tiles_m;
@@ -140,9 +144,11 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
     for (int e = tid; e < BM * BN / 4; e += NT)
         reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = tid; r < rows_here; r += NT) orow[r] = p.row_order ? p.row_order[row0 + r] : (int32_t)(row0 + r);
     if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
         for (int r = tid; r < BM; r += NT) {
-            in_list[r] = (int32_t)min(row0 + r, p.m_in - 1);
+            const int64_t gr = min(row0 + r, p.m_out - 1);
+            in_list[r] = p.row_order ? p.row_order[gr] : (int32_t)gr;
             out_list[r] = (uint8_t)r;
         }
         if (tid == 0) cnt[0] = rows_here;
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
             const float4 s = *reinterpret_cast<const float4*>(p.shift + col);
             v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
         }
-        const int64_t o = (row0 + r) * p.c_out + col;
+        const int64_t o = (int64_t)orow[r] * p.c_out + col;
         if (p.residual) {
             const float4 s = *reinterpret_cast<const float4*>(p.residual + o);
             v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
@@ -656,7 +662,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
                                  const float* w_packed, const int32_t* nbr, int32_t k_vol, int64_t m_in,
                                  int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
                                  const float* ep_shift, const float* residual, int32_t relu,
-                                 int32_t replicas, int32_t flags, void* stream) {
+                                 const int32_t* row_order, int32_t replicas, int32_t flags, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0, "in_a / c_in_a");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
@@ -667,7 +673,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     if (m_out == 0) return 0;
     LIDIFF_CHECK_ARG(m_in > 0, "outputs without inputs");
     ConvParams p{};
-    p.in_a = in_a; p.in_b = in_b; p.wp = w_packed; p.nbr = nbr; p.out = out;
+    p.in_a = in_a; p.in_b = in_b; p.wp = w_packed; p.nbr = nbr; p.row_order = row_order; p.out = out;
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;

@@ -79,14 +79,24 @@ def _fusable(*mods) -> bool:
     return _FUSION and not torch.is_grad_enabled() and not any(m.training for m in mods)
 
 
+# Sparse-conv tiles in Morton order of the output map (row_order of lidiff_spconv_fwd).  Measured on the bench
+# workload it LOSES 5-10 % (spatially compact tiles have strongly varying pair counts -> worse load balance, and
+# the L2 hits it buys do not pay for that), so it is off; the knob stays for maps with other statistics.
+_ORDERED_TILES = False
+
+
 def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=None) -> ME.SparseTensor:
     """relu?( bn(conv([x | extra])) + residual ) as ONE kernel launch (eval mode only)."""
     nbr, _, ts_out, _ = conv.maps(x)
     mgr = x.coordinate_manager
     m_out = mgr.maps[ts_out].coords.shape[0]
+    order = None
+    if nbr is not None and _ORDERED_TILES:
+        nbr, order = mgr.kernel_map_ordered(x.tensor_stride, ts_out, conv.kernel_size, conv.transposed)
     scale, shift = _bn_affine(bn)
     f = ops.spconv_fwd(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift,
-                       residual=residual, relu=relu, sparse_map=conv.sparse_hint(x, ts_out), replicas=x.replicas)
+                       residual=residual, relu=relu, sparse_map=conv.sparse_hint(x, ts_out), replicas=x.replicas,
+                       row_order=order)
     out = ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
     out.replicas = x.replicas
     return out

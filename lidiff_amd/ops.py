@@ -114,6 +114,17 @@ def kernel_map_up(fine_coords: torch.Tensor, parent: torch.Tensor, ts_fine: int)
     return nbr
 
 
+def tile_order(coords: torch.Tensor, ts: int) -> torch.Tensor:
+    """Permutation of a coordinate map's rows by Morton (Z-order) key at the map's resolution: consecutive rows
+    of the result are neighbours in space, so a 128-row conv tile gathers overlapping input rows (L2 hits)."""
+    require_device(coords)
+    coords = coords.contiguous()
+    m = coords.shape[0]
+    keys = torch.empty(m, dtype=torch.int64, device=coords.device)
+    call("lidiff_morton_keys", ptr(coords), m, int(ts), ptr(keys), stream_ptr())
+    return torch.argsort(keys).to(torch.int32)
+
+
 def rulebook_compact(nbr: torch.Tensor):
     """ME-layout rulebook from a neighbour table: (pairs_in, pairs_out, offset_ptr[K+1])."""
     require_device(nbr)
@@ -205,12 +216,15 @@ def packed_weights(w: torch.Tensor) -> torch.Tensor:
 
 def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
-               relu: bool = False, sparse_map: bool = False, replicas: int = 1) -> torch.Tensor:
+               relu: bool = False, sparse_map: bool = False, replicas: int = 1,
+               row_order: torch.Tensor | None = None) -> torch.Tensor:
     """Sparse convolution forward with fused epilogue (MinkowskiConvolution[Transpose];
     minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1).  sparse_map: hint that
     the kernel map has only a few pairs per offset and 128-row tile (CoordinateManager.is_sparse_map).
     replicas: R feature matrices stacked row-wise share the map and the weights (the CFG pair): in_a is
-    [R * M_in, C], the result [R * m_out, C_out]."""
+    [R * M_in, C], the result [R * m_out, C_out].
+    row_order: int32 permutation of the output rows (tile_order()); `nbr` must then hold its columns in that
+    order (nbr[:, row_order]).  Results do not depend on it."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
     wp = packed_weights(w)
     if w.dim() == 2:
@@ -232,6 +246,8 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     if residual is not None:
         residual = residual.contiguous()
         assert residual.shape == (replicas * m_out, c_out)
+    if row_order is not None:
+        assert row_order.dtype == torch.int32 and row_order.shape == (m_out,) and row_order.is_contiguous()
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
     prof = PROFILER
     if prof is not None and not prof.wants(conv_variant(c_out)):
@@ -240,8 +256,8 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
-         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), int(bool(sparse_map)),
-         stream_ptr())
+         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas),
+         int(bool(sparse_map)), stream_ptr())
     if prof is not None:
         end.record()
         prof.launches.append((conv_variant(c_out), start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))

@@ -180,6 +180,35 @@ def test_spconv_low_density_maps(device, cin, cout):
     conv_case(device, random_cloud(3000, 20, 6, dup=0.0), cin, cout, "up", seed=3)
 
 
+def test_spconv_row_order(device):
+    """Morton-ordered tiles (row_order + permuted table columns): identical results, epilogue included."""
+    from lidiff_amd import ops
+    coords = random_cloud(5000, 9, 43, batch=2)
+    uniq, _, _ = me.voxelize(coords)
+    nbr_np = me.kernel_map(uniq, uniq, 3, 1)
+    m = uniq.shape[0]
+    order = ops.tile_order(dev_i32(uniq, device), 1)
+    assert sorted(order.cpu().tolist()) == list(range(m))
+    key = lambda c: [int(v) for v in c]
+    # Morton order: consecutive rows are close in space (mean L1 step far below a random permutation's)
+    cu = torch.from_numpy(uniq[:, 1:]).float().to(device)
+    step_sorted = (cu[order.long()][1:] - cu[order.long()][:-1]).abs().sum(1).mean().item()
+    step_plain = (cu[1:] - cu[:-1]).abs().sum(1).mean().item()
+    assert step_sorted < 0.5 * step_plain
+    nbr = dev_i32(nbr_np, device)
+    nbr_o = nbr.index_select(1, order.long()).contiguous()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2 * m, 64, generator=g).to(device)
+    w = (torch.randn(27, 64, 128, generator=g) * 0.1).to(device)
+    res = torch.randn(2 * m, 128, generator=g).to(device)
+    sc, sh = (torch.rand(128, generator=g) + 0.5).to(device), torch.randn(128, generator=g).to(device)
+    plain = ops.spconv_fwd(x, w, nbr, m, scale=sc, shift=sh, residual=res, relu=True, replicas=2)
+    ordered = ops.spconv_fwd(x, w, nbr_o, m, scale=sc, shift=sh, residual=res, relu=True, replicas=2, row_order=order)
+    assert torch.allclose(plain, ordered, rtol=1e-5, atol=1e-5)
+    w1 = (torch.randn(1, 64, 32, generator=g) * 0.1).to(device)                   # identity map through the order
+    assert torch.allclose(ops.spconv_fwd(x[:m], w1, None, m), ops.spconv_fwd(x[:m], w1, None, m, row_order=order), atol=1e-6)
+
+
 def test_spconv_replicas(device):
     """R stacked feature matrices over one kernel map (the CFG pair): one launch == R launches."""
     from lidiff_amd import ops

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kind", default="k3")
     ap.add_argument("--sweep", action="store_true", help="all levels x the network's channel pairs")
+    ap.add_argument("--ordered", action="store_true", help="Morton-ordered tiles (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
     ap.add_argument("--probe", type=int, default=None,
                     help="diagnostic build (-DLIDIFF_CONV_PROBE): bit 0 = skip the A gather, 1 = skip the W loads, 2 = no barrier, 4 = no flush")
@@ -70,17 +71,21 @@ def main():
         pairs = int((nbr >= 0).sum()) if nbr is not None else m_in
         x = torch.randn(m_in, cin, device=dev)
         w = torch.randn(k, cin, cout, device=dev) * 0.05
+        order = None
+        if args.ordered and nbr is not None:
+            order = ops.tile_order(mgr.maps[ts if kind != "down" else ts * 2].coords, ts if kind != "down" else ts * 2)
+            nbr = nbr.index_select(1, order.long()).contiguous()
         hint = {"k3": mgr.is_sparse_map(ts, ts, 3), "down": mgr.is_sparse_map(ts, ts * 2, 2),
                 "up": mgr.is_sparse_map(ts * 2, ts, 2, True), "k1": False}[kind]
         if args.sparse_hint >= 0:
             hint = bool(args.sparse_hint)
         for _ in range(3):
-            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint)
+            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(args.iters):
-            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint)
+            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
         e.record()
         torch.cuda.synchronize()
         us = 1e3 * s.elapsed_time(e) / args.iters

@@ -144,6 +144,13 @@ int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int
 int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
                             float* dst, void* stream);
 
+/* Hidden layer of the conditioning MLPs -- minkunet.py:424-431 (latemp_* applied to cat(latent(match), temp)):
+ * with the row-wise Linear commuted in front of the gather, dst[r,:] = leaky_relu(src[idx[r],:] + bias[:], slope)
+ * in one pass (src = first-Linear output on the few part rows, bias = the time-embedding half + Linear bias).
+ * c % 4 == 0, pointers 16-byte aligned. */
+int lidiff_gather_bias_leaky(const float* src, const int64_t* idx, const float* bias, int64_t n_rows, int32_t c,
+                             float slope, float* dst, void* stream);
+
 /* MinkUNetDiff.match_part_to_full -- minkunet.py:403-418 (pykeops argKmin(1)): for every
  * full row the index of the nearest part row by squared L2 over (b*scale, x, y, z), ties to
  * the lowest index. scale = 2 * (*d_max_coord) as in the reference (d_max_coord: device int32,

@@ -365,6 +365,24 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
         dst[r * c + j] = src[s * c + j];
 }
 
+// out[r, :] = leaky_relu(src[idx[r], :] + bias[:], slope): the conditioning path's hidden layer
+// (minkunet.py:424-431 after commuting the row-wise MLP with the gather): one pass instead of gather + add + activation.
+__global__ void gather_bias_leaky_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                         const float* __restrict__ bias, int64_t n, int c4, float slope,
+                                         float* __restrict__ dst) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * c4) return;
+    const int64_t r = e / c4;
+    const int j = (int)(e % c4);
+    const float4 v = reinterpret_cast<const float4*>(src)[idx[r] * c4 + j];
+    const float4 b = reinterpret_cast<const float4*>(bias)[j];
+    float4 o;
+    o.x = v.x + b.x; o.y = v.y + b.y; o.z = v.z + b.z; o.w = v.w + b.w;
+    o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+    o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+    reinterpret_cast<float4*>(dst)[r * c4 + j] = o;
+}
+
 __global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
                                         int64_t n, int c, float* __restrict__ dst) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -539,6 +557,17 @@ int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int
         gather_rows_kernel<true><<<(unsigned)ceil_div(n_rows * (c / 4), kBlock), kBlock, 0, st>>>(src, idx, n_rows, c, dst);
     else
         gather_rows_kernel<false><<<(unsigned)ceil_div(n_rows * c, kBlock), kBlock, 0, st>>>(src, idx, n_rows, c, dst);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_gather_bias_leaky(const float* src, const int64_t* idx, const float* bias, int64_t n_rows, int32_t c,
+                             float slope, float* dst, void* stream) {
+    LIDIFF_CHECK_ARG(c > 0 && c % 4 == 0 && n_rows >= 0, "c must be a positive multiple of 4");
+    LIDIFF_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)bias) & 15) == 0, "pointers must be 16-byte aligned");
+    if (n_rows == 0) return 0;
+    gather_bias_leaky_kernel<<<(unsigned)ceil_div(n_rows * (c / 4), kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        src, idx, bias, n_rows, c / 4, slope, dst);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

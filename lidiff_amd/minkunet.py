@@ -305,33 +305,42 @@ class MinkUNetDiff(_Base):
     def _rows_per_batch(x):
         return torch.unique(x.C[:, 0], return_counts=True)[1]
 
-    def _condition_weight(self, name, x, part, temp_emb):
-        """w = latemp(cat(latent(match), temp)) for the rows of x's coordinate map (fused plan): the row-wise MLPs
+    def _condition_hidden(self, name, x, part, temp_emb, out=None):
+        """leaky(lin1(cat(latent(match), temp))) for the rows of x's coordinate map (fused plan): the row-wise MLPs
         run on the few part rows BEFORE the gather they commute with, the first latemp Linear is split over its
-        (p, t) inputs."""
+        (p, t) inputs, and gather + time bias + activation are one kernel."""
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"                      # minkunet.py:461: cat((t4, p4))
         idx = self.match_index(x, part)
         lat = latent(part.F)                                     # [M_p, 256] instead of [M_l, 256]
-        lin1, lin2 = latemp[0], latemp[2]
+        lin1 = latemp[0]
         c = lat.shape[1]
         w_t, w_p = (lin1.weight[:, :c], lin1.weight[:, c:]) if t_first else (lin1.weight[:, c:], lin1.weight[:, :c])
         h_p = lat @ w_p.t()                                      # [M_p, h]
         h_t = TF.linear(temp(temp_emb), w_t, lin1.bias)          # [B, h]
-        if h_t.shape[0] > 1:
-            h_t = torch.repeat_interleave(h_t, self._rows_per_batch(x), dim=0)
+        if h_t.shape[0] == 1 and h_p.shape[1] % 4 == 0:
+            return ops.gather_bias_leaky(h_p, idx, h_t, 0.1, out=out)
+        h_t = torch.repeat_interleave(h_t, self._rows_per_batch(x), dim=0)
         hidden = TF.leaky_relu(ops.gather_rows(h_p, idx) + h_t, 0.1)
-        return lin2(hidden)
+        if out is not None:
+            out.copy_(hidden)
+            return out
+        return hidden
 
     def _condition(self, name, x, part, temp_emb):
         """x * w with w = latemp(cat(latent(match), temp)) -- e.g. minkunet.py:424-431.  `part` may be a tuple of
-        part tensors, one per replica of x (the CFG pair)."""
+        part tensors, one per replica of x (the CFG pair): their hidden layers fill one stacked buffer, so the
+        second Linear and the multiply run once over all replicas."""
         if _fusable(self):
             parts = part if isinstance(part, (tuple, list)) else (part,)
             assert len(parts) == x.replicas
-            w = [self._condition_weight(name, x, q, temp_emb) for q in parts]
-            return x * (w[0] if len(w) == 1 else torch.cat(w, dim=0))
+            lin2 = getattr(self, f"latemp_{name}")[2]
+            m = x.F.shape[0] // x.replicas
+            hidden = torch.empty((x.F.shape[0], lin2.in_features), dtype=torch.float32, device=x.F.device)
+            for r, q in enumerate(parts):
+                self._condition_hidden(name, x, q, temp_emb, out=hidden[r * m:(r + 1) * m])
+            return x * lin2(hidden)
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"

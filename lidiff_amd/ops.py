@@ -297,6 +297,21 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def gather_bias_leaky(src: torch.Tensor, idx: torch.Tensor, bias: torch.Tensor, slope: float,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
+    """leaky_relu(src[idx] + bias, slope) in one pass (conditioning MLP hidden layer, minkunet.py:424-431).
+    `out`: optional [len(idx), C] destination (a row slice of a larger buffer)."""
+    require_device(src, idx, bias)
+    src, idx, bias = src.contiguous(), idx.contiguous(), bias.contiguous().reshape(-1)
+    n, c = idx.shape[0], src.shape[1]
+    assert bias.shape[0] == c and idx.dtype == torch.int64
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    assert out.shape == (n, c) and out.is_contiguous()
+    call("lidiff_gather_bias_leaky", ptr(src), ptr(idx), ptr(bias), n, c, float(slope), ptr(out), stream_ptr())
+    return out
+
+
 def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tensor:
     src = src.contiguous()
     n, c = src.shape

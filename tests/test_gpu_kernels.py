@@ -332,6 +332,17 @@ def test_gather_scatter_rows(device):
         assert torch.allclose(ops.scatter_add_rows(vals.to(device), idx.to(device), 500).cpu(), want, atol=1e-4)
 
 
+def test_gather_bias_leaky(device):
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(2)
+    src, bias = torch.randn(300, 96, generator=g), torch.randn(1, 96, generator=g)
+    idx = torch.randint(0, 300, (5000,), generator=g)
+    want = torch.nn.functional.leaky_relu(src[idx] + bias, 0.1)
+    buf = torch.zeros(2 * 5000, 96, device=device)
+    got = ops.gather_bias_leaky(src.to(device), idx.to(device), bias.to(device), 0.1, out=buf[5000:])
+    assert torch.equal(got.cpu(), want) and torch.equal(buf[5000:].cpu(), want) and float(buf[:5000].abs().sum()) == 0.0
+
+
 def test_nn_match(device):
     from lidiff_amd import ops
     full = random_cloud(5000, 60, 3, batch=2)

@@ -158,6 +158,13 @@ int lidiff_gather_bias_leaky(const float* src, const int64_t* idx, const float* 
 int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
                     const int32_t* d_max_coord, int64_t* idx, void* stream);
 
+/* The same arg-min when the part rows are a coordinate map of tensor stride `part_stride` with hash table
+ * (hkeys_part, hvals_part, cap_part): searches the lattice cells around every full row in growing shells instead
+ * of scanning all part rows; exact (same winner, same tie rule), with the exhaustive scan as per-row fallback. */
+int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
+                         const uint64_t* hkeys_part, const int32_t* hvals_part, int64_t cap_part, int32_t part_stride,
+                         const int32_t* d_max_coord, int64_t* idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

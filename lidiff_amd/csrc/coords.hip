@@ -427,6 +427,61 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
     if (i < m_full) idx[i] = best_j;
 }
 
+// Same arg-min through the part map's hash table: part voxels sit on a lattice of pitch `ps` (their tensor
+// stride), so the nearest one is found by visiting the lattice cells around the query in growing cubic shells.
+// After shell R every unvisited voxel is at least ps*R + 1 away along some axis, so the search stops as soon as
+// the best squared distance is strictly below (ps*R + 1)^2 (strict: an equal distance further out could carry
+// a lower row index).  Queries with no same-batch part voxel within kMatchShells shells -- or whose best
+// distance could be beaten from another batch -- fall back to the exhaustive scan.  Exact, ties to the lowest row.
+constexpr int kMatchShells = 6;
+__global__ void nn_match_grid_kernel(const int32_t* __restrict__ full, int64_t m_full,
+                                     const int32_t* __restrict__ part, int64_t m_part,
+                                     const uint64_t* __restrict__ hkeys, const int32_t* __restrict__ hvals,
+                                     uint32_t mask, int ps, const int32_t* __restrict__ d_max_coord,
+                                     int64_t* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m_full) return;
+    const int4 q = reinterpret_cast<const int4*>(full)[i];
+    const int cx = floor_div(q.y, ps) * ps, cy = floor_div(q.z, ps) * ps, cz = floor_div(q.w, ps) * ps;
+    const float scale = 2.0f * (float)(*d_max_coord);
+    long long best = 0x7fffffffffffffffll;
+    int best_j = 0x7fffffff;
+    bool done = false;
+    for (int R = 0; R <= kMatchShells && !done; ++R) {
+        for (int dz = -R; dz <= R; ++dz)
+            for (int dy = -R; dy <= R; ++dy) {
+                const bool face = (dz == -R || dz == R || dy == -R || dy == R);
+                for (int dx = -R; dx <= R; dx += (face || R == 0) ? 1 : 2 * R) {      // only the shell's cells
+                    bool ok;
+                    const uint64_t key = pack_key(q.x, cx + dx * ps, cy + dy * ps, cz + dz * ps, ok);
+                    if (!ok) continue;
+                    const int j = hash_find(hkeys, hvals, mask, key);
+                    if (j < 0) continue;
+                    const long long ex = q.y - (cx + dx * ps), ey = q.z - (cy + dy * ps), ez = q.w - (cz + dz * ps);
+                    const long long d = ex * ex + ey * ey + ez * ez;
+                    if (d < best || (d == best && j < best_j)) { best = d; best_j = j; }
+                }
+            }
+        const long long lim = (long long)ps * R + 1;
+        done = best < lim * lim;
+    }
+    // another batch is at least `scale` away: only when the same-batch winner is that far does it matter
+    if (!done || (double)best >= (double)scale * (double)scale) {
+        const float fb = (float)q.x * scale, fx = (float)q.y, fy = (float)q.z, fz = (float)q.w;
+        float bd = INFINITY;
+        int64_t bj = 0;
+        for (int64_t j = 0; j < m_part; ++j) {
+            const int4 c = reinterpret_cast<const int4*>(part)[j];
+            const float db = fb - (float)c.x * scale, dx = fx - (float)c.y, dy = fy - (float)c.z, dz = fz - (float)c.w;
+            const float d = db * db + dx * dx + dy * dy + dz * dz;
+            if (d < bd) { bd = d; bj = j; }
+        }
+        idx[i] = bj;
+        return;
+    }
+    idx[i] = best_j;
+}
+
 }  // namespace lidiff
 
 // =======================================================================================
@@ -588,6 +643,19 @@ int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, in
     if (m_full == 0) return 0;
     nn_match_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, (hipStream_t)stream>>>(
         full, m_full, part, m_part, d_max_coord, idx);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
+                         const uint64_t* hkeys_part, const int32_t* hvals_part, int64_t cap_part, int32_t part_stride,
+                         const int32_t* d_max_coord, int64_t* idx, void* stream) {
+    LIDIFF_CHECK_ARG(m_part >= 1, "part tensor has no rows");
+    LIDIFF_CHECK_ARG(part_stride >= 1, "part_stride must be >= 1");
+    LIDIFF_CHECK_ARG(cap_part > 0 && (cap_part & (cap_part - 1)) == 0, "cap must be a power of two");
+    if (m_full == 0) return 0;
+    nn_match_grid_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        full, m_full, part, m_part, hkeys_part, hvals_part, (uint32_t)(cap_part - 1), part_stride, d_max_coord, idx);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

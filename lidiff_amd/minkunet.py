@@ -294,6 +294,8 @@ class MinkUNetDiff(_Base):
         hit = cache.get(key)
         if hit is not None and hit[0] is x_part.coordinate_manager:
             return hit[1]
+        # exhaustive scan: on the noisy x_t of the bench workload (sigma up to 1 m, many voxels far from every part voxel)
+        # it beats the lattice-shell search of lidiff_nn_match_grid (0.44 vs 1.1 ms at 180k x 5.8k rows)
         idx = ops.nn_match(x_full.C, x_part.C)
         cache[key] = (x_part.coordinate_manager, idx)          # the manager reference keeps the id unique
         return idx

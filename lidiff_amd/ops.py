@@ -320,14 +320,20 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
     return dst
 
 
-def nn_match(full_c: torch.Tensor, part_c: torch.Tensor) -> torch.Tensor:
-    """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416)."""
+def nn_match(full_c: torch.Tensor, part_c: torch.Tensor, part_table: HashTable | None = None,
+             part_stride: int = 0) -> torch.Tensor:
+    """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416).  With the part map's hash table and
+    tensor stride the search walks lattice shells around every row instead of scanning all part rows (same result)."""
     require_device(full_c, part_c)
     full_c = full_c.contiguous()
     part_c = part_c.contiguous()
     assert full_c.dtype == torch.int32 and part_c.dtype == torch.int32
     max_coord = full_c.max().to(torch.int32).reshape(1)
     idx = torch.empty(full_c.shape[0], dtype=torch.int64, device=full_c.device)
-    call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord),
-         ptr(idx), stream_ptr())
+    if part_table is not None and part_stride >= 1 and part_c.shape[0] > 64:
+        call("lidiff_nn_match_grid", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(part_table.keys),
+             ptr(part_table.vals), part_table.cap, int(part_stride), ptr(max_coord), ptr(idx), stream_ptr())
+    else:
+        call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord),
+             ptr(idx), stream_ptr())
     return idx

@@ -351,6 +351,15 @@ def test_nn_match(device):
     assert np.array_equal(got, me.argmin_match(full, part))
     one = np.zeros((1, 4), np.int32)                                   # x_uncond: a single part voxel
     assert np.all(ops.nn_match(dev_i32(full, device), dev_i32(one, device)).cpu().numpy() == 0)
+    # lattice-shell search through the part map's hash table: same winners as the exhaustive scan
+    st = status(device)
+    for seed, (n_full, n_part, ext, nb) in enumerate([(20000, 3000, 300, 1), (8000, 400, 500, 2), (5000, 100, 2000, 3)]):
+        fc = random_cloud(n_full, ext, 50 + seed, batch=nb)
+        pc_raw = me.floor_to_stride(random_cloud(n_part, ext // 2, 60 + seed, batch=nb), 16)
+        puniq, _, _, ptable = ops.vox_unique(dev_i32(pc_raw, device), st)
+        want = me.argmin_match(fc, puniq.cpu().numpy())
+        got = ops.nn_match(dev_i32(fc, device), puniq, part_table=ptable, part_stride=16).cpu().numpy()
+        assert np.array_equal(got, want), (seed, int((got != want).sum()))
     f = np.array([[0, 0, 0, 0]], np.int32)                             # exact tie -> lowest index
     p = np.array([[0, 2, 0, 0], [0, -2, 0, 0], [0, 0, 2, 0]], np.int32)
     assert ops.nn_match(dev_i32(f, device), dev_i32(p, device)).item() == 0

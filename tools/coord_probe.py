@@ -70,9 +70,17 @@ def main():
     f96 = torch.randn(M, 96, device=dev)
     us = timed(lambda: ops.gather_rows(f96, inv))
     rows.append(("gather_rows (slice) [M,96] -> [N,96]", us, 4 * (M * 96 + N * 96) + 8 * N))
-    part = cur                                                # stride-16 map as the 'part' side (like x_cond's encoder output)
+    # the 'part' side as in the network: stride-16 map of the clean 18k-point scan (x_cond's encoder output)
+    pc = torch.cat([torch.zeros(18000, 1, device=dev), torch.round(torch.from_numpy(scan.astype(np.float32)).to(dev) / 0.05)], 1)
+    p0, _, _, _ = ops.vox_unique(ops.coords_floor(pc), st)
+    pcur, ptab = p0, None
+    for s_ in (2, 4, 8, 16):
+        pcur, _, ptab = ops.map_stride(pcur, s_, st)
+    part = pcur
     us = timed(lambda: ops.nn_match(uniq, part))
-    rows.append((f"nn_match full {M} x part {part.shape[0]} (brute force, {8e-9 * M * part.shape[0]:.1f} GFLOP)", us, 16 * (M + part.shape[0]) + 8 * M))
+    rows.append((f"nn_match exhaustive, full {M} x part {part.shape[0]} ({8e-9 * M * part.shape[0]:.1f} GFLOP)", us, 16 * (M + part.shape[0]) + 8 * M))
+    us = timed(lambda: ops.nn_match(uniq, part, part_table=ptab, part_stride=16))
+    rows.append((f"nn_match lattice shells, full {M} x part {part.shape[0]}", us, 16 * (M + part.shape[0]) + 8 * M))
     print(f"sigma={a.sigma}")
     print("kernel | us | algorithmic MB | GB/s | % of 8 TB/s")
     for name, us, b in rows:

@@ -137,6 +137,14 @@ int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int3
                       const float* ep_scale, const float* ep_shift, const float* residual,
                       int32_t relu, const int32_t* row_order, int32_t replicas, int32_t flags, void* stream);
 
+/* Weight gradient of lidiff_spconv_fwd (training path, models.py:180-217; ME: ConvolutionBackwardGPU):
+ * dw[k] += gather(in)[pairs_k]^T @ grad_out[pairs_k], in = [in_a | in_b].  dw [K, c_in, c_out] must be zeroed by the
+ * caller (row slices are summed with fp32 atomics).  Channel counts multiples of 4.  The input gradient needs no
+ * entry point of its own: it is lidiff_spconv_fwd over the swapped map with W^T. */
+int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
+                        const float* grad_out, const int32_t* nbr, int32_t k_vol,
+                        int64_t m_in, int64_t m_out, int32_t c_out, float* dw, void* stream);
+
 /* Row gather / scatter-add -- SparseTensor.slice(field).F minkunet.py:497,619 and the
  * x_part.F[idx] of match_part_to_full minkunet.py:418; scatter-add is their backward. */
 int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,

@@ -697,3 +697,130 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     if (c_out % 32 == 0) return dispatch_fwd<128, 2, 4>(p, vec, st);
     return dispatch_fwd<128, 1, 8>(p, vec, st);
 }
+
+// =======================================================================================
+// Weight gradient of the sparse convolution (training path, models.py:180-217; ME: ConvolutionBackwardGPU):
+//     dW[k][ci][co] = sum over the pairs (i, o) of offset k of  in[i][ci] * g[o][co]
+// One workgroup owns a [64 ci x 128 co] tile of dW[k] for a slice of the output rows.  Per chunk of 64 output rows it
+// compacts the offset's column of the neighbour table with a wave ballot, gathers the pair rows of `in` (64
+// channels) and of `g` (128 channels) with coalesced loads and stores them TRANSPOSED in LDS ([channel][pair]),
+// so that an MFMA operand fragment (4 consecutive pairs of one channel) is a
+// single 16-byte LDS read, and multiplies in^T g with v_mfma_f32_16x16x4_f32 (K = pairs).  Slices are summed with
+// fp32 atomics (as ME does), so dW is deterministic only up to the order of those adds.
+namespace lidiff {
+
+constexpr int kDwCi = 64, kDwCo = 128, kDwRows = 64, kDwPitch = kDwRows + 4;   // pitch 68: 16-byte aligned rows
+
+__global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restrict__ in_a, int c_in_a,
+                                                           const float* __restrict__ in_b, int c_in_b,
+                                                           const float* __restrict__ g, const int32_t* __restrict__ nbr,
+                                                           int64_t m_out, int c_out, int rows_per_slice,
+                                                           float* __restrict__ dw) {
+    __shared__ __attribute__((aligned(16))) float a_t[kDwCi * kDwPitch];     // [ci][pair]
+    __shared__ __attribute__((aligned(16))) float g_t[kDwCo * kDwPitch];     // [co][pair]
+    __shared__ int32_t pin[kDwRows], pout[kDwRows];
+    __shared__ int npairs_s;
+    const int c_in = c_in_a + c_in_b;
+    const int k = blockIdx.z;
+    const int co_tiles = (c_out + kDwCo - 1) / kDwCo;
+    const int ci0 = (blockIdx.y / co_tiles) * kDwCi, co0 = (blockIdx.y % co_tiles) * kDwCo;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_slice;
+    const int64_t r_end = min(m_out, r_begin + rows_per_slice);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    // wave w: co block w (16 columns), all 4 ci blocks
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int32_t* col = nbr ? nbr + (int64_t)k * m_out : nullptr;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += kDwRows) {
+        // ---- pairs of this chunk (ordered compaction, wave 0) ----
+        if (wave == 0) {
+            const int64_t o = r0 + lane;
+            int v = -1;
+            if (o < r_end) v = col ? col[o] : (int32_t)o;
+            const bool valid = v >= 0;
+            const unsigned long long m = __ballot(valid);
+            if (valid) {
+                const int q = popc_below(m);
+                pin[q] = v;
+                pout[q] = (int32_t)o;
+            }
+            if (lane == 0) npairs_s = __popcll(m);
+        }
+        __syncthreads();
+        const int np = npairs_s;
+        if (np > 0) {
+            // ---- gather, transposed into LDS; pairs beyond np are zero ----
+            for (int e = tid; e < kDwRows * (kDwCi / 4); e += 512) {
+                const int pr = e / (kDwCi / 4), c4 = (e % (kDwCi / 4)) * 4, ci = ci0 + c4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pr < np && ci < c_in) {
+                    const int64_t row = pin[pr];
+                    v = ci < c_in_a ? *reinterpret_cast<const float4*>(in_a + row * c_in_a + ci)
+                                    : *reinterpret_cast<const float4*>(in_b + row * c_in_b + (ci - c_in_a));
+                }
+                a_t[(c4 + 0) * kDwPitch + pr] = v.x; a_t[(c4 + 1) * kDwPitch + pr] = v.y;
+                a_t[(c4 + 2) * kDwPitch + pr] = v.z; a_t[(c4 + 3) * kDwPitch + pr] = v.w;
+            }
+            for (int e = tid; e < kDwRows * (kDwCo / 4); e += 512) {
+                const int pr = e / (kDwCo / 4), c4 = (e % (kDwCo / 4)) * 4, co = co0 + c4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pr < np && co < c_out) v = *reinterpret_cast<const float4*>(g + (int64_t)pout[pr] * c_out + co);
+                g_t[(c4 + 0) * kDwPitch + pr] = v.x; g_t[(c4 + 1) * kDwPitch + pr] = v.y;
+                g_t[(c4 + 2) * kDwPitch + pr] = v.z; g_t[(c4 + 3) * kDwPitch + pr] = v.w;
+            }
+            __syncthreads();
+            // ---- in^T g: MFMA step (s, e) takes pair 16 s + 4 lq + e from both operands ----
+            const int steps = (np + 15) >> 4;
+            for (int s = 0; s < steps; ++s) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(g_t + (16 * wave + li) * kDwPitch + 16 * s + 4 * lq);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x4 af = *reinterpret_cast<const f32x4*>(a_t + (16 * b + li) * kDwPitch + 16 * s + 4 * lq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D layout: col = lane & 15 (co), row = 4 (lane >> 4) + reg (ci)
+    float* dwk = dw + (int64_t)k * c_in * c_out;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = ci0 + 16 * b + 4 * lq + r, co = co0 + 16 * wave + li;
+            if (ci < c_in && co < c_out && acc[b][r] != 0.f) atomicAdd(dwk + (int64_t)ci * c_out + co, acc[b][r]);
+        }
+}
+
+}  // namespace lidiff
+
+extern "C" int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
+                                   const float* grad_out, const int32_t* nbr, int32_t k_vol, int64_t m_in,
+                                   int64_t m_out, int32_t c_out, float* dw, void* stream) {
+    LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && grad_out != nullptr && dw != nullptr, "null pointer");
+    LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
+    LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
+    LIDIFF_CHECK_ARG(c_in_a % 4 == 0 && c_in_b % 4 == 0 && c_out % 4 == 0, "channel counts must be multiples of 4");
+    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+    LIDIFF_CHECK_ARG(al16(in_a) && al16(in_b) && al16(grad_out), "feature pointers must be 16-byte aligned");
+    if (m_out == 0) return 0;
+    const int c_in = c_in_a + c_in_b;
+    const int tiles = (int)(ceil_div(c_in, kDwCi) * ceil_div(c_out, kDwCo));
+    // enough row slices to fill the chip a few times over, at least 8 chunks each
+    int64_t slices = ceil_div(2048, (int64_t)tiles * k_vol);
+    const int64_t max_slices = ceil_div(m_out, 8 * kDwRows);
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    int64_t rows_per_slice = ceil_div(ceil_div(m_out, slices), kDwRows) * kDwRows;
+    slices = ceil_div(m_out, rows_per_slice);
+    hipLaunchKernelGGL(spconv_bwd_w_kernel, dim3((unsigned)slices, (unsigned)tiles, (unsigned)k_vol), dim3(512), 0,
+                       (hipStream_t)stream, in_a, c_in_a, in_b, c_in_b, grad_out, nbr, m_out, c_out, (int)rows_per_slice, dw);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}

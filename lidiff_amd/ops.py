@@ -266,22 +266,30 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
 
 def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None) -> torch.Tensor:
     """Weight gradient of spconv_fwd (training path, models.py:180-217): dW[k] = gather(in)[pairs_k]^T @
-    grad_out[pairs_k].  Composed from the ME-layout rulebook (lidiff_rulebook_compact), row gathers
-    (lidiff_gather_rows) and one library GEMM per kernel offset; a fused HIP kernel is a later round's work."""
-    x = in_a if in_b is None else torch.cat([in_a, in_b], dim=1)
-    x = x.contiguous()
+    grad_out[pairs_k] by the MFMA kernel lidiff_spconv_bwd_w; channel counts that are not multiples of 4 (the
+    3-channel stem) go through the rulebook + row gathers + one library GEMM per offset."""
+    require_device(in_a, grad_out, nbr, in_b)
+    in_a = in_a.contiguous()
     grad_out = grad_out.contiguous()
+    c_a, c_b = in_a.shape[1], 0 if in_b is None else in_b.shape[1]
+    m_out, c_out = grad_out.shape
+    if c_a % 4 == 0 and c_b % 4 == 0 and c_out % 4 == 0:
+        if in_b is not None:
+            in_b = in_b.contiguous()
+        dw = torch.zeros((k, c_a + c_b, c_out), dtype=torch.float32, device=in_a.device)
+        call("lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out), ptr(nbr), k, in_a.shape[0], m_out,
+             c_out, ptr(dw), stream_ptr())
+        return dw
+    x = in_a if in_b is None else torch.cat([in_a, in_b], dim=1)
     if nbr is None:                                   # kernel_size 1: identity map
         return (x.t() @ grad_out).unsqueeze(0)
     pin, pout, off = rulebook_compact(nbr)
     off = off.tolist()
-    dw = torch.zeros((k, x.shape[1], grad_out.shape[1]), dtype=torch.float32, device=x.device)
+    dw = torch.zeros((k, x.shape[1], c_out), dtype=torch.float32, device=x.device)
     for kk in range(k):
         lo, hi = off[kk], off[kk + 1]
         if hi > lo:
-            a = gather_rows(x, pin[lo:hi].long())
-            g = gather_rows(grad_out, pout[lo:hi].long())
-            dw[kk] = a.t() @ g
+            dw[kk] = gather_rows(x, pin[lo:hi].long()).t() @ gather_rows(grad_out, pout[lo:hi].long())
     return dw
 
 

@@ -173,6 +173,13 @@ int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* par
                          const uint64_t* hkeys_part, const int32_t* hvals_part, int64_t cap_part, int32_t part_stride,
                          const int32_t* d_max_coord, int64_t* idx, void* stream);
 
+/* Farthest-point sampling -- DiffCompletion.preprocess_scan, pipeline:92-105 (open3d farthest_point_down_sample):
+ * points [n,3] float64; selected[0] = 0, selected[i+1] = the point farthest (squared distance, first maximum) from
+ * selected[0..i].  n_samples - 1 launches on `stream`, no host synchronisation.  workspace: lidiff_fps_workspace_bytes. */
+int64_t lidiff_fps_workspace_bytes(int64_t n_points);
+int lidiff_fps(const double* points, int64_t n_points, int64_t n_samples, int64_t* selected, void* workspace,
+               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -482,6 +482,74 @@ __global__ void nn_match_grid_kernel(const int32_t* __restrict__ full, int64_t m
     idx[i] = best_j;
 }
 
+// ---------------------------------------------------------------------------------------
+// Farthest-point sampling of the input scan -- DiffCompletion.preprocess_scan (pipeline:92-105; open3d
+// farthest_point_down_sample): start from point 0; every step lowers each point's distance to the selected set by
+// the newest selection and picks the farthest point (first maximum).  float64 like the reference.  One launch per
+// selection, no host round trip: every block reduces its points, the last block to finish (device-wide counter)
+// reduces the per-block maxima and publishes the next selection.
+constexpr int kFpsBlock = 1024;
+__global__ __launch_bounds__(kFpsBlock) void fps_step_kernel(const double* __restrict__ pts, double* __restrict__ dist,
+                                                            int64_t n, int64_t* __restrict__ sel, int64_t step,
+                                                            double* __restrict__ blk_val, int64_t* __restrict__ blk_idx,
+                                                            unsigned int* __restrict__ counter) {
+    __shared__ double s_val[kFpsBlock / kWave];
+    __shared__ int64_t s_idx[kFpsBlock / kWave];
+    __shared__ bool is_last;
+    const int64_t cur = sel[step];                         // newest selection
+    const double sx = pts[3 * cur], sy = pts[3 * cur + 1], sz = pts[3 * cur + 2];
+    const int64_t i = (int64_t)blockIdx.x * kFpsBlock + threadIdx.x;
+    double best = -1.0;
+    int64_t best_i = 0x7fffffffffffffffll;
+    if (i < n) {
+        const double dx = pts[3 * i] - sx, dy = pts[3 * i + 1] - sy, dz = pts[3 * i + 2] - sz;
+        const double d = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));   // no fma contraction
+        const double nd = fmin(dist[i], d);
+        dist[i] = nd;
+        best = nd;
+        best_i = i;
+    }
+    auto better = [](double v, int64_t j, double bv, int64_t bj) { return v > bv || (v == bv && j < bj); };
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off);
+        const int64_t oj = __shfl_down(best_i, off);
+        if (better(ov, oj, best, best_i)) { best = ov; best_i = oj; }
+    }
+    if (lane_id() == 0) { s_val[threadIdx.x / kWave] = best; s_idx[threadIdx.x / kWave] = best_i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kFpsBlock / kWave; ++w)
+            if (better(s_val[w], s_idx[w], best, best_i)) { best = s_val[w]; best_i = s_idx[w]; }
+        blk_val[blockIdx.x] = best;
+        blk_idx[blockIdx.x] = best_i;
+        __threadfence();                                   // publish before taking the ticket
+        is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();                                       // acquire the other blocks' maxima
+    best = -1.0;
+    best_i = 0x7fffffffffffffffll;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += kFpsBlock) {
+        const double v = __hip_atomic_load(&blk_val[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t j = __hip_atomic_load(&blk_idx[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (better(v, j, best, best_i)) { best = v; best_i = j; }
+    }
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off);
+        const int64_t oj = __shfl_down(best_i, off);
+        if (better(ov, oj, best, best_i)) { best = ov; best_i = oj; }
+    }
+    if (lane_id() == 0) { s_val[threadIdx.x / kWave] = best; s_idx[threadIdx.x / kWave] = best_i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kFpsBlock / kWave; ++w)
+            if (better(s_val[w], s_idx[w], best, best_i)) { best = s_val[w]; best_i = s_idx[w]; }
+        sel[step + 1] = best_i;
+        *counter = 0;
+    }
+}
+
 }  // namespace lidiff
 
 // =======================================================================================
@@ -656,6 +724,30 @@ int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* par
     if (m_full == 0) return 0;
     nn_match_grid_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, (hipStream_t)stream>>>(
         full, m_full, part, m_part, hkeys_part, hvals_part, (uint32_t)(cap_part - 1), part_stride, d_max_coord, idx);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int64_t lidiff_fps_workspace_bytes(int64_t n_points) {
+    const int64_t blocks = ceil_div(n_points > 0 ? n_points : 1, kFpsBlock);
+    return n_points * 8 + blocks * 16 + 64;
+}
+
+int lidiff_fps(const double* points, int64_t n_points, int64_t n_samples, int64_t* selected, void* workspace,
+               void* stream) {
+    LIDIFF_CHECK_ARG(n_points >= 1 && n_samples >= 1 && n_samples <= n_points, "need 1 <= n_samples <= n_points");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)ceil_div(n_points, kFpsBlock);
+    double* dist = (double*)workspace;
+    double* blk_val = dist + n_points;
+    int64_t* blk_idx = (int64_t*)(blk_val + blocks);
+    unsigned int* counter = (unsigned int*)(blk_idx + blocks);
+    // distances start "infinite": bytes 0x7f give 1.4e306, above any squared distance of finite float32 coordinates
+    LIDIFF_CHECK_HIP(hipMemsetAsync(dist, 0x7f, (size_t)n_points * 8, st));
+    LIDIFF_CHECK_HIP(hipMemsetAsync(counter, 0, 64, st));
+    LIDIFF_CHECK_HIP(hipMemsetAsync(selected, 0, 8, st));                             // selection 0 = point 0
+    for (int64_t i = 0; i + 1 < n_samples; ++i)
+        fps_step_kernel<<<blocks, kFpsBlock, 0, st>>>(points, dist, n_points, selected, i, blk_val, blk_idx, counter);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

@@ -328,6 +328,21 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
     return dst
 
 
+def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
+    """open3d farthest_point_down_sample stand-in of preprocess_scan (pipeline:97-99): indices of n_samples
+    points, greedy from index 0, float64 squared distances, first maximum wins.  One kernel per selection, queued
+    without host synchronisation."""
+    require_device(points)
+    pts = points.contiguous().double()
+    n = pts.shape[0]
+    if n_samples >= n:
+        return torch.arange(n, device=pts.device)
+    sel = torch.empty(n_samples, dtype=torch.int64, device=pts.device)
+    ws = torch.empty(_lib.load().lidiff_fps_workspace_bytes(n), dtype=torch.uint8, device=pts.device)
+    call("lidiff_fps", ptr(pts), n, int(n_samples), ptr(sel), ptr(ws), stream_ptr())
+    return sel
+
+
 def nn_match(full_c: torch.Tensor, part_c: torch.Tensor, part_table: HashTable | None = None,
              part_stride: int = 0) -> torch.Tensor:
     """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416).  With the part map's hash table and

@@ -173,9 +173,12 @@ def _merge(base, over):
 
 
 def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
-    """open3d ``farthest_point_down_sample`` stand-in (pipeline:97-99): greedy FPS starting from
-    index 0, returns the selected indices in selection order.  Host-driven torch loop; a HIP
-    kernel for it is a SURVEY.md 8(f) 'next' row, outside the per-step hot path."""
+    """open3d ``farthest_point_down_sample`` stand-in (pipeline:97-99): greedy FPS starting from index 0, returns
+    the selected indices in selection order.  On the GPU this is the HIP kernel behind ``ops.farthest_point_sample``;
+    CPU tensors (host-side tooling, golden-file generation) take the plain torch loop with the same arithmetic."""
+    if points.is_cuda:
+        from . import ops
+        return ops.farthest_point_sample(points, n_samples)
     n = points.shape[0]
     if n_samples >= n:
         return torch.arange(n, device=points.device)

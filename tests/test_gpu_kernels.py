@@ -332,6 +332,27 @@ def test_gather_scatter_rows(device):
         assert torch.allclose(ops.scatter_add_rows(vals.to(device), idx.to(device), 500).cpu(), want, atol=1e-4)
 
 
+def test_farthest_point_sample(device, fps_scan):
+    """preprocess_scan (pipeline:92-105): the HIP FPS must pick the same indices as the float64 torch loop
+    (open3d semantics: start at 0, first maximum), duplicates and ties included."""
+    from lidiff_amd import ops
+    from lidiff_amd.pipeline import farthest_point_sample
+    g = torch.Generator().manual_seed(4)
+    pts = torch.randn(5000, 3, generator=g, dtype=torch.float64) * torch.tensor([20.0, 20.0, 1.0], dtype=torch.float64)
+    pts[100:200] = pts[0:100]                                   # exact duplicates: zero distances, index ties
+    want = farthest_point_sample(pts, 400)
+    got = ops.farthest_point_sample(pts.to(device), 400).cpu()
+    assert torch.equal(got, want)
+    # lattice points: many exactly equal distances -> the first maximum must win
+    grid = torch.stack(torch.meshgrid(torch.arange(12.0), torch.arange(12.0), torch.arange(3.0), indexing="ij"), -1)
+    grid = grid.reshape(-1, 3).double()
+    assert torch.equal(ops.farthest_point_sample(grid.to(device), 100).cpu(), farthest_point_sample(grid, 100))
+    # the bundled scan's 18 000 samples, re-sampled: still a subset in the same order on both sides
+    sub = torch.from_numpy(fps_scan.astype(np.float64))
+    assert torch.equal(ops.farthest_point_sample(sub.to(device), 2000).cpu(), farthest_point_sample(sub, 2000))
+    assert torch.equal(ops.farthest_point_sample(sub.to(device), 18000).cpu(), torch.arange(18000))
+
+
 def test_gather_bias_leaky(device):
     from lidiff_amd import ops
     g = torch.Generator().manual_seed(2)

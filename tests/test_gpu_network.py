@@ -269,3 +269,17 @@ def test_cfg_pair_equals_two_forwards(device, models, fps_scan):
     # ... and the stacked pass keeps them apart: each half matches ITS condition far better than the other one
     assert (two_c - one_c).abs().max().item() <= max(1e-6, 0.05 * gap), ((two_c - one_c).abs().max().item(), gap)
     assert (two_u - one_u).abs().max().item() <= max(1e-6, 0.05 * gap), ((two_u - one_u).abs().max().item(), gap)
+
+
+def test_complete_scan_end_to_end(device, fps_scan):
+    """DiffCompletion.complete_scan (pipeline:117-132) on the bundled scan: range filter, GPU farthest-point
+    sampling, T = 2 CFG denoising steps (stacked pair), post-filter, refinement network -> [6 * P, 3] points."""
+    from lidiff_amd.pipeline import DiffCompletion
+    torch.manual_seed(0)
+    pipe = DiffCompletion(denoising_steps=2, cond_weight=6.0, device=device,
+                          hparams={"data": {"num_points": 20000}})
+    gen = torch.Generator(device=device).manual_seed(3)
+    refined, diffused = pipe.complete_scan(fps_scan.astype(np.float64), generator=gen)
+    assert diffused.ndim == 2 and diffused.shape[1] == 3 and 0 < diffused.shape[0] <= 20000
+    assert refined.shape == (6 * diffused.shape[0], 3)
+    assert np.isfinite(refined).all() and np.isfinite(diffused).all()

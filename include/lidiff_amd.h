@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 5
+#define LIDIFF_ABI_VERSION 6
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */   /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -179,6 +179,15 @@ int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* par
 int64_t lidiff_fps_workspace_bytes(int64_t n_points);
 int lidiff_fps(const double* points, int64_t n_points, int64_t n_samples, int64_t* selected, void* workspace,
                void* stream);
+
+/* Nearest neighbour of every point of a [n,3] in b [m,3] (both float when elem_bytes = 4, both double when 8):
+ * d2[i] = min_j |a_i - b_j|^2 (element type of the inputs), idx[i] = the lowest such j.  Replaces open3d
+ * PointCloud.compute_point_cloud_distance in utils/metrics.py:68,128-129,150-153 (distance = sqrt(d2)) and the
+ * K=1 knn_points search inside pytorch3d chamfer_distance, models_refine.py:72.  Exhaustive, exact, deterministic.
+ * workspace: lidiff_nn_dist_workspace_bytes(n, m, elem_bytes). */
+int64_t lidiff_nn_dist_workspace_bytes(int64_t n, int64_t m, int32_t elem_bytes);
+int lidiff_nn_dist(const void* a, int64_t n, const void* b, int64_t m, int32_t elem_bytes, void* d2, int64_t* idx,
+                   void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

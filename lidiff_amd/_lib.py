@@ -42,6 +42,8 @@ SIGNATURES = {
     "lidiff_fps_workspace_bytes": (_i64, [_i64]),
     "lidiff_fps": (_i32, [_p, _i64, _i64, _p, _p, _p]),
     "lidiff_nn_match_grid": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p]),
+    "lidiff_nn_dist_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
 _lib = None
@@ -59,7 +61,7 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if lib.lidiff_abi_version() != 5:
+        if lib.lidiff_abi_version() != 6:
             raise RuntimeError("lidiff_amd ABI version mismatch")
         _lib = lib
     return _lib

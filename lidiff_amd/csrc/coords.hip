@@ -550,6 +550,86 @@ __global__ __launch_bounds__(kFpsBlock) void fps_step_kernel(const double* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// nearest neighbour of every point of a in b (3-D, squared Euclidean distance, T = float or double): the distance
+// queries behind the evaluation metrics and the Chamfer loss.  Exhaustive and exact: kNnPt query points per lane,
+// b streamed through LDS tiles (broadcast reads), b split over blockIdx.y when a alone cannot fill the chip; the
+// partial winners of the splits are merged in ascending split order with strict '<', so the lowest b index wins ties.
+constexpr int kNnTile = 1024;
+constexpr int kNnPt = 2;
+template <typename T>
+__global__ void nn_dist_kernel(const T* __restrict__ a, int64_t n, const T* __restrict__ b, int64_t m,
+                               int64_t m_per_split, T* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
+    __shared__ T tx[kNnTile], ty[kNnTile], tz[kNnTile];
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kNnPt;
+    T ax[kNnPt], ay[kNnPt], az[kNnPt], best[kNnPt];
+    int32_t best_j[kNnPt];
+#pragma unroll
+    for (int q = 0; q < kNnPt; ++q) {
+        const int64_t i = min(i0 + q, n - 1);
+        ax[q] = a[3 * i]; ay[q] = a[3 * i + 1]; az[q] = a[3 * i + 2];
+        best[q] = (T)INFINITY; best_j[q] = 0;
+    }
+    const int64_t lo = (int64_t)blockIdx.y * m_per_split, hi = min(m, lo + m_per_split);
+    for (int64_t base = lo; base < hi; base += kNnTile) {
+        const int cnt = (int)min((int64_t)kNnTile, hi - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+            tx[t] = b[3 * (base + t)]; ty[t] = b[3 * (base + t) + 1]; tz[t] = b[3 * (base + t) + 2];
+        }
+        __syncthreads();
+        for (int t = 0; t < cnt; ++t) {
+            const T bx = tx[t], by = ty[t], bz = tz[t];
+#pragma unroll
+            for (int q = 0; q < kNnPt; ++q) {
+                const T dx = ax[q] - bx, dy = ay[q] - by, dz = az[q] - bz;
+                const T d = dx * dx + dy * dy + dz * dz;
+                if (d < best[q]) { best[q] = d; best_j[q] = (int32_t)(base + t); }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kNnPt; ++q)
+        if (i0 + q < n) {
+            part_d2[(int64_t)blockIdx.y * n + i0 + q] = best[q];
+            part_idx[(int64_t)blockIdx.y * n + i0 + q] = best_j[q];
+        }
+}
+
+template <typename T>
+__global__ void nn_dist_merge_kernel(const T* __restrict__ part_d2, const int32_t* __restrict__ part_idx, int64_t n,
+                                     int splits, T* __restrict__ d2, int64_t* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T best = part_d2[i];
+    int32_t j = part_idx[i];
+    for (int s = 1; s < splits; ++s) {
+        const T d = part_d2[(int64_t)s * n + i];
+        if (d < best) { best = d; j = part_idx[(int64_t)s * n + i]; }
+    }
+    d2[i] = best;
+    idx[i] = j;
+}
+
+static int nn_dist_splits(int64_t n, int64_t m) {
+    const int64_t blocks_a = ceil_div(n > 0 ? n : 1, (int64_t)kBlock * kNnPt);
+    int64_t s = ceil_div((int64_t)2048, blocks_a);                 // >= 8 workgroups per CU in flight
+    s = min(s, ceil_div(m > 0 ? m : 1, (int64_t)kNnTile));
+    return (int)max((int64_t)1, min(s, (int64_t)256));
+}
+
+template <typename T>
+static void nn_dist_launch(const void* a, int64_t n, const void* b, int64_t m, void* d2, int64_t* idx, void* ws,
+                           hipStream_t st) {
+    const int splits = nn_dist_splits(n, m);
+    const int64_t per = ceil_div(ceil_div(m, (int64_t)splits), (int64_t)kNnTile) * kNnTile;
+    T* part_d2 = (T*)ws;
+    int32_t* part_idx = (int32_t*)(part_d2 + (int64_t)splits * n);
+    const dim3 grid((unsigned)ceil_div(n, (int64_t)kBlock * kNnPt), (unsigned)splits);
+    nn_dist_kernel<T><<<grid, kBlock, 0, st>>>((const T*)a, n, (const T*)b, m, per, part_d2, part_idx);
+    nn_dist_merge_kernel<T><<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>(part_d2, part_idx, n, splits, (T*)d2, idx);
+}
+
 }  // namespace lidiff
 
 // =======================================================================================
@@ -748,6 +828,22 @@ int lidiff_fps(const double* points, int64_t n_points, int64_t n_samples, int64_
     LIDIFF_CHECK_HIP(hipMemsetAsync(selected, 0, 8, st));                             // selection 0 = point 0
     for (int64_t i = 0; i + 1 < n_samples; ++i)
         fps_step_kernel<<<blocks, kFpsBlock, 0, st>>>(points, dist, n_points, selected, i, blk_val, blk_idx, counter);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int64_t lidiff_nn_dist_workspace_bytes(int64_t n, int64_t m, int32_t elem_bytes) {
+    return (int64_t)nn_dist_splits(n, m) * (n > 0 ? n : 1) * (elem_bytes + 4) + 64;
+}
+
+int lidiff_nn_dist(const void* a, int64_t n, const void* b, int64_t m, int32_t elem_bytes, void* d2, int64_t* idx,
+                   void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(elem_bytes == 4 || elem_bytes == 8, "elem_bytes must be 4 (float) or 8 (double)");
+    LIDIFF_CHECK_ARG(m >= 1, "the searched cloud has no points");
+    LIDIFF_CHECK_ARG(m < (int64_t)1 << 31, "the searched cloud is too large for 32-bit row indices");
+    if (n == 0) return 0;
+    if (elem_bytes == 4) nn_dist_launch<float>(a, n, b, m, d2, idx, workspace, (hipStream_t)stream);
+    else nn_dist_launch<double>(a, n, b, m, d2, idx, workspace, (hipStream_t)stream);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

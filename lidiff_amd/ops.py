@@ -343,6 +343,25 @@ def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
     return sel
 
 
+def nn_dist(a: torch.Tensor, b: torch.Tensor):
+    """Squared distance and row index of the nearest point of b [M,3] for every point of a [N,3] (float32 or
+    float64, lowest index on ties): open3d compute_point_cloud_distance (utils/metrics.py:68,128-129) and the
+    K=1 search of pytorch3d chamfer_distance (models_refine.py:72).  Returns (d2 [N], idx int64 [N])."""
+    require_device(a, b)
+    if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.float64):
+        raise TypeError("nn_dist needs two float32 or two float64 clouds")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != 3 or b.shape[1] != 3:
+        raise ValueError("nn_dist needs [N,3] and [M,3] clouds")
+    a = a.detach().contiguous()
+    b = b.detach().contiguous()
+    n, m, eb = a.shape[0], b.shape[0], a.element_size()
+    d2 = torch.empty(n, dtype=a.dtype, device=a.device)
+    idx = torch.empty(n, dtype=torch.int64, device=a.device)
+    ws = torch.empty(_lib.load().lidiff_nn_dist_workspace_bytes(n, m, eb), dtype=torch.uint8, device=a.device)
+    call("lidiff_nn_dist", ptr(a), n, ptr(b), m, eb, ptr(d2), ptr(idx), ptr(ws), stream_ptr())
+    return d2, idx
+
+
 def nn_match(full_c: torch.Tensor, part_c: torch.Tensor, part_table: HashTable | None = None,
              part_stride: int = 0) -> torch.Tensor:
     """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416).  With the part map's hash table and

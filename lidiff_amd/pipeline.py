@@ -58,6 +58,10 @@ class DiffCompletion(nn.Module):
         self.hparams["data"]["max_range"] = 50.0
         self.w_uncond = cond_weight
         self.pair_cfg = True       # run the CFG pair as one stacked pass (False: two forwards, as the reference does)
+        # x_cond / x_uncond are rebuilt from the same points every step (pipeline:86-90,166), so
+        # partial_enc(x_cond) and partial_enc(x_uncond) are step-invariant; with this flag completion_loop encodes
+        # them once per scan (bit-identical results: eval mode, deterministic kernels).  Needs pair_cfg.
+        self.cache_condition = False
         self.new_scheduler()
 
     def new_scheduler(self):
@@ -128,13 +132,18 @@ class DiffCompletion(nn.Module):
         return out.reshape(t.shape[0], -1, 3)
 
     # pipeline:148-153
-    def classfree_forward(self, x_t, x_cond, x_uncond, t):
+    def encode_conditions(self, x_cond, x_uncond):
+        with torch.no_grad():
+            return self.partial_enc(x_cond), self.partial_enc(x_uncond)
+
+    def classfree_forward(self, x_t, x_cond, x_uncond, t, parts=None):
         with torch.no_grad():
             x_t_sparse = x_t.sparse()
             if self.pair_cfg:
                 # same arithmetic as the two forwards below, but the conditional / unconditional pair shares one
                 # pass over x_t's maps: every sparse conv is ONE launch with two stacked feature matrices
-                parts = (self.partial_enc(x_cond), self.partial_enc(x_uncond))
+                if parts is None:
+                    parts = self.encode_conditions(x_cond, x_uncond)
                 e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t)
                 e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
                 return e_uncond + self.w_uncond * (e_cond - e_uncond)
@@ -142,22 +151,25 @@ class DiffCompletion(nn.Module):
         e_uncond = self.forward(x_t, x_t_sparse, x_uncond, t)
         return e_uncond + self.w_uncond * (e_cond - e_uncond)
 
-    def denoise_step(self, x_init, x_t, x_cond, x_uncond, t_int: int, noise=None):
+    def denoise_step(self, x_init, x_t, x_cond, x_uncond, t_int: int, noise=None, parts=None):
         """One iteration of completion_loop (pipeline:158-167): CFG network pair, DPM-Solver++
-        update on the per-point offsets, re-voxelisation of x_t and the two conditions."""
+        update on the per-point offsets, re-voxelisation of x_t and the two conditions (`parts`: the
+        encoded conditions of a cache_condition run, which then skips their re-voxelisation too)."""
         t = torch.full((1,), t_int, dtype=torch.int64, device=self.device)
-        noise_t = self.classfree_forward(x_t, x_cond, x_uncond, t)
+        noise_t = self.classfree_forward(x_t, x_cond, x_uncond, t, parts)
         input_noise = x_t.F.reshape(t.shape[0], -1, 3) - x_init
         x_new = x_init + self.dpm_scheduler.step(noise_t, t_int, input_noise, noise=noise)["prev_sample"]
         x_t = self.points_to_tensor(x_new)
-        x_cond, x_uncond = self.reset_partial_pcd(x_cond, x_uncond)
+        if parts is None:
+            x_cond, x_uncond = self.reset_partial_pcd(x_cond, x_uncond)
         return x_t, x_cond, x_uncond
 
     # pipeline:155-169
     def completion_loop(self, x_init, x_t, x_cond, x_uncond, noises=None):
+        parts = self.encode_conditions(x_cond, x_uncond) if self.cache_condition and self.pair_cfg else None
         for i, t_int in enumerate(self.dpm_scheduler.host_timesteps):
             x_t, x_cond, x_uncond = self.denoise_step(x_init, x_t, x_cond, x_uncond, t_int,
-                                                      None if noises is None else noises[i])
+                                                      None if noises is None else noises[i], parts)
         x_t.coordinate_manager.check()
         return x_t.F.cpu().detach().numpy()
 

@@ -216,6 +216,13 @@ def test_completion_loop_vs_oracle(device, models):
     # legitimately changes that point's trajectory; require 98 % of the points within tolerance.
     err = np.abs(out - want).max(axis=1)
     assert np.mean(err > 5e-3) < 0.02 and np.median(err) < 1e-3, (np.mean(err > 5e-3), np.median(err), err.max())
+    # encoding the step-invariant conditions once per scan changes nothing, bit for bit
+    pipe.cache_condition = True
+    pipe.new_scheduler()
+    cached = pipe.completion_loop(scan, pipe.points_to_tensor(x_feats), pipe.points_to_tensor(scan),
+                                  pipe.points_to_tensor(torch.zeros_like(scan)),
+                                  noises=[torch.from_numpy(z[i]).to(device) for i in range(3)])
+    assert np.array_equal(cached, out)
 
 
 def test_training_steps_run_and_learn(device):

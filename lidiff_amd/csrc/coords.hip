@@ -396,21 +396,30 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int
 // arithmetic as pykeops does (exact on integer coordinates below 2^12), strict '<' while
 // scanning j ascending => lowest index wins ties.
 constexpr int kMatchTile = 1024;
+constexpr int kMatchPt = 2;                               // full rows per lane: every LDS read feeds two evaluations
+// blockIdx.y splits the part rows when the full rows alone cannot fill the chip (SPLIT): the partial winners meet
+// in idx[] through a 64-bit atomic min on (distance bits << 32 | row) -- non-negative floats order like their
+// bits, equal distances fall to the lower row -- and nn_match_finish_kernel strips the distance.
+template <bool SPLIT>
 __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full,
-                                const int32_t* __restrict__ part, int64_t m_part,
+                                const int32_t* __restrict__ part, int64_t m_part, int64_t part_per_split,
                                 const int32_t* __restrict__ d_max_coord, int64_t* __restrict__ idx) {
     __shared__ float4 tile[kMatchTile];
     const float scale = 2.0f * (float)(*d_max_coord);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float fb = 0.f, fx = 0.f, fy = 0.f, fz = 0.f;
-    if (i < m_full) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x * kMatchPt + threadIdx.x;   // rows i0, i0 + blockDim.x
+    float fb[kMatchPt], fx[kMatchPt], fy[kMatchPt], fz[kMatchPt], best[kMatchPt];
+    int best_j[kMatchPt];
+#pragma unroll
+    for (int q = 0; q < kMatchPt; ++q) {
+        const int64_t i = min(i0 + (int64_t)q * blockDim.x, m_full - 1);
         const int4 c = reinterpret_cast<const int4*>(full)[i];
-        fb = (float)c.x * scale; fx = (float)c.y; fy = (float)c.z; fz = (float)c.w;
+        fb[q] = (float)c.x * scale; fx[q] = (float)c.y; fy[q] = (float)c.z; fz[q] = (float)c.w;
+        best[q] = INFINITY; best_j[q] = 0;
     }
-    float best = INFINITY;
-    int64_t best_j = 0;
-    for (int64_t base = 0; base < m_part; base += kMatchTile) {
-        const int cnt = (int)min((int64_t)kMatchTile, m_part - base);
+    const int64_t lo = SPLIT ? (int64_t)blockIdx.y * part_per_split : 0;
+    const int64_t hi = SPLIT ? min(m_part, lo + part_per_split) : m_part;
+    for (int64_t base = lo; base < hi; base += kMatchTile) {
+        const int cnt = (int)min((int64_t)kMatchTile, hi - base);
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
             const int4 c = reinterpret_cast<const int4*>(part)[base + t];
@@ -419,12 +428,31 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
         __syncthreads();
         for (int t = 0; t < cnt; ++t) {
             const float4 p = tile[t];
-            const float db = fb - p.x, dx = fx - p.y, dy = fy - p.z, dz = fz - p.w;
-            const float d = db * db + dx * dx + dy * dy + dz * dz;
-            if (d < best) { best = d; best_j = base + t; }
+#pragma unroll
+            for (int q = 0; q < kMatchPt; ++q) {
+                const float db = fb[q] - p.x, dx = fx[q] - p.y, dy = fy[q] - p.z, dz = fz[q] - p.w;
+                const float d = db * db + dx * dx + dy * dy + dz * dz;
+                if (d < best[q]) { best[q] = d; best_j[q] = (int)(base + t); }
+            }
         }
     }
-    if (i < m_full) idx[i] = best_j;
+#pragma unroll
+    for (int q = 0; q < kMatchPt; ++q) {
+        const int64_t i = i0 + (int64_t)q * blockDim.x;
+        if (i >= m_full) continue;
+        if constexpr (SPLIT) {
+            if (lo < hi)
+                atomicMin(reinterpret_cast<unsigned long long*>(idx) + i,
+                          ((unsigned long long)__float_as_uint(best[q]) << 32) | (unsigned int)best_j[q]);
+        } else {
+            idx[i] = best_j[q];
+        }
+    }
+}
+
+__global__ void nn_match_finish_kernel(int64_t* __restrict__ idx, int64_t m_full) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m_full) idx[i] &= 0xffffffffll;
 }
 
 // Same arg-min through the part map's hash table: part voxels sit on a lattice of pitch `ps` (their tensor
@@ -789,8 +817,19 @@ int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, in
                     const int32_t* d_max_coord, int64_t* idx, void* stream) {
     LIDIFF_CHECK_ARG(m_part >= 1, "part tensor has no rows");
     if (m_full == 0) return 0;
-    nn_match_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, (hipStream_t)stream>>>(
-        full, m_full, part, m_part, d_max_coord, idx);
+    LIDIFF_CHECK_ARG(m_part < (int64_t)1 << 31, "part tensor too large for 32-bit row indices");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t blocks = ceil_div(m_full, (int64_t)kBlock * kMatchPt);
+    const int64_t splits = min(ceil_div((int64_t)2048, blocks), ceil_div(m_part, (int64_t)kMatchTile));
+    if (splits <= 1) {
+        nn_match_kernel<false><<<(unsigned)blocks, kBlock, 0, st>>>(full, m_full, part, m_part, 0, d_max_coord, idx);
+    } else {
+        const int64_t per = ceil_div(ceil_div(m_part, splits), (int64_t)kMatchTile) * kMatchTile;
+        LIDIFF_CHECK_HIP(hipMemsetAsync(idx, 0xff, (size_t)m_full * 8, st));
+        nn_match_kernel<true><<<dim3((unsigned)blocks, (unsigned)splits), kBlock, 0, st>>>(
+            full, m_full, part, m_part, per, d_max_coord, idx);
+        nn_match_finish_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, st>>>(idx, m_full);
+    }
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

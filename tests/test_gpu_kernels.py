@@ -370,6 +370,13 @@ def test_nn_match(device):
     part = me.voxelize(me.floor_to_stride(random_cloud(1500, 60, 4, batch=2), 16))[0]
     got = ops.nn_match(dev_i32(full, device), dev_i32(part, device)).cpu().numpy()
     assert np.array_equal(got, me.argmin_match(full, part))
+    # more part rows than one LDS tile -> the part rows are split over blockIdx.y and merged by atomic min;
+    # duplicated part rows put exact ties into different splits (lowest row must still win)
+    part_dup = np.tile(me.floor_to_stride(random_cloud(1700, 40, 9, batch=2), 16), (3, 1))
+    for n_full in (300, 5000, 70000):
+        fc = random_cloud(n_full, 60, 10 + n_full, batch=2)
+        got = ops.nn_match(dev_i32(fc, device), dev_i32(part_dup, device)).cpu().numpy()
+        assert np.array_equal(got, me.argmin_match(fc, part_dup)), n_full
     one = np.zeros((1, 4), np.int32)                                   # x_uncond: a single part voxel
     assert np.all(ops.nn_match(dev_i32(full, device), dev_i32(one, device)).cpu().numpy() == 0)
     # lattice-shell search through the part map's hash table: same winners as the exhaustive scan

@@ -58,12 +58,15 @@ struct ConvParams {
     int tiles_m, tiles_n, flags, replicas;
     int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
                               // 2 = no barrier, 4 = no flush
+    long long* timeline;      // LIDIFF_CONV_PROBE builds only: 8 cycle counters per workgroup (tools/conv_probe.py)
 };
 
 #ifdef LIDIFF_CONV_PROBE
 #define PROBE(bit) (p.probe & (bit))
+#define STAMP(var) const long long var = __builtin_readcyclecounter()
 #else
 #define PROBE(bit) false
+#define STAMP(var)
 #endif
 
 template <int I>
@@ -140,6 +143,10 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int wn = wave % WN, wm = wave / WN;
+    STAMP(t_start);
+#ifdef LIDIFF_CONV_PROBE
+    long long t_barrier = 0, t_flush = 0, t_issue = 0, t_mma = 0;
+#endif
 
     // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
     for (int e = tid; e < BM * BN / 4; e += NT)
@@ -328,9 +335,9 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                 const float* As = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a_buf) + img);
                 f32x4 a[NB][NJ];
 #pragma unroll
-                for (int b = 0; b < NB; ++b)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
+                    for (int b = 0; b < NB; ++b)
                         a[b][j] = *reinterpret_cast<const f32x4*>(As + (wm + WM * b) * (16 * KS) + foff[j]);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
@@ -339,24 +346,57 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
                             acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][j][e], wc[j][e], acc[b], 0, 0, 0);
+                // Fragment reads run one 16-channel group ahead of the MFMAs: left to itself the scheduler issues
+                // the reads of group j+1 only after the last MFMA of group j, and the MFMA pipe then idles for an LDS
+                // round trip four times per stage (both waves of a SIMD leave the barrier in lockstep, so neither
+                // fills the other's gap).
+                __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
+#pragma unroll
+                for (int j = 0; j + 1 < NJ; ++j)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB, 0);
             }
         };
         auto stage_end = [&]() {
-            if (!PROBE(4)) __syncthreads();   // next stage landed (vmcnt) and visible; this image is free again
+#ifdef LIDIFF_CONV_PROBE
+            STAMP(tb0);
+            if (!PROBE(4)) __syncthreads();
+            t_barrier += __builtin_readcyclecounter() - tb0;
+#else
+            __syncthreads();                  // next stage landed (vmcnt) and visible; this image is free again
+#endif
 #pragma unroll
             for (int h = 0; h < NJ; ++h) wc[h] = wnx[h];
             img ^= IMG;
         };
+#ifdef LIDIFF_CONV_PROBE
+#define PHASE(acc, from) { const long long now_ = __builtin_readcyclecounter(); acc += now_ - from; from = now_; }
+        long long tp = __builtin_readcyclecounter();
+#else
+#define PHASE(acc, from)
+#endif
         for (int s = 0; s + 1 < nslab; ++s) {             // not the last slab: the next stage is the same item
             issue(img ^ IMG, item.k, s + 1, item.n, wnx);
+            PHASE(t_issue, tp);
             mma();
+            PHASE(t_mma, tp);
             stage_end();
+#ifdef LIDIFF_CONV_PROBE
+            tp = __builtin_readcyclecounter();
+#endif
         }
         if (has_next) {                                   // last slab: the next stage opens the next item
             load_rows(next);
             issue(img ^ IMG, next.k, 0, next.n, wnx);
         }
+        PHASE(t_issue, tp);
         mma();
+        PHASE(t_mma, tp);
+        STAMP(tf0);
         if constexpr (NB > 0) {
             if (!PROBE(16)) {
                 const uint8_t* ol = out_list + item.k * BM + item.start;
@@ -384,6 +424,9 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                     for (int r = 0; r < 4; ++r) acc_lds[addr[b][r]] = old[b][r] + acc[b][r];
             }
         }
+#ifdef LIDIFF_CONV_PROBE
+        t_flush += __builtin_readcyclecounter() - tf0;
+#endif
         stage_end();
     };
 
@@ -531,6 +574,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     };
 
     // ---- main loop: work items, loads one stage ahead ------------------------------------------
+    STAMP(t_loop);
     if (packed) {
         run_packed();
     } else {
@@ -558,6 +602,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     }
     }
 
+    STAMP(t_epi);
     // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
     for (int e = tid; e < rows_here * (BN / 4); e += NT) {
         const int r = e / (BN / 4), cq = e % (BN / 4);
@@ -581,6 +626,14 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         }
         *reinterpret_cast<float4*>(p.out + o) = v;
     }
+#ifdef LIDIFF_CONV_PROBE
+    if (p.timeline != nullptr && lane == 0 && (wave == 0 || wave == NW / 2)) {   // the two waves of SIMD 0
+        STAMP(t_end);
+        long long* d = p.timeline + ((int64_t)blockIdx.x * 2 + (wave != 0)) * 10;
+        d[0] = t_loop - t_start; d[1] = t_epi - t_loop; d[2] = t_end - t_epi; d[3] = t_barrier; d[4] = t_flush;
+        d[5] = nwork; d[6] = nslab; d[7] = t_start; d[8] = t_issue; d[9] = t_mma;
+    }
+#endif
 }
 
 // W [K, c_in, c_out] row-major  ->  [K][slab32][c_out/16][j 0..1][lane 0..63][e 0..3]  with
@@ -637,8 +690,10 @@ static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
 using namespace lidiff;
 
 static int g_conv_probe = 0;
+static long long* g_conv_timeline = nullptr;
 #ifdef LIDIFF_CONV_PROBE
 extern "C" void lidiff_debug_set_conv_probe(int flags) { g_conv_probe = flags; }
+extern "C" void lidiff_debug_set_conv_timeline(long long* buf) { g_conv_timeline = buf; }
 #endif
 
 extern "C" int64_t lidiff_spconv_packed_weight_floats(int32_t k_vol, int32_t c_in, int32_t c_out) {
@@ -677,7 +732,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
-    p.k_vol = k_vol; p.relu = relu; p.flags = flags; p.replicas = replicas; p.probe = g_conv_probe;
+    p.k_vol = k_vol; p.relu = relu; p.flags = flags; p.replicas = replicas; p.probe = g_conv_probe; p.timeline = g_conv_timeline;
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(w_packed) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
                      "w_packed/out/epilogue pointers must be 16-byte aligned");

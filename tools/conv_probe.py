@@ -27,9 +27,13 @@ def main():
     ap.add_argument("--sweep", action="store_true", help="all levels x the network's channel pairs")
     ap.add_argument("--ordered", action="store_true", help="Morton-ordered tiles (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
+    ap.add_argument("--timeline", action="store_true",
+                    help="diagnostic build: per-workgroup cycle counters (prologue / main loop / epilogue / barrier / flush)")
     ap.add_argument("--probe", type=int, default=None,
                     help="diagnostic build (-DLIDIFF_CONV_PROBE): bit 0 = skip the A gather, 1 = skip the W loads, 2 = no barrier, 4 = no flush")
     args = ap.parse_args()
+    if args.timeline and args.probe is None:
+        args.probe = 0
     if args.probe is not None:
         import ctypes
         import subprocess
@@ -90,8 +94,25 @@ def main():
         torch.cuda.synchronize()
         us = 1e3 * s.elapsed_time(e) / args.iters
         tf = 2.0 * pairs * cin * cout / (us * 1e-6) / 1e12
-        print(f"sigma={args.sigma} level={level} kind={kind} {cin}->{cout} m_in={m_in} m_out={m_out} pairs={pairs} "
-              f"nbrs/row={pairs / m_out:.2f} hint={int(hint)} avg_us={us:.1f} TFLOP/s={tf:.2f}", flush=True)
+        if args.timeline:
+            import ctypes
+            from lidiff_amd import _lib
+            tl = torch.zeros(1 << 15, 2, 10, dtype=torch.int64, device=dev)
+            _lib.load().lidiff_debug_set_conv_timeline(ctypes.c_void_p(tl.data_ptr()))
+            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
+            torch.cuda.synchronize()
+            _lib.load().lidiff_debug_set_conv_timeline(ctypes.c_void_p(0))
+            t = tl.cpu().numpy().astype(np.float64)
+            t = t[t[:, 0, 5] > 0]
+            stages = (t[:, 0, 5] * t[:, 0, 6]).mean()
+            print(f"  timeline (s_memtime ticks; the two waves of SIMD 0): workgroups {len(t)}, items {t[:, 0, 5].mean():.1f} x "
+                  f"slabs {t[:, 0, 6].mean():.0f} = {stages:.0f} stages")
+            for wv, name in ((0, "wave 0"), (1, f"wave NW/2")):
+                q = t[:, wv]
+                print(f"  {name}: prologue {q[:, 0].mean():.0f}  main loop {q[:, 1].mean():.0f}  epilogue {q[:, 2].mean():.0f} | per stage: "
+                      f"loop {q[:, 1].mean() / stages:.0f} = issue {q[:, 8].mean() / stages:.0f} + mma {q[:, 9].mean() / stages:.0f} + "
+                      f"flush {q[:, 4].mean() / stages:.0f} + barrier {q[:, 3].mean() / stages:.0f} + rest "
+                      f"{(q[:, 1] - q[:, 8] - q[:, 9] - q[:, 4] - q[:, 3]).mean() / stages:.0f}")
 
     if args.sweep:
         shapes = [(0, 32, 32), (1, 32, 32), (1, 32, 64), (2, 64, 64), (2, 64, 128), (3, 128, 128), (3, 128, 256),

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     const int wn = wave % WN, wm = wave / WN;
     STAMP(t_start);
 #ifdef LIDIFF_CONV_PROBE
+    const long long rt_start = __builtin_amdgcn_s_memrealtime();      // 100 MHz wall clock
     long long t_barrier = 0, t_flush = 0, t_issue = 0, t_mma = 0;
 #endif
 
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         STAMP(t_end);
         long long* d = p.timeline + ((int64_t)blockIdx.x * 2 + (wave != 0)) * 10;
         d[0] = t_loop - t_start; d[1] = t_epi - t_loop; d[2] = t_end - t_epi; d[3] = t_barrier; d[4] = t_flush;
-        d[5] = nwork; d[6] = nslab; d[7] = t_start; d[8] = t_issue; d[9] = t_mma;
+        d[5] = nwork; d[6] = nslab; d[7] = __builtin_amdgcn_s_memrealtime() - rt_start; d[8] = t_issue; d[9] = t_mma;
     }
 #endif
 }

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--kind", default="k3")
     ap.add_argument("--sweep", action="store_true", help="all levels x the network's channel pairs")
     ap.add_argument("--ordered", action="store_true", help="Morton-ordered tiles (row_order + permuted table)")
+    ap.add_argument("--lpt", action="store_true", help="128-row tiles in descending pair-count order (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
     ap.add_argument("--timeline", action="store_true",
                     help="diagnostic build: per-workgroup cycle counters (prologue / main loop / epilogue / barrier / flush)")
@@ -79,6 +80,18 @@ def main():
         if args.ordered and nbr is not None:
             order = ops.tile_order(mgr.maps[ts if kind != "down" else ts * 2].coords, ts if kind != "down" else ts * 2)
             nbr = nbr.index_select(1, order.long()).contiguous()
+        if args.lpt and nbr is not None:
+            m = nbr.shape[1]
+            tiles = (m + 127) // 128
+            cnt = torch.zeros(tiles * 128, dtype=torch.int32, device=dev)
+            cnt[:m] = (nbr >= 0).sum(0).to(torch.int32)
+            per_tile = cnt.view(tiles, 128).sum(1)
+            last = per_tile[-1].clone()
+            per_tile[-1] = -1                                   # the ragged last tile stays last
+            tord = torch.argsort(per_tile, descending=True, stable=True)
+            rows = (tord[:, None] * 128 + torch.arange(128, device=dev)[None, :]).reshape(-1)
+            order = rows[rows < m].to(torch.int32)
+            nbr = nbr.index_select(1, order.long()).contiguous()
         hint = {"k3": mgr.is_sparse_map(ts, ts, 3), "down": mgr.is_sparse_map(ts, ts * 2, 2),
                 "up": mgr.is_sparse_map(ts * 2, ts, 2, True), "k1": False}[kind]
         if args.sparse_hint >= 0:
@@ -94,6 +107,8 @@ def main():
         torch.cuda.synchronize()
         us = 1e3 * s.elapsed_time(e) / args.iters
         tf = 2.0 * pairs * cin * cout / (us * 1e-6) / 1e12
+        print(f"sigma={args.sigma} level={level} kind={kind} {cin}->{cout} m_in={m_in} m_out={m_out} pairs={pairs} "
+              f"nbrs/row={pairs / m_out:.2f} hint={int(hint)} avg_us={us:.1f} TFLOP/s={tf:.2f}", flush=True)
         if args.timeline:
             import ctypes
             from lidiff_amd import _lib
@@ -102,7 +117,13 @@ def main():
             ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
             torch.cuda.synchronize()
             _lib.load().lidiff_debug_set_conv_timeline(ctypes.c_void_p(0))
-            t = tl.cpu().numpy().astype(np.float64)
+            raw = tl.cpu().numpy()
+            live = raw[:, 0, 5] > 0
+            q = raw[live, 0].astype(np.float64)
+            mhz = (q[:, 0] + q[:, 1] + q[:, 2]) / (q[:, 7] / 100.0)      # s_memtime ticks per us of the 100 MHz wall clock
+            print(f"  shader clock while the kernel runs (s_memtime / s_memrealtime): mean {mhz.mean():.0f} MHz, "
+                  f"min {mhz.min():.0f}, max {mhz.max():.0f}; mean workgroup duration {q[:, 7].mean() / 100:.1f} us")
+            t = raw.astype(np.float64)
             t = t[t[:, 0, 5] > 0]
             stages = (t[:, 0, 5] * t[:, 0, 6]).mean()
             print(f"  timeline (s_memtime ticks; the two waves of SIMD 0): workgroups {len(t)}, items {t[:, 0, 5].mean():.1f} x "

@@ -82,20 +82,22 @@ struct ConvCfg {
     static constexpr int NCH = BM / kChunk;      // chunks per offset (upper bound)
     static constexpr int A_FLOATS = kChunk * KS; // one A image (16 / 32 KB)
     static_assert(KS == 32 || KS == 64, "KS");
-    static_assert(BM % kChunk == 0 && BM <= 256, "BM");     // out_list is uint8
+    static_assert(BM % kChunk == 0, "BM");
     static_assert(RB % WM == 0, "WM must divide 8");
     static_assert(NT <= 1024, "workgroup size");
 
+    // pair list of output rows: byte offsets into the accumulator tile (dummy row included); 16-bit where they
+    // fit -- the narrow tiles of the low-density maps stay below 80 KB of LDS, i.e. two workgroups per CU
+    using OutT = std::conditional_t<((BM + 1) * BN * 4 < 65536), uint16_t, int32_t>;
     __host__ __device__ static size_t lds_bytes(int k_vol) {
         size_t b = 2 * (size_t)A_FLOATS * 4;              // A images (LDS-DMA targets, kept below 64 KB)
-        b += (size_t)BM * BN * 4;                         // accumulator tile
+        b += (size_t)(BM + 1) * BN * 4;                   // accumulator tile + one dummy row (branch-free flush)
         b += (size_t)k_vol * BM * 4;                      // in_list
         b += 32 * 4;                                      // cnt (k_vol <= 27; cnt[31] = #work items)
         b += (size_t)kWorkInts * 4;                       // work list
-        b += (size_t)k_vol * BM;                          // out_list (uint8)
-        b = (b + 15) & ~(size_t)15;
         b += (size_t)BM * 4;                              // output row of every tile row
-        return b + 64 * 4;                                // per-lane dummy words for the branch-free flush
+        b += (size_t)k_vol * BM * sizeof(OutT);           // out_list
+        return (b + 15) & ~(size_t)15;
     }
 };
 
@@ -112,13 +114,24 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* a_buf = reinterpret_cast<float*>(smem);
     float* acc_lds = a_buf + 2 * AF;
-    int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + BM * BN);
+    int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + (BM + 1) * BN);
     int32_t* cnt = in_list + p.k_vol * BM;
     int32_t* work = cnt + 32;
-    uint8_t* out_list = reinterpret_cast<uint8_t*>(work + kWorkInts);
-    // float index (relative to acc_lds) of 64 dummy words behind everything else
-    const int dummy_off = (int)((Cfg::lds_bytes(p.k_vol) - 64 * 4 - 2 * AF * 4) / 4);
-    int32_t* orow = reinterpret_cast<int32_t*>(acc_lds + dummy_off) - BM;      // output row of every tile row
+    int32_t* orow = work + kWorkInts;                         // output row of every tile row
+    // out_list[k][q] = byte offset of the accumulator row of pair q of offset k (its tile row x BN x 4).
+    // Entries behind an offset's last pair point at the dummy row BM, so the flush needs no bounds test
+    // and one add per element as its only address arithmetic.
+    using OutT = typename Cfg::OutT;
+    OutT* out_list = reinterpret_cast<OutT*>(orow + BM);
+    auto out4 = [&](const OutT* q) {                          // four consecutive list entries (16- or 8-byte read)
+        if constexpr (sizeof(OutT) == 4) {
+            return *reinterpret_cast<const int4*>(q);
+        } else {
+            const uint2 w = *reinterpret_cast<const uint2*>(q);
+            return make_int4((int)(w.x & 0xffff), (int)(w.x >> 16), (int)(w.y & 0xffff), (int)(w.y >> 16));
+        }
+    };
+    constexpr int kDummyRow = BM * BN * 4;
 
     // XCD-aware tile mapping: the column tiles of one row tile share an XCD (their gathers hit the
     // same L2), consecutive row tiles round-robin over the 8 XCDs.
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         for (int r = tid; r < BM; r += NT) {
             const int64_t gr = min(row0 + r, p.m_out - 1);
             in_list[r] = p.row_order ? p.row_order[gr] : (int32_t)gr;
-            out_list[r] = (uint8_t)r;
+            out_list[r] = (OutT)(r < rows_here ? r * BN * 4 : kDummyRow);
         }
         if (tid == 0) cnt[0] = rows_here;
     } else {
@@ -181,10 +194,13 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                 if (valid) {
                     const int q = pos + popc_below(m);
                     in_list[k * BM + q] = v;
-                    out_list[k * BM + q] = (uint8_t)r;
+                    out_list[k * BM + q] = (OutT)(r * BN * 4);
                 }
                 pos += __popcll(m);
             }
+#pragma unroll
+            for (int c = 0; c < BM; c += 64)
+                if (c + lane >= pos) out_list[k * BM + c + lane] = (OutT)kDummyRow;
             if (lane == 0) cnt[k] = pos;
         }
     }
@@ -400,29 +416,25 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         STAMP(tf0);
         if constexpr (NB > 0) {
             if (!PROBE(16)) {
-                const uint8_t* ol = out_list + item.k * BM + item.start;
-                uint32_t o4[NB];
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-                    o4[b] = *reinterpret_cast<const uint32_t*>(ol + 16 * (wm + WM * b) + 4 * lq);
+                // per element: its list word (one b128 read per block), one address add, read, add, write
+                const OutT* ol = out_list + item.k * BM + item.start + 4 * lq;
+                const int colb = (16 * wn + li) * 4;
+                char* accb = reinterpret_cast<char*>(acc_lds);
                 int addr[NB][4];
 #pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int prow = 16 * (wm + WM * b) + 4 * lq + r;
-                        const int orow = (o4[b] >> (8 * r)) & 0xff;
-                        addr[b][r] = prow < item.n ? orow * BN + 16 * wn + li : dummy_off + lane;
-                    }
+                for (int b = 0; b < NB; ++b) {
+                    const int4 o = out4(ol + 16 * (wm + WM * b));
+                    addr[b][0] = o.x + colb; addr[b][1] = o.y + colb; addr[b][2] = o.z + colb; addr[b][3] = o.w + colb;
+                }
                 float old[NB][4];
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) old[b][r] = acc_lds[addr[b][r]];
+                    for (int r = 0; r < 4; ++r) old[b][r] = *reinterpret_cast<const float*>(accb + addr[b][r]);
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc_lds[addr[b][r]] = old[b][r] + acc[b][r];
+                    for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(accb + addr[b][r]) = old[b][r] + acc[b][r];
             }
         }
 #ifdef LIDIFF_CONV_PROBE
@@ -538,31 +550,26 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                     if (wm == round) {
 #pragma unroll
                         for (int q = 0; q < NSW; ++q) {
-                            uint32_t o4[BLQ];
-                            int base[BLQ];
+                            if (dc.n[q] == 0) continue;          // no segment here: nothing to add
+                            int addr[BLQ][4];
+                            char* accb = reinterpret_cast<char*>(acc_lds);
+                            const int colb = (16 * wn + li) * 4;
 #pragma unroll
                             for (int g = 0; g < BLQ; ++g) {
                                 const int gb = wm + WM * (q * BLQ + g);
-                                base[g] = 16 * (gb % BPS) + 4 * lq;
-                                o4[g] = *reinterpret_cast<const uint32_t*>(out_list + dc.k[q] * BM + dc.start[q] + base[g]);
+                                const int4 o = out4(out_list + dc.k[q] * BM + dc.start[q] + 16 * (gb % BPS) + 4 * lq);
+                                addr[g][0] = o.x + colb; addr[g][1] = o.y + colb; addr[g][2] = o.z + colb; addr[g][3] = o.w + colb;
                             }
-                            int addr[BLQ][4];
-#pragma unroll
-                            for (int g = 0; g < BLQ; ++g)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int orow = (o4[g] >> (8 * r)) & 0xff;
-                                    addr[g][r] = base[g] + r < dc.n[q] ? orow * BN + 16 * wn + li : dummy_off + lane;
-                                }
                             float old[BLQ][4];
 #pragma unroll
                             for (int g = 0; g < BLQ; ++g)
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) old[g][r] = acc_lds[addr[g][r]];
+                                for (int r = 0; r < 4; ++r) old[g][r] = *reinterpret_cast<const float*>(accb + addr[g][r]);
 #pragma unroll
                             for (int g = 0; g < BLQ; ++g)
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) acc_lds[addr[g][r]] = old[g][r] + acc[q * BLQ + g][r];
+                                for (int r = 0; r < 4; ++r)
+                                    *reinterpret_cast<float*>(accb + addr[g][r]) = old[g][r] + acc[q * BLQ + g][r];
                             asm volatile("" ::: "memory");       // keep the segments' read-modify-writes in order
                         }
                     }

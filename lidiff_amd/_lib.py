@@ -33,7 +33,7 @@ SIGNATURES = {
     "lidiff_spconv_packed_weight_floats": (_i64, [_i32, _i32, _i32]),
     "lidiff_spconv_pack_weights": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
     "lidiff_spconv_fwd": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p]),
-    "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p]),
+    "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p]),
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
@@ -61,7 +61,7 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if lib.lidiff_abi_version() != 6:
+        if lib.lidiff_abi_version() != 7:
             raise RuntimeError("lidiff_amd ABI version mismatch")
         _lib = lib
     return _lib

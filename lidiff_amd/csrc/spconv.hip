@@ -761,129 +761,183 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     return dispatch_fwd<128, 1, 8>(p, vec, st);
 }
 
+namespace lidiff {
+
 // =======================================================================================
 // Weight gradient of the sparse convolution (training path, models.py:180-217; ME: ConvolutionBackwardGPU):
 //     dW[k][ci][co] = sum over the pairs (i, o) of offset k of  in[i][ci] * g[o][co]
-// One workgroup owns a [64 ci x 128 co] tile of dW[k] for a slice of the output rows.  Per chunk of 64 output rows it
-// compacts the offset's column of the neighbour table with a wave ballot, gathers the pair rows of `in` (64
-// channels) and of `g` (128 channels) with coalesced loads and stores them TRANSPOSED in LDS ([channel][pair]),
-// so that an MFMA operand fragment (4 consecutive pairs of one channel) is a
-// single 16-byte LDS read, and multiplies in^T g with v_mfma_f32_16x16x4_f32 (K = pairs).  Slices are summed with
-// fp32 atomics (as ME does), so dW is deterministic only up to the order of those adds.
-namespace lidiff {
+// i.e. per offset a [c_in x P_k] x [P_k x c_out] product whose K dimension is the offset's pair list (the
+// ME-layout rulebook: pairs sorted by offset).  One workgroup of 8 waves owns a [16 NBI ci x 128 CB co] tile of
+// dW[k] -- up to the whole 256 x 256 block, so that every pair row is gathered once -- entirely in MFMA
+// accumulators (wave w: co blocks w CB .. w CB + CB - 1, all NBI ci blocks), for one slice of the offset's pairs.
+// Per chunk of 64 pairs the gathered rows of `in` and `g` are stored row-major in LDS with a pitch = 16 mod 32
+// words: the v_mfma_f32_16x16x4_f32 operand of a lane is then in[pair 4 s + (lane >> 4)][ci block + (lane & 15)],
+// a conflict-free 4-byte read, and nothing is transposed.  The next chunk's rows are prefetched into registers
+// while the current one is multiplied.  Slices are summed with fp32 atomics (as ME does), so dW is deterministic
+// only up to the order of those adds.
+constexpr int kDwPairs = 64;                              // pairs per chunk (K of the product: 16 MFMA steps)
 
-constexpr int kDwCi = 64, kDwCo = 128, kDwRows = 64, kDwPitch = kDwRows + 4;   // pitch 68: 16-byte aligned rows
-
+template <int NBI, int CB>
 __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restrict__ in_a, int c_in_a,
                                                            const float* __restrict__ in_b, int c_in_b,
-                                                           const float* __restrict__ g, const int32_t* __restrict__ nbr,
-                                                           int64_t m_out, int c_out, int rows_per_slice,
-                                                           float* __restrict__ dw) {
-    __shared__ __attribute__((aligned(16))) float a_t[kDwCi * kDwPitch];     // [ci][pair]
-    __shared__ __attribute__((aligned(16))) float g_t[kDwCo * kDwPitch];     // [co][pair]
-    __shared__ int32_t pin[kDwRows], pout[kDwRows];
-    __shared__ int npairs_s;
+                                                           const float* __restrict__ g, const int32_t* __restrict__ pairs_in,
+                                                           const int32_t* __restrict__ pairs_out,
+                                                           const int32_t* __restrict__ offset_ptr, int64_t m_out,
+                                                           int c_out, int slices, float* __restrict__ dw) {
+    constexpr int CIT = 16 * NBI, COT = 128 * CB;        // tile extents
+    constexpr int PA = CIT + 16, PG = COT + 16;          // LDS row pitches (words): = 16 mod 32
+    constexpr int A4 = kDwPairs * (CIT / 4), G4 = kDwPairs * (COT / 4);   // float4 pieces per chunk
+    constexpr int NA = (A4 + 511) / 512, NG = (G4 + 511) / 512;          // ... per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* a_s = reinterpret_cast<float*>(smem);          // [pair][ci]
+    float* g_s = a_s + kDwPairs * PA;                     // [pair][co]
     const int c_in = c_in_a + c_in_b;
-    const int k = blockIdx.z;
-    const int co_tiles = (c_out + kDwCo - 1) / kDwCo;
-    const int ci0 = (blockIdx.y / co_tiles) * kDwCi, co0 = (blockIdx.y % co_tiles) * kDwCo;
-    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_slice;
-    const int64_t r_end = min(m_out, r_begin + rows_per_slice);
+    // offsets vary fastest over the grid: workgroups in flight together work on the same stretch of rows under
+    // different offsets, i.e. on the same rows of g and neighbouring rows of in (L2 reuse)
+    const int k = blockIdx.x;
+    const int co_tiles = (c_out + COT - 1) / COT;
+    const int ci0 = (blockIdx.y / co_tiles) * CIT, co0 = (blockIdx.y % co_tiles) * COT;
+    // this offset's pairs, and this workgroup's slice of them (whole chunks)
+    const int64_t p_lo = offset_ptr ? offset_ptr[k] : 0, p_hi = offset_ptr ? offset_ptr[k + 1] : m_out;
+    const int64_t per = (((p_hi - p_lo + slices - 1) / slices + kDwPairs - 1) / kDwPairs) * kDwPairs;
+    const int64_t s_lo = p_lo + (int64_t)blockIdx.z * per, s_hi = min(p_hi, s_lo + per);
+    if (s_lo >= s_hi) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    // wave w: co block w (16 columns), all 4 ci blocks
-    f32x4 acc[4];
+
+    float4 pa[NA], pg[NG];                                // the next chunk's rows, in flight
+    auto fetch = [&](int64_t base) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int32_t* col = nbr ? nbr + (int64_t)k * m_out : nullptr;
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += kDwRows) {
-        // ---- pairs of this chunk (ordered compaction, wave 0) ----
-        if (wave == 0) {
-            const int64_t o = r0 + lane;
-            int v = -1;
-            if (o < r_end) v = col ? col[o] : (int32_t)o;
-            const bool valid = v >= 0;
-            const unsigned long long m = __ballot(valid);
-            if (valid) {
-                const int q = popc_below(m);
-                pin[q] = v;
-                pout[q] = (int32_t)o;
-            }
-            if (lane == 0) npairs_s = __popcll(m);
-        }
-        __syncthreads();
-        const int np = npairs_s;
-        if (np > 0) {
-            // ---- gather, transposed into LDS; pairs beyond np are zero ----
-            for (int e = tid; e < kDwRows * (kDwCi / 4); e += 512) {
-                const int pr = e / (kDwCi / 4), c4 = (e % (kDwCi / 4)) * 4, ci = ci0 + c4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pr < np && ci < c_in) {
-                    const int64_t row = pin[pr];
-                    v = ci < c_in_a ? *reinterpret_cast<const float4*>(in_a + row * c_in_a + ci)
+        for (int t = 0; t < NA; ++t) {
+            const int e = tid + 512 * t, pr = e / (CIT / 4), ci = ci0 + (e % (CIT / 4)) * 4;
+            pa[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < A4 && base + pr < s_hi && ci < c_in) {
+                const int64_t row = pairs_in ? pairs_in[base + pr] : base + pr;
+                pa[t] = ci < c_in_a ? *reinterpret_cast<const float4*>(in_a + row * c_in_a + ci)
                                     : *reinterpret_cast<const float4*>(in_b + row * c_in_b + (ci - c_in_a));
-                }
-                a_t[(c4 + 0) * kDwPitch + pr] = v.x; a_t[(c4 + 1) * kDwPitch + pr] = v.y;
-                a_t[(c4 + 2) * kDwPitch + pr] = v.z; a_t[(c4 + 3) * kDwPitch + pr] = v.w;
-            }
-            for (int e = tid; e < kDwRows * (kDwCo / 4); e += 512) {
-                const int pr = e / (kDwCo / 4), c4 = (e % (kDwCo / 4)) * 4, co = co0 + c4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pr < np && co < c_out) v = *reinterpret_cast<const float4*>(g + (int64_t)pout[pr] * c_out + co);
-                g_t[(c4 + 0) * kDwPitch + pr] = v.x; g_t[(c4 + 1) * kDwPitch + pr] = v.y;
-                g_t[(c4 + 2) * kDwPitch + pr] = v.z; g_t[(c4 + 3) * kDwPitch + pr] = v.w;
-            }
-            __syncthreads();
-            // ---- in^T g: MFMA step (s, e) takes pair 16 s + 4 lq + e from both operands ----
-            const int steps = (np + 15) >> 4;
-            for (int s = 0; s < steps; ++s) {
-                const f32x4 bf = *reinterpret_cast<const f32x4*>(g_t + (16 * wave + li) * kDwPitch + 16 * s + 4 * lq);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const f32x4 af = *reinterpret_cast<const f32x4*>(a_t + (16 * b + li) * kDwPitch + 16 * s + 4 * lq);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[b], 0, 0, 0);
-                }
             }
         }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int e = tid + 512 * t, pr = e / (COT / 4), co = co0 + (e % (COT / 4)) * 4;
+            pg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < G4 && base + pr < s_hi && co < c_out) {
+                const int64_t row = pairs_out ? pairs_out[base + pr] : base + pr;
+                pg[t] = *reinterpret_cast<const float4*>(g + row * c_out + co);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int e = tid + 512 * t;
+            if (e < A4) *reinterpret_cast<float4*>(a_s + (e / (CIT / 4)) * PA + (e % (CIT / 4)) * 4) = pa[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int e = tid + 512 * t;
+            if (e < G4) *reinterpret_cast<float4*>(g_s + (e / (COT / 4)) * PG + (e % (COT / 4)) * 4) = pg[t];
+        }
+    };
+
+    f32x4 acc[NBI][CB];
+#pragma unroll
+    for (int b = 0; b < NBI; ++b)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(s_lo);
+    for (int64_t base = s_lo; base < s_hi; base += kDwPairs) {
+        __syncthreads();                                  // the previous chunk has been multiplied
+        stash();
         __syncthreads();
+        if (base + kDwPairs < s_hi) fetch(base + kDwPairs);
+        const int steps = (int)min((int64_t)kDwPairs / 4, (s_hi - base + 3) / 4);
+        for (int s4 = 0; s4 < steps; ++s4) {              // MFMA step: pairs 4 s4 .. 4 s4 + 3 (k = lane >> 4)
+            const float* ar = a_s + (4 * s4 + lq) * PA + li;
+            const float* gr = g_s + (4 * s4 + lq) * PG + 16 * CB * wave + li;
+            float bf[CB];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) bf[c] = gr[16 * c];
+#pragma unroll
+            for (int b = 0; b < NBI; ++b) {
+                const float af = ar[16 * b];
+#pragma unroll
+                for (int c = 0; c < CB; ++c) acc[b][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[c], acc[b][c], 0, 0, 0);
+            }
+        }
     }
     // D layout: col = lane & 15 (co), row = 4 (lane >> 4) + reg (ci)
     float* dwk = dw + (int64_t)k * c_in * c_out;
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NBI; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ci = ci0 + 16 * b + 4 * lq + r, co = co0 + 16 * wave + li;
-            if (ci < c_in && co < c_out && acc[b][r] != 0.f) atomicAdd(dwk + (int64_t)ci * c_out + co, acc[b][r]);
-        }
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + 16 * b + 4 * lq + r, co = co0 + 16 * (CB * wave + c) + li;
+                if (ci < c_in && co < c_out && acc[b][c][r] != 0.f)
+                    atomicAdd(dwk + (int64_t)ci * c_out + co, acc[b][c][r]);
+            }
+}
+
+template <int NBI, int CB>
+static int launch_bwd_w(const float* in_a, int c_in_a, const float* in_b, int c_in_b, const float* g,
+                        const int32_t* pin, const int32_t* pout, const int32_t* off, int k_vol, int64_t m_out,
+                        int64_t n_pairs, int c_out, float* dw, hipStream_t st) {
+    constexpr int CIT = 16 * NBI, COT = 128 * CB;
+    const size_t lds = (size_t)kDwPairs * ((CIT + 16) + (COT + 16)) * 4;
+    auto kern = spconv_bwd_w_kernel<NBI, CB>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int c_in = c_in_a + c_in_b;
+    const int tiles = (int)(ceil_div(c_in, CIT) * ceil_div(c_out, COT));
+    // pair slices: a few workgroups per CU, but at least 4 chunks each (pairs spread evenly over the offsets)
+    int64_t slices = ceil_div((int64_t)1024, (int64_t)tiles * k_vol);
+    const int64_t max_slices = max((int64_t)1, n_pairs / k_vol / (4 * kDwPairs));
+    slices = max((int64_t)1, min(slices, max_slices));
+    hipLaunchKernelGGL(kern, dim3((unsigned)k_vol, (unsigned)tiles, (unsigned)slices), dim3(512), lds, st, in_a, c_in_a,
+                       in_b, c_in_b, g, pin, pout, off, m_out, c_out, (int)slices, dw);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
 }
 
 }  // namespace lidiff
 
 extern "C" int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
-                                   const float* grad_out, const int32_t* nbr, int32_t k_vol, int64_t m_in,
+                                   const float* grad_out, const int32_t* pairs_in, const int32_t* pairs_out,
+                                   const int32_t* offset_ptr, int64_t n_pairs, int32_t k_vol, int64_t m_in,
                                    int64_t m_out, int32_t c_out, float* dw, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && grad_out != nullptr && dw != nullptr, "null pointer");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
-    LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
+    const bool identity = pairs_in == nullptr && pairs_out == nullptr && offset_ptr == nullptr;
+    LIDIFF_CHECK_ARG(identity ? (k_vol == 1 && m_in == m_out) : (pairs_in && pairs_out && offset_ptr),
+                     "rulebook pointers must be all set, or all null for the identity map (K=1, m_in==m_out)");
     LIDIFF_CHECK_ARG(c_in_a % 4 == 0 && c_in_b % 4 == 0 && c_out % 4 == 0, "channel counts must be multiples of 4");
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(in_a) && al16(in_b) && al16(grad_out), "feature pointers must be 16-byte aligned");
-    if (m_out == 0) return 0;
+    if (identity) n_pairs = m_out;
+    if (m_out == 0 || n_pairs <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
     const int c_in = c_in_a + c_in_b;
-    const int tiles = (int)(ceil_div(c_in, kDwCi) * ceil_div(c_out, kDwCo));
-    // enough row slices to fill the chip a few times over, at least 8 chunks each
-    int64_t slices = ceil_div(2048, (int64_t)tiles * k_vol);
-    const int64_t max_slices = ceil_div(m_out, 8 * kDwRows);
-    if (slices > max_slices) slices = max_slices;
-    if (slices < 1) slices = 1;
-    int64_t rows_per_slice = ceil_div(ceil_div(m_out, slices), kDwRows) * kDwRows;
-    slices = ceil_div(m_out, rows_per_slice);
-    hipLaunchKernelGGL(spconv_bwd_w_kernel, dim3((unsigned)slices, (unsigned)tiles, (unsigned)k_vol), dim3(512), 0,
-                       (hipStream_t)stream, in_a, c_in_a, in_b, c_in_b, grad_out, nbr, m_out, c_out, (int)rows_per_slice, dw);
-    LIDIFF_CHECK_LAUNCH();
-    return 0;
+    const int nbi = c_in > 128 ? 16 : c_in > 64 ? 8 : c_in > 32 ? 4 : 2;      // ci blocks of the tile (<= 256 channels)
+#define LIDIFF_DW(NBI, CB) \
+    return launch_bwd_w<NBI, CB>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr, k_vol, m_out, \
+                                 n_pairs, c_out, dw, st)
+    if (c_out > 128) {
+        if (nbi == 16) LIDIFF_DW(16, 2);
+        if (nbi == 8) LIDIFF_DW(8, 2);
+        if (nbi == 4) LIDIFF_DW(4, 2);
+        LIDIFF_DW(2, 2);
+    }
+    if (nbi == 16) LIDIFF_DW(16, 1);
+    if (nbi == 8) LIDIFF_DW(8, 1);
+    if (nbi == 4) LIDIFF_DW(4, 1);
+    LIDIFF_DW(2, 1);
+#undef LIDIFF_DW
 }

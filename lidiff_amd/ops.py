@@ -264,10 +264,21 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     return out
 
 
+def rulebook_of(nbr: torch.Tensor):
+    """(pairs_in, pairs_out, offset_ptr, n_pairs) of a neighbour table, built once and kept on the table tensor
+    (kernel maps are cached per coordinate manager, so every conv on the map shares it in backward)."""
+    rb = getattr(nbr, "_lidiff_rulebook", None)
+    if rb is None:
+        pin, pout, off = rulebook_compact(nbr)
+        rb = (pin, pout, off, int(pin.shape[0]))
+        nbr._lidiff_rulebook = rb
+    return rb
+
+
 def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None) -> torch.Tensor:
     """Weight gradient of spconv_fwd (training path, models.py:180-217): dW[k] = gather(in)[pairs_k]^T @
-    grad_out[pairs_k] by the MFMA kernel lidiff_spconv_bwd_w; channel counts that are not multiples of 4 (the
-    3-channel stem) go through the rulebook + row gathers + one library GEMM per offset."""
+    grad_out[pairs_k] by the MFMA kernel lidiff_spconv_bwd_w over the map's rulebook; channel counts that are not
+    multiples of 4 (the 3-channel stem) go through row gathers + one library GEMM per offset."""
     require_device(in_a, grad_out, nbr, in_b)
     in_a = in_a.contiguous()
     grad_out = grad_out.contiguous()
@@ -277,13 +288,14 @@ def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None) -> torch.Tensor:
         if in_b is not None:
             in_b = in_b.contiguous()
         dw = torch.zeros((k, c_a + c_b, c_out), dtype=torch.float32, device=in_a.device)
-        call("lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out), ptr(nbr), k, in_a.shape[0], m_out,
-             c_out, ptr(dw), stream_ptr())
+        pin, pout, off, n_pairs = (None, None, None, m_out) if nbr is None else rulebook_of(nbr)
+        call("lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out), ptr(pin), ptr(pout), ptr(off),
+             n_pairs, k, in_a.shape[0], m_out, c_out, ptr(dw), stream_ptr())
         return dw
     x = in_a if in_b is None else torch.cat([in_a, in_b], dim=1)
     if nbr is None:                                   # kernel_size 1: identity map
         return (x.t() @ grad_out).unsqueeze(0)
-    pin, pout, off = rulebook_compact(nbr)
+    pin, pout, off, _ = rulebook_of(nbr)
     off = off.tolist()
     dw = torch.zeros((k, x.shape[1], c_out), dtype=torch.float32, device=x.device)
     for kk in range(k):

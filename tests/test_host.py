@@ -22,7 +22,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported"
-    assert lib.lidiff_abi_version() == 6
+    assert lib.lidiff_abi_version() == 7
     assert lib.lidiff_hash_capacity(180000) == 524288 and lib.lidiff_hash_capacity(1) == 1024
     assert lib.lidiff_unique_workspace_bytes(1000) >= 1000 * 4
     # host-side argument validation reaches the error string without touching a device

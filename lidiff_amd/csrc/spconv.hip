@@ -777,7 +777,7 @@ namespace lidiff {
 // only up to the order of those adds.
 constexpr int kDwPairs = 64;                              // pairs per chunk (K of the product: 16 MFMA steps)
 
-template <int NBI, int CB>
+template <int NBI, int CB, bool IDENT>
 __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restrict__ in_a, int c_in_a,
                                                            const float* __restrict__ in_b, int c_in_b,
                                                            const float* __restrict__ g, const int32_t* __restrict__ pairs_in,
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
     const int co_tiles = (c_out + COT - 1) / COT;
     const int ci0 = (blockIdx.y / co_tiles) * CIT, co0 = (blockIdx.y % co_tiles) * COT;
     // this offset's pairs, and this workgroup's slice of them (whole chunks)
-    const int64_t p_lo = offset_ptr ? offset_ptr[k] : 0, p_hi = offset_ptr ? offset_ptr[k + 1] : m_out;
+    const int64_t p_lo = IDENT ? 0 : offset_ptr[k], p_hi = IDENT ? m_out : offset_ptr[k + 1];
     const int64_t per = (((p_hi - p_lo + slices - 1) / slices + kDwPairs - 1) / kDwPairs) * kDwPairs;
     const int64_t s_lo = p_lo + (int64_t)blockIdx.z * per, s_hi = min(p_hi, s_lo + per);
     if (s_lo >= s_hi) return;
@@ -807,37 +807,55 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
     const int li = lane & 15, lq = lane >> 4;
 
     float4 pa[NA], pg[NG];                                // the next chunk's rows, in flight
+    unsigned keep = 0;                                    // which of them are real (bit t: pa[t], bit 16 + t: pg[t])
+    // Branch-free and in two rounds -- all pair indices, then all rows -- so that the loads of a chunk are in
+    // flight together (a per-piece "if valid: index, then row" compiles to a chain of dependent round trips).
+    // Pieces outside the slice or the channel range load a clamped address and are zeroed when stashed.
     auto fetch = [&](int64_t base) {
+        int ra[NA], rg[NG];                               // IDENT: the identity map of a kernel_size-1 convolution
+        keep = 0;
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
-            const int e = tid + 512 * t, pr = e / (CIT / 4), ci = ci0 + (e % (CIT / 4)) * 4;
-            pa[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < A4 && base + pr < s_hi && ci < c_in) {
-                const int64_t row = pairs_in ? pairs_in[base + pr] : base + pr;
-                pa[t] = ci < c_in_a ? *reinterpret_cast<const float4*>(in_a + row * c_in_a + ci)
-                                    : *reinterpret_cast<const float4*>(in_b + row * c_in_b + (ci - c_in_a));
-            }
+            const int64_t pp = min(base + min(tid + 512 * t, A4 - 1) / (CIT / 4), s_hi - 1);
+            ra[t] = IDENT ? (int)pp : pairs_in[pp];
         }
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
-            const int e = tid + 512 * t, pr = e / (COT / 4), co = co0 + (e % (COT / 4)) * 4;
-            pg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < G4 && base + pr < s_hi && co < c_out) {
-                const int64_t row = pairs_out ? pairs_out[base + pr] : base + pr;
-                pg[t] = *reinterpret_cast<const float4*>(g + row * c_out + co);
-            }
+            const int64_t pp = min(base + min(tid + 512 * t, G4 - 1) / (COT / 4), s_hi - 1);
+            rg[t] = IDENT ? (int)pp : pairs_out[pp];
+        }
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int e = tid + 512 * t, ec = min(e, A4 - 1), pr = ec / (CIT / 4), ci = ci0 + (ec % (CIT / 4)) * 4;
+            const int cic = min(ci, c_in - 4);
+            const float* src = cic < c_in_a ? in_a + (int64_t)ra[t] * c_in_a + cic
+                                            : in_b + (int64_t)ra[t] * c_in_b + (cic - c_in_a);
+            pa[t] = *reinterpret_cast<const float4*>(src);
+            keep |= (e < A4 && base + pr < s_hi && ci < c_in) ? 1u << t : 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int e = tid + 512 * t, ec = min(e, G4 - 1), pr = ec / (COT / 4), co = co0 + (ec % (COT / 4)) * 4;
+            pg[t] = *reinterpret_cast<const float4*>(g + (int64_t)rg[t] * c_out + min(co, c_out - 4));
+            keep |= (e < G4 && base + pr < s_hi && co < c_out) ? 1u << (16 + t) : 0u;
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
             const int e = tid + 512 * t;
-            if (e < A4) *reinterpret_cast<float4*>(a_s + (e / (CIT / 4)) * PA + (e % (CIT / 4)) * 4) = pa[t];
+            const float m = (keep >> t) & 1u ? 1.f : 0.f;
+            if (e < A4)
+                *reinterpret_cast<float4*>(a_s + (e / (CIT / 4)) * PA + (e % (CIT / 4)) * 4) =
+                    make_float4(pa[t].x * m, pa[t].y * m, pa[t].z * m, pa[t].w * m);
         }
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
             const int e = tid + 512 * t;
-            if (e < G4) *reinterpret_cast<float4*>(g_s + (e / (COT / 4)) * PG + (e % (COT / 4)) * 4) = pg[t];
+            const float m = (keep >> (16 + t)) & 1u ? 1.f : 0.f;
+            if (e < G4)
+                *reinterpret_cast<float4*>(g_s + (e / (COT / 4)) * PG + (e % (COT / 4)) * 4) =
+                    make_float4(pg[t].x * m, pg[t].y * m, pg[t].z * m, pg[t].w * m);
         }
     };
 
@@ -881,13 +899,13 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
             }
 }
 
-template <int NBI, int CB>
+template <int NBI, int CB, bool IDENT>
 static int launch_bwd_w(const float* in_a, int c_in_a, const float* in_b, int c_in_b, const float* g,
                         const int32_t* pin, const int32_t* pout, const int32_t* off, int k_vol, int64_t m_out,
                         int64_t n_pairs, int c_out, float* dw, hipStream_t st) {
     constexpr int CIT = 16 * NBI, COT = 128 * CB;
     const size_t lds = (size_t)kDwPairs * ((CIT + 16) + (COT + 16)) * 4;
-    auto kern = spconv_bwd_w_kernel<NBI, CB>;
+    auto kern = spconv_bwd_w_kernel<NBI, CB, IDENT>;
     static thread_local bool configured = false;
     if (!configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -926,9 +944,11 @@ extern "C" int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const floa
     hipStream_t st = (hipStream_t)stream;
     const int c_in = c_in_a + c_in_b;
     const int nbi = c_in > 128 ? 16 : c_in > 64 ? 8 : c_in > 32 ? 4 : 2;      // ci blocks of the tile (<= 256 channels)
-#define LIDIFF_DW(NBI, CB) \
-    return launch_bwd_w<NBI, CB>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr, k_vol, m_out, \
-                                 n_pairs, c_out, dw, st)
+#define LIDIFF_DW(NBI, CB)                                                                                          \
+    return identity ? launch_bwd_w<NBI, CB, true>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr,  \
+                                                  k_vol, m_out, n_pairs, c_out, dw, st)                                \
+                    : launch_bwd_w<NBI, CB, false>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr, \
+                                                   k_vol, m_out, n_pairs, c_out, dw, st)
     if (c_out > 128) {
         if (nbi == 16) LIDIFF_DW(16, 2);
         if (nbi == 8) LIDIFF_DW(8, 2);

@@ -407,7 +407,10 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
     __shared__ float4 tile[kMatchTile];
     const float scale = 2.0f * (float)(*d_max_coord);
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x * kMatchPt + threadIdx.x;   // rows i0, i0 + blockDim.x
-    float fb[kMatchPt], fx[kMatchPt], fy[kMatchPt], fz[kMatchPt], best[kMatchPt];
+    static_assert(kMatchPt == 2, "the two rows of a lane ride in the halves of packed-fp32 registers");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 fb, fx, fy, fz;                                 // component q = row q of this lane (v_pk_add / v_pk_fma)
+    float best[kMatchPt];
     int best_j[kMatchPt];
 #pragma unroll
     for (int q = 0; q < kMatchPt; ++q) {
@@ -428,12 +431,11 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
         __syncthreads();
         for (int t = 0; t < cnt; ++t) {
             const float4 p = tile[t];
+            const f32x2 db = fb - p.x, dx = fx - p.y, dy = fy - p.z, dz = fz - p.w;
+            const f32x2 d = db * db + dx * dx + dy * dy + dz * dz;       // same operation order as the scalar form
 #pragma unroll
-            for (int q = 0; q < kMatchPt; ++q) {
-                const float db = fb[q] - p.x, dx = fx[q] - p.y, dy = fy[q] - p.z, dz = fz[q] - p.w;
-                const float d = db * db + dx * dx + dy * dy + dz * dz;
-                if (d < best[q]) { best[q] = d; best_j[q] = (int)(base + t); }
-            }
+            for (int q = 0; q < kMatchPt; ++q)
+                if (d[q] < best[q]) { best[q] = d[q]; best_j[q] = (int)(base + t); }
         }
     }
 #pragma unroll

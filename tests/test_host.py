@@ -22,6 +22,18 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported"
+    # the ctypes mirror must take exactly the parameters the header declares (pointer / integer / float classes too)
+    import ctypes as C
+    flat = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    for name, params in re.findall(r"\b(lidiff_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", flat):
+        params = [q.strip() for q in params.split(",") if q.strip() and q.strip() != "void"]
+        argtypes = _lib.SIGNATURES[name][1]
+        assert len(params) == len(argtypes), (name, params, argtypes)
+        for q, a in zip(params, argtypes):
+            want = C.c_void_p if "*" in q else C.c_float if q.startswith("float") else None
+            assert (a is want) if want is not None else a in (C.c_int32, C.c_int64), (name, q, a)
+            if want is None:
+                assert a is (C.c_int64 if q.startswith("int64_t") else C.c_int32), (name, q, a)
     assert lib.lidiff_abi_version() == 7
     assert lib.lidiff_hash_capacity(180000) == 524288 and lib.lidiff_hash_capacity(1) == 1024
     assert lib.lidiff_unique_workspace_bytes(1000) >= 1000 * 4

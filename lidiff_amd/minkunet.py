@@ -338,20 +338,24 @@ class MinkUNetDiff(_Base):
             cache[key] = hit
         return _RepeatSegments.apply(t, hit[1])
 
-    def _condition_hidden(self, name, x, part, temp_emb, out=None):
-        """leaky(lin1(cat(latent(match), temp))) for the rows of x's coordinate map (fused plan): the row-wise MLPs
-        run on the few part rows BEFORE the gather they commute with, the first latemp Linear is split over its
-        (p, t) inputs, and gather + time bias + activation are one kernel."""
+    def _condition_terms(self, name, part, temp_emb):
+        """The two summands of lin1(cat(latent(match), temp)) before the gather (fused plan): the row-wise MLPs run on
+        the few part rows BEFORE the gather they commute with, and the first latemp Linear is split over its (p, t)
+        inputs.  Returns (h_p [M_p, h], h_t [B, h])."""
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"                      # minkunet.py:461: cat((t4, p4))
-        idx = self.match_index(x, part)
         lat = latent(part.F)                                     # [M_p, 256] instead of [M_l, 256]
         lin1 = latemp[0]
         c = lat.shape[1]
         w_t, w_p = (lin1.weight[:, :c], lin1.weight[:, c:]) if t_first else (lin1.weight[:, c:], lin1.weight[:, :c])
-        h_p = lat @ w_p.t()                                      # [M_p, h]
-        h_t = TF.linear(temp(temp_emb), w_t, lin1.bias)          # [B, h]
+        return lat @ w_p.t(), TF.linear(temp(temp_emb), w_t, lin1.bias)
+
+    def _condition_hidden(self, name, x, part, temp_emb, out=None):
+        """leaky(lin1(cat(latent(match), temp))) for the rows of x's coordinate map: gather + time bias + activation
+        are one kernel."""
+        h_p, h_t = self._condition_terms(name, part, temp_emb)
+        idx = self.match_index(x, part)
         if h_t.shape[0] == 1 and h_p.shape[1] % 4 == 0:
             return ops.gather_bias_leaky(h_p, idx, h_t, 0.1, out=out)
         h_t = self._per_batch_rows(h_t, x)
@@ -364,16 +368,30 @@ class MinkUNetDiff(_Base):
     def _condition(self, name, x, part, temp_emb):
         """x * w with w = latemp(cat(latent(match), temp)) -- e.g. minkunet.py:424-431.  `part` may be a tuple of
         part tensors, one per replica of x (the CFG pair): their hidden layers fill one stacked buffer, so the
-        second Linear and the multiply run once over all replicas."""
+        second Linear runs once over all replicas.  A part tensor with a single voxel -- the unconditional branch,
+        whose condition is the all-zero scan (pipeline:89) -- matches every row to that voxel: its w is ONE row,
+        computed once and broadcast, instead of M_l identical rows through the gather and the Linear."""
         if _fusable(self):
             parts = part if isinstance(part, (tuple, list)) else (part,)
             assert len(parts) == x.replicas
             lin2 = getattr(self, f"latemp_{name}")[2]
             m = x.F.shape[0] // x.replicas
-            hidden = torch.empty((x.F.shape[0], lin2.in_features), dtype=torch.float32, device=x.F.device)
-            for r, q in enumerate(parts):
-                self._condition_hidden(name, x, q, temp_emb, out=hidden[r * m:(r + 1) * m])
-            return x * lin2(hidden)
+            const = [q.F.shape[0] == 1 and temp_emb.shape[0] == 1 for q in parts]
+            full = [r for r in range(len(parts)) if not const[r]]
+            out = torch.empty_like(x.F)
+            if full:
+                hidden = torch.empty((len(full) * m, lin2.in_features), dtype=torch.float32, device=x.F.device)
+                for i, r in enumerate(full):
+                    self._condition_hidden(name, x, parts[r], temp_emb, out=hidden[i * m:(i + 1) * m])
+                w = lin2(hidden)
+                for i, r in enumerate(full):
+                    torch.mul(x.F[r * m:(r + 1) * m], w[i * m:(i + 1) * m], out=out[r * m:(r + 1) * m])
+            for r in range(len(parts)):
+                if const[r]:
+                    h_p, h_t = self._condition_terms(name, parts[r], temp_emb)
+                    w_row = lin2(TF.leaky_relu(h_p + h_t, 0.1))                    # [1, C]
+                    torch.mul(x.F[r * m:(r + 1) * m], w_row, out=out[r * m:(r + 1) * m])
+            return x._like(out)
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"

@@ -277,10 +277,12 @@ def test_spconv_linearity_full_size(device, fps_scan):
 
 
 @pytest.mark.parametrize("kind,ks,stride,cin,cout", [("conv", 3, 1, 32, 64), ("conv", 2, 2, 64, 64), ("tconv", 2, 2, 64, 32),
-                                                    ("conv", 1, 1, 96, 32)])
+                                                    ("conv", 1, 1, 96, 32), ("conv", 3, 1, 256, 256),
+                                                    ("conv", 3, 1, 192, 144), ("conv", 1, 1, 320, 256)])
 def test_spconv_backward_vs_oracle_autograd(device, kind, ks, stride, cin, cout):
     """Training path (models.py:180-217): dX (the same HIP kernel over the swapped map with W^T) and dW
-    (rulebook + gathers + GEMM) of the ME-shim convolutions against torch autograd through the oracle."""
+    (lidiff_spconv_bwd_w over the map's rulebook: every tile instantiation, partial ci / co tiles, the identity map)
+    of the ME-shim convolutions against torch autograd through the oracle."""
     import lidiff_amd.MinkowskiEngine as ME
     coords = random_cloud(1500, 5, 31, batch=2)
     g = torch.Generator().manual_seed(7)

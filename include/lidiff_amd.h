@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 7
+#define LIDIFF_ABI_VERSION 8
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */   /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -154,6 +154,13 @@ int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int
                        float* dst, void* stream);
 int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
                             float* dst, void* stream);
+
+/* The conditioning multiply x * w, w = latemp(cat(latent(match), temp)) -- minkunet.py:424-431 etc.: for one batch
+ * (one time embedding) every layer of that MLP is row-wise and commutes with the gather of match_part_to_full, so w
+ * is table[idx] with table = the MLP evaluated on the few part rows: dst[r,:] = x[r,:] * table[idx[r],:] in one pass.
+ * c % 4 == 0, pointers 16-byte aligned. */
+int lidiff_gather_mul_rows(const float* x, const float* table, const int64_t* idx, int64_t n_rows, int32_t c,
+                           float* dst, void* stream);
 
 /* Hidden layer of the conditioning MLPs -- minkunet.py:424-431 (latemp_* applied to cat(latent(match), temp)):
  * with the row-wise Linear commuted in front of the gather, dst[r,:] = leaky_relu(src[idx[r],:] + bias[:], slope)

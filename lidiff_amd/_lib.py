@@ -38,6 +38,7 @@ SIGNATURES = {
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
     "lidiff_scatter_add_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "lidiff_gather_mul_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     "lidiff_nn_match": (_i32, [_p, _i64, _p, _i64, _p, _p, _p]),
     "lidiff_fps_workspace_bytes": (_i64, [_i64]),
     "lidiff_fps": (_i32, [_p, _i64, _i64, _p, _p, _p]),
@@ -61,7 +62,7 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if lib.lidiff_abi_version() != 7:
+        if lib.lidiff_abi_version() != 8:
             raise RuntimeError("lidiff_amd ABI version mismatch")
         _lib = lib
     return _lib

@@ -367,6 +367,18 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
 
 // out[r, :] = leaky_relu(src[idx[r], :] + bias[:], slope): the conditioning path's hidden layer
 // (minkunet.py:424-431 after commuting the row-wise MLP with the gather): one pass instead of gather + add + activation.
+// dst[r,:] = x[r,:] * table[idx[r],:] -- the conditioning multiply with the whole MLP commuted in front of the gather
+__global__ void gather_mul_rows_kernel(const float* __restrict__ x, const float* __restrict__ table,
+                                       const int64_t* __restrict__ idx, int64_t n, int c4, float* __restrict__ dst) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * c4) return;
+    const int64_t r = e / c4;
+    const int j = (int)(e % c4);
+    const float4 v = reinterpret_cast<const float4*>(x)[e];
+    const float4 w = reinterpret_cast<const float4*>(table)[idx[r] * c4 + j];
+    reinterpret_cast<float4*>(dst)[e] = make_float4(v.x * w.x, v.y * w.y, v.z * w.z, v.w * w.w);
+}
+
 __global__ void gather_bias_leaky_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
                                          const float* __restrict__ bias, int64_t n, int c4, float slope,
                                          float* __restrict__ dst) {
@@ -801,6 +813,17 @@ int lidiff_gather_bias_leaky(const float* src, const int64_t* idx, const float* 
     if (n_rows == 0) return 0;
     gather_bias_leaky_kernel<<<(unsigned)ceil_div(n_rows * (c / 4), kBlock), kBlock, 0, (hipStream_t)stream>>>(
         src, idx, bias, n_rows, c / 4, slope, dst);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_gather_mul_rows(const float* x, const float* table, const int64_t* idx, int64_t n_rows, int32_t c,
+                           float* dst, void* stream) {
+    LIDIFF_CHECK_ARG(c > 0 && c % 4 == 0 && n_rows >= 0, "c must be a positive multiple of 4");
+    LIDIFF_CHECK_ARG((((uintptr_t)x | (uintptr_t)dst | (uintptr_t)table) & 15) == 0, "pointers must be 16-byte aligned");
+    if (n_rows == 0) return 0;
+    gather_mul_rows_kernel<<<(unsigned)ceil_div(n_rows * (c / 4), kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        x, table, idx, n_rows, c / 4, dst);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

@@ -368,29 +368,31 @@ class MinkUNetDiff(_Base):
     def _condition(self, name, x, part, temp_emb):
         """x * w with w = latemp(cat(latent(match), temp)) -- e.g. minkunet.py:424-431.  `part` may be a tuple of
         part tensors, one per replica of x (the CFG pair): their hidden layers fill one stacked buffer, so the
-        second Linear runs once over all replicas.  A part tensor with a single voxel -- the unconditional branch,
-        whose condition is the all-zero scan (pipeline:89) -- matches every row to that voxel: its w is ONE row,
-        computed once and broadcast, instead of M_l identical rows through the gather and the Linear."""
+        second Linear runs once over all replicas (several batches), or -- one batch -- the whole MLP runs on the part
+        rows and w is a gather of its output."""
         if _fusable(self):
             parts = part if isinstance(part, (tuple, list)) else (part,)
             assert len(parts) == x.replicas
             lin2 = getattr(self, f"latemp_{name}")[2]
             m = x.F.shape[0] // x.replicas
-            const = [q.F.shape[0] == 1 and temp_emb.shape[0] == 1 for q in parts]
-            full = [r for r in range(len(parts)) if not const[r]]
             out = torch.empty_like(x.F)
-            if full:
-                hidden = torch.empty((len(full) * m, lin2.in_features), dtype=torch.float32, device=x.F.device)
-                for i, r in enumerate(full):
-                    self._condition_hidden(name, x, parts[r], temp_emb, out=hidden[i * m:(i + 1) * m])
-                w = lin2(hidden)
-                for i, r in enumerate(full):
-                    torch.mul(x.F[r * m:(r + 1) * m], w[i * m:(i + 1) * m], out=out[r * m:(r + 1) * m])
-            for r in range(len(parts)):
-                if const[r]:
-                    h_p, h_t = self._condition_terms(name, parts[r], temp_emb)
-                    w_row = lin2(TF.leaky_relu(h_p + h_t, 0.1))                    # [1, C]
-                    torch.mul(x.F[r * m:(r + 1) * m], w_row, out=out[r * m:(r + 1) * m])
+            if temp_emb.shape[0] == 1 and lin2.out_features % 4 == 0:
+                # one batch: the time-embedding term is the same row everywhere, so the activation and the second
+                # Linear are row-wise too and the WHOLE MLP commutes with the gather -- w = table[idx] with the
+                # table evaluated on the part rows (one row for the single-voxel unconditional branch: broadcast)
+                for r, q in enumerate(parts):
+                    h_p, h_t = self._condition_terms(name, q, temp_emb)
+                    table = lin2(TF.leaky_relu(h_p + h_t, 0.1))                     # [M_p, C]
+                    rows = slice(r * m, (r + 1) * m)
+                    if table.shape[0] == 1:
+                        torch.mul(x.F[rows], table, out=out[rows])
+                    else:
+                        ops.gather_mul_rows(x.F[rows], table, self.match_index(x, q), out=out[rows])
+                return x._like(out)
+            hidden = torch.empty((x.F.shape[0], lin2.in_features), dtype=torch.float32, device=x.F.device)
+            for r, q in enumerate(parts):
+                self._condition_hidden(name, x, q, temp_emb, out=hidden[r * m:(r + 1) * m])
+            torch.mul(x.F, lin2(hidden), out=out)
             return x._like(out)
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))

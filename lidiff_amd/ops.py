@@ -332,6 +332,20 @@ def gather_bias_leaky(src: torch.Tensor, idx: torch.Tensor, bias: torch.Tensor, 
     return out
 
 
+def gather_mul_rows(x: torch.Tensor, table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor | None = None):
+    """x * table[idx] in one pass (the conditioning multiply of minkunet.py:431 etc. with its MLP evaluated on the
+    part rows).  `out`: optional destination of x's shape (may be a row slice of a larger buffer)."""
+    require_device(x, table, idx)
+    x, table, idx = x.contiguous(), table.contiguous(), idx.contiguous()
+    n, c = x.shape
+    assert table.shape[1] == c and idx.shape[0] == n and idx.dtype == torch.int64
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    assert out.shape == (n, c) and out.is_contiguous()
+    call("lidiff_gather_mul_rows", ptr(x), ptr(table), ptr(idx), n, c, ptr(out), stream_ptr())
+    return out
+
+
 def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tensor:
     src = src.contiguous()
     n, c = src.shape

@@ -355,6 +355,20 @@ def test_farthest_point_sample(device, fps_scan):
     assert torch.equal(ops.farthest_point_sample(sub.to(device), 18000).cpu(), torch.arange(18000))
 
 
+def test_gather_mul_rows(device):
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for n, mp, c in ((1, 1, 32), (3001, 700, 96), (20000, 5824, 256)):
+        x, table = torch.randn(n, c, generator=g), torch.randn(mp, c, generator=g)
+        idx = torch.randint(0, mp, (n,), generator=g)
+        got = ops.gather_mul_rows(x.to(device), table.to(device), idx.to(device))
+        assert torch.equal(got.cpu(), x * table[idx])                  # one multiply per element: bit-exact
+    buf = torch.zeros(10, 32, device=device)
+    ops.gather_mul_rows(torch.ones(4, 32, device=device), torch.full((2, 32), 3.0, device=device),
+                        torch.tensor([0, 1, 1, 0], device=device), out=buf[3:7])
+    assert float(buf.sum()) == 4 * 32 * 3.0 and float(buf[:3].abs().sum() + buf[7:].abs().sum()) == 0.0
+
+
 def test_gather_bias_leaky(device):
     from lidiff_amd import ops
     g = torch.Generator().manual_seed(2)

@@ -338,14 +338,15 @@ class MinkUNetDiff(_Base):
             cache[key] = hit
         return _RepeatSegments.apply(t, hit[1])
 
-    def _condition_terms(self, name, part, temp_emb):
+    def _condition_terms(self, name, part_feats, temp_emb):
         """The two summands of lin1(cat(latent(match), temp)) before the gather (fused plan): the row-wise MLPs run on
         the few part rows BEFORE the gather they commute with, and the first latemp Linear is split over its (p, t)
-        inputs.  Returns (h_p [M_p, h], h_t [B, h])."""
+        inputs.  `part_feats` [M_p, 256] (the rows of several part tensors may be stacked).  Returns (h_p [M_p, h],
+        h_t [B, h])."""
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"                      # minkunet.py:461: cat((t4, p4))
-        lat = latent(part.F)                                     # [M_p, 256] instead of [M_l, 256]
+        lat = latent(part_feats)                                 # [M_p, 256] instead of [M_l, 256]
         lin1 = latemp[0]
         c = lat.shape[1]
         w_t, w_p = (lin1.weight[:, :c], lin1.weight[:, c:]) if t_first else (lin1.weight[:, c:], lin1.weight[:, :c])
@@ -354,7 +355,7 @@ class MinkUNetDiff(_Base):
     def _condition_hidden(self, name, x, part, temp_emb, out=None):
         """leaky(lin1(cat(latent(match), temp))) for the rows of x's coordinate map: gather + time bias + activation
         are one kernel."""
-        h_p, h_t = self._condition_terms(name, part, temp_emb)
+        h_p, h_t = self._condition_terms(name, part.F, temp_emb)
         idx = self.match_index(x, part)
         if h_t.shape[0] == 1 and h_p.shape[1] % 4 == 0:
             return ops.gather_bias_leaky(h_p, idx, h_t, 0.1, out=out)
@@ -380,9 +381,14 @@ class MinkUNetDiff(_Base):
                 # one batch: the time-embedding term is the same row everywhere, so the activation and the second
                 # Linear are row-wise too and the WHOLE MLP commutes with the gather -- w = table[idx] with the
                 # table evaluated on the part rows (one row for the single-voxel unconditional branch: broadcast)
+                # (the part rows of all replicas go through the small MLPs together: one launch per Linear)
+                feats = parts[0].F if len(parts) == 1 else torch.cat([q.F for q in parts], dim=0)
+                h_p, h_t = self._condition_terms(name, feats, temp_emb)
+                tables = lin2(TF.leaky_relu(h_p + h_t, 0.1))                        # [sum M_p, C]
+                lo = 0
                 for r, q in enumerate(parts):
-                    h_p, h_t = self._condition_terms(name, q, temp_emb)
-                    table = lin2(TF.leaky_relu(h_p + h_t, 0.1))                     # [M_p, C]
+                    table = tables[lo:lo + q.F.shape[0]]
+                    lo += q.F.shape[0]
                     rows = slice(r * m, (r + 1) * m)
                     if table.shape[0] == 1:
                         torch.mul(x.F[rows], table, out=out[rows])

@@ -201,3 +201,20 @@ def test_q_sample_schedule_constants():
     b = linear_beta_schedule(1000, 3.5e-5, 0.007)
     acp = torch.cumprod(1 - b, 0)
     assert abs(float(torch.sqrt(1 - acp[999])) - 0.985) < 2e-3
+
+
+def test_repeat_segments_matches_repeat_interleave_autograd():
+    """The per-batch broadcast of the time embedding (minkunet.py:427-428): same forward and gradient as
+    torch.repeat_interleave, with a segmented-sum backward."""
+    from lidiff_amd.minkunet import _RepeatSegments
+    g = torch.Generator().manual_seed(0)
+    t = torch.randn(3, 5, generator=g, dtype=torch.float64, requires_grad=True)
+    counts = [4, 0, 7]
+    up = torch.randn(sum(counts), 5, generator=g, dtype=torch.float64)
+    out = _RepeatSegments.apply(t, counts)
+    ref_in = t.detach().clone().requires_grad_(True)
+    ref = torch.repeat_interleave(ref_in, torch.tensor(counts), dim=0)
+    assert torch.equal(out, ref)
+    (out * up).sum().backward()
+    (ref * up).sum().backward()
+    assert torch.allclose(t.grad, ref_in.grad, rtol=1e-12, atol=0)

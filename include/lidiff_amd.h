@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 8
+#define LIDIFF_ABI_VERSION 9
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */   /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -182,6 +182,13 @@ int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, in
 int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
                          const uint64_t* hkeys_part, const int32_t* hvals_part, int64_t cap_part, int32_t part_stride,
                          const int32_t* d_max_coord, int64_t* idx, void* stream);
+
+/* The generic brute-force arg-min behind the reference's pykeops expression (minkunet.py:412-416:
+ * ((LazyTensor(f[:,None,:]) - LazyTensor(p[None,:,:]))**2).sum(-1).argKmin(1, dim=1)): rows are float4
+ * (dimension <= 4, zero padded by the caller), idx[i] = the lowest j minimising |a_i - b_j|^2 in fp32 with the
+ * summation order of the scalar expression.  Binding target of lidiff_amd/compat's LazyTensor shim, which lets the
+ * reference's own minkunet.py run unmodified on this library. */
+int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m, int64_t* idx, void* stream);
 
 /* Farthest-point sampling -- DiffCompletion.preprocess_scan, pipeline:92-105 (open3d farthest_point_down_sample):
  * points [n,3] float64; selected[0] = 0, selected[i+1] = the point farthest (squared distance, first maximum) from

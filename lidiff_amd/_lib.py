@@ -40,6 +40,7 @@ SIGNATURES = {
     "lidiff_scatter_add_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_mul_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     "lidiff_nn_match": (_i32, [_p, _i64, _p, _i64, _p, _p, _p]),
+    "lidiff_argmin_rows_f32": (_i32, [_p, _i64, _p, _i64, _p, _p]),
     "lidiff_fps_workspace_bytes": (_i64, [_i64]),
     "lidiff_fps": (_i32, [_p, _i64, _i64, _p, _p, _p]),
     "lidiff_nn_match_grid": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
+ABI_VERSION = 9
 _lib = None
 
 
@@ -62,7 +64,7 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if lib.lidiff_abi_version() != 8:
+        if lib.lidiff_abi_version() != ABI_VERSION:
             raise RuntimeError("lidiff_amd ABI version mismatch")
         _lib = lib
     return _lib

@@ -412,12 +412,13 @@ constexpr int kMatchPt = 2;                               // full rows per lane:
 // blockIdx.y splits the part rows when the full rows alone cannot fill the chip (SPLIT): the partial winners meet
 // in idx[] through a 64-bit atomic min on (distance bits << 32 | row) -- non-negative floats order like their
 // bits, equal distances fall to the lower row -- and nn_match_finish_kernel strips the distance.
-template <bool SPLIT>
+// F32IN: the rows are float4 already (the generic pykeops-style arg-min of lidiff_argmin_rows_f32: no batch scale).
+template <bool SPLIT, bool F32IN = false>
 __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full,
                                 const int32_t* __restrict__ part, int64_t m_part, int64_t part_per_split,
                                 const int32_t* __restrict__ d_max_coord, int64_t* __restrict__ idx) {
     __shared__ float4 tile[kMatchTile];
-    const float scale = 2.0f * (float)(*d_max_coord);
+    const float scale = F32IN ? 1.0f : 2.0f * (float)(*d_max_coord);
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x * kMatchPt + threadIdx.x;   // rows i0, i0 + blockDim.x
     static_assert(kMatchPt == 2, "the two rows of a lane ride in the halves of packed-fp32 registers");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -427,8 +428,13 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
 #pragma unroll
     for (int q = 0; q < kMatchPt; ++q) {
         const int64_t i = min(i0 + (int64_t)q * blockDim.x, m_full - 1);
-        const int4 c = reinterpret_cast<const int4*>(full)[i];
-        fb[q] = (float)c.x * scale; fx[q] = (float)c.y; fy[q] = (float)c.z; fz[q] = (float)c.w;
+        if constexpr (F32IN) {
+            const float4 c = reinterpret_cast<const float4*>(full)[i];
+            fb[q] = c.x; fx[q] = c.y; fy[q] = c.z; fz[q] = c.w;
+        } else {
+            const int4 c = reinterpret_cast<const int4*>(full)[i];
+            fb[q] = (float)c.x * scale; fx[q] = (float)c.y; fy[q] = (float)c.z; fz[q] = (float)c.w;
+        }
         best[q] = INFINITY; best_j[q] = 0;
     }
     const int64_t lo = SPLIT ? (int64_t)blockIdx.y * part_per_split : 0;
@@ -437,8 +443,12 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
         const int cnt = (int)min((int64_t)kMatchTile, hi - base);
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
-            const int4 c = reinterpret_cast<const int4*>(part)[base + t];
-            tile[t] = make_float4((float)c.x * scale, (float)c.y, (float)c.z, (float)c.w);
+            if constexpr (F32IN) {
+                tile[t] = reinterpret_cast<const float4*>(part)[base + t];
+            } else {
+                const int4 c = reinterpret_cast<const int4*>(part)[base + t];
+                tile[t] = make_float4((float)c.x * scale, (float)c.y, (float)c.z, (float)c.w);
+            }
         }
         __syncthreads();
         for (int t = 0; t < cnt; ++t) {
@@ -672,6 +682,24 @@ static void nn_dist_launch(const void* a, int64_t n, const void* b, int64_t m, v
     nn_dist_merge_kernel<T><<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>(part_d2, part_idx, n, splits, (T*)d2, idx);
 }
 
+template <bool F32IN>
+static int nn_match_launch(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
+                           const int32_t* d_max_coord, int64_t* idx, hipStream_t st) {
+    const int64_t blocks = ceil_div(m_full, (int64_t)kBlock * kMatchPt);
+    const int64_t splits = min(ceil_div((int64_t)2048, blocks), ceil_div(m_part, (int64_t)kMatchTile));
+    if (splits <= 1) {
+        nn_match_kernel<false, F32IN><<<(unsigned)blocks, kBlock, 0, st>>>(full, m_full, part, m_part, 0, d_max_coord, idx);
+    } else {
+        const int64_t per = ceil_div(ceil_div(m_part, splits), (int64_t)kMatchTile) * kMatchTile;
+        LIDIFF_CHECK_HIP(hipMemsetAsync(idx, 0xff, (size_t)m_full * 8, st));
+        nn_match_kernel<true, F32IN><<<dim3((unsigned)blocks, (unsigned)splits), kBlock, 0, st>>>(
+            full, m_full, part, m_part, per, d_max_coord, idx);
+        nn_match_finish_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, st>>>(idx, m_full);
+    }
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace lidiff
 
 // =======================================================================================
@@ -843,20 +871,14 @@ int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, in
     LIDIFF_CHECK_ARG(m_part >= 1, "part tensor has no rows");
     if (m_full == 0) return 0;
     LIDIFF_CHECK_ARG(m_part < (int64_t)1 << 31, "part tensor too large for 32-bit row indices");
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t blocks = ceil_div(m_full, (int64_t)kBlock * kMatchPt);
-    const int64_t splits = min(ceil_div((int64_t)2048, blocks), ceil_div(m_part, (int64_t)kMatchTile));
-    if (splits <= 1) {
-        nn_match_kernel<false><<<(unsigned)blocks, kBlock, 0, st>>>(full, m_full, part, m_part, 0, d_max_coord, idx);
-    } else {
-        const int64_t per = ceil_div(ceil_div(m_part, splits), (int64_t)kMatchTile) * kMatchTile;
-        LIDIFF_CHECK_HIP(hipMemsetAsync(idx, 0xff, (size_t)m_full * 8, st));
-        nn_match_kernel<true><<<dim3((unsigned)blocks, (unsigned)splits), kBlock, 0, st>>>(
-            full, m_full, part, m_part, per, d_max_coord, idx);
-        nn_match_finish_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, st>>>(idx, m_full);
-    }
-    LIDIFF_CHECK_LAUNCH();
-    return 0;
+    return nn_match_launch<false>(full, m_full, part, m_part, d_max_coord, idx, (hipStream_t)stream);
+}
+
+int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m, int64_t* idx, void* stream) {
+    LIDIFF_CHECK_ARG(m >= 1 && m < (int64_t)1 << 31, "the searched rows must number 1 .. 2^31-1");
+    LIDIFF_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "rows must be 16-byte aligned float4");
+    if (n == 0) return 0;
+    return nn_match_launch<true>((const int32_t*)a, n, (const int32_t*)b, m, nullptr, idx, (hipStream_t)stream);
 }
 
 int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,

@@ -405,3 +405,16 @@ def nn_match(full_c: torch.Tensor, part_c: torch.Tensor, part_table: HashTable |
         call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord),
              ptr(idx), stream_ptr())
     return idx
+
+
+def argmin_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """idx[i] = argmin_j |a_i - b_j|^2 (fp32, lowest j on ties) for rows of dimension <= 4: the pykeops expression of
+    minkunet.py:412-416 evaluated by the HIP brute-force kernel (lidiff_argmin_rows_f32)."""
+    require_device(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1] or a.shape[1] > 4:
+        raise ValueError("argmin_rows needs [N,D] and [M,D] rows with D <= 4")
+    pad = lambda t: torch.nn.functional.pad(t.float(), (0, 4 - t.shape[1])).contiguous()
+    a4, b4 = pad(a), pad(b)
+    idx = torch.empty(a4.shape[0], dtype=torch.int64, device=a.device)
+    call("lidiff_argmin_rows_f32", ptr(a4), a4.shape[0], ptr(b4), b4.shape[0], ptr(idx), stream_ptr())
+    return idx

@@ -106,7 +106,41 @@ def make_dpm():
     np.savez_compressed(os.path.join(HERE, "dpm_trajectory.npz"), **out)
 
 
+def reference_unet_outputs():
+    """The CFG output and the refinement output of unet_small.npz computed by the REFERENCE'S OWN CODE
+    (/root/reference/lidiff/models/minkunet.py, imported unmodified by tests/ref_exec.py) over the oracle's ME / KeOps
+    stand-ins: classfree_forward of tools/diff_completion_pipeline.py:140-153 written out with the reference modules."""
+    import ref_exec
+    enc, unet, refine = build_seeded_models(42)
+    ref, mods = ref_exec.reference_minkunet("oracle")
+    ME = mods["MinkowskiEngine"]
+    r_enc, r_unet = ref.MinkGlobalEnc(in_channels=3, out_channels=96), ref.MinkUNetDiff(in_channels=3, out_channels=96)
+    r_ref = ref.MinkUNet(in_channels=3, out_channels=18)
+    r_enc.load_state_dict(enc.state_dict()), r_unet.load_state_dict(unet.state_dict()), r_ref.load_state_dict(refine.state_dict())
+    r_enc.eval(), r_unet.eval(), r_ref.eval()
+    scan, noisy = small_scene()
+
+    def field(points):
+        cpu = net.points_to_field(points)
+        return ME.TensorField(features=cpu.F, coordinates=cpu.coords_f,
+                              quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                              minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED)
+
+    with torch.no_grad():
+        t = torch.tensor([500])
+        xf = field(torch.from_numpy(noisy)[None])
+        xs = xf.sparse()
+        e_c = r_unet(xf, xs, r_enc(field(torch.from_numpy(scan)[None])), t).reshape(1, -1, 3)
+        e_u = r_unet(xf, xs, r_enc(field(torch.zeros(1, scan.shape[0], 3))), t).reshape(1, -1, 3)
+        eps = e_u + 6.0 * (e_c - e_u)
+        off = r_ref(field(torch.from_numpy(noisy)[None]))
+    return eps.numpy(), off.numpy()
+
+
 def make_unet():
+    """unet_small.npz: produced by the reference's own networks when /root/reference is mounted (and cross-checked
+    against the functional oracle), by the functional oracle otherwise."""
+    import ref_exec
     enc, unet, refine = build_seeded_models(42)
     sd = diffusion_state_dict(enc, unet)
     scan, noisy = small_scene()
@@ -115,12 +149,17 @@ def make_unet():
         cf = net.points_to_field(torch.from_numpy(scan)[None])
         uf = net.points_to_field(torch.zeros(1, scan.shape[0], 3))
         t = torch.tensor([500])
-        eps = net.classfree_forward(sd, xf, cf, uf, t, w=6.0)
+        eps = net.classfree_forward(sd, xf, cf, uf, t, w=6.0).numpy()
         rf = net.points_to_field(torch.from_numpy(noisy)[None])
-        off = net.unet_refine_forward(refine.state_dict(), rf)
-    np.savez_compressed(os.path.join(HERE, "unet_small.npz"), scan=scan, noisy=noisy, eps=eps.numpy(),
-                        refine=off.numpy())
-    print("unet eps", eps.shape, float(eps.abs().mean()), "refine", off.shape)
+        off = net.unet_refine_forward(refine.state_dict(), rf).numpy()
+    source = "oracle/minkunet_cpu.py"
+    if ref_exec.have_reference():
+        r_eps, r_off = reference_unet_outputs()
+        assert np.allclose(r_eps, eps, rtol=1e-5, atol=1e-5) and np.allclose(r_off, off, rtol=1e-5, atol=1e-5)
+        eps, off, source = r_eps, r_off, "/root/reference/lidiff/models/minkunet.py over oracle/me_shim.py"
+    np.savez_compressed(os.path.join(HERE, "unet_small.npz"), scan=scan, noisy=noisy, eps=eps, refine=off,
+                        source=np.array(source))
+    print("unet eps", eps.shape, float(np.abs(eps).mean()), "refine", off.shape, "from", source)
 
 
 if __name__ == "__main__":

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- denoising steps/sec on a 180k-point scan (BASELINE.json metric), MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]         (N > 1: spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   (the driver's form; same ranks, same line)
 
 Workload = BASELINE.json configs[1] ("single scan, T=50 DPM-Solver++ steps, fp32, 1x MI355X"):
 the reference's bundled scan (lidiff/Datasets/test/000123.ply -> range filter -> FPS 18 000,
@@ -143,6 +143,46 @@ def traffic_from_profile(variant):
     return js["traffic_bytes_per_launch"] / 1e9          # GB per launch (achieved/peak are TFLOP/s: see "traffic_unit")
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` outside a torchrun environment: re-execute under torch.distributed.run with one
+    rank per GPU on 127.0.0.1 (the form the driver uses itself) and hand its exit code back.  A box with fewer
+    visible GPUs than ranks is refused here, with a clear message, before anything is launched."""
+    import socket
+    import subprocess
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this box "
+                             f"(torch.cuda.device_count() = {have}); one rank per GPU, no oversubscription")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """The N-rank plumbing without kernels (CPU, gloo): rendezvous, one all-reduce, barrier-bracketed timing with
+    the max over ranks, one JSON line from rank 0 -- what tests/test_host.py runs in the build container."""
+    import torch.distributed as tdist
+    from lidiff_amd import dist as ldist
+    seen = int(ldist.sum_over_ranks(1.0))
+    ldist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank))                       # "steps" of unequal length: the slowest rank sets the time
+    ldist.barrier()
+    elapsed = ldist.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "denoising steps/sec on 180k-pt scan", "dry_run": True, "n_gpus": world,
+                          "rccl_ranks_seen": seen, "backend": tdist.get_backend() if world > 1 else None,
+                          "steps": args.steps, "warmup": args.warmup, "elapsed_s": elapsed,
+                          "shards": [ldist.shard_items(world, r, world) for r in range(world)]}))
+    if world > 1:
+        tdist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,17 +194,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cached-condition", action="store_true",
                     help="also time the same steps with the step-invariant conditions encoded once (reported beside the metric)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / timing plumbing only, on the CPU over gloo (no kernels): CI of the N > 1 path")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
     from lidiff_amd import dist as ldist
-    from lidiff_amd import ops
-    rank, world, local = ldist.init_from_env("nccl")
+    rank, world, local = ldist.init_from_env("gloo" if args.dry_run else "nccl")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    from lidiff_amd import ops
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    # one tiny collective over RCCL before anything is timed: every rank must be seen (the data path itself has none)
+    ranks_seen = int(ldist.sum_over_ranks(1.0, device=device))
 
     scan_np = load_scan()
     pipe = build_pipeline(device)
@@ -203,7 +253,8 @@ def main():
         return
     out = {
         "metric": "denoising steps/sec on 180k-pt scan", "value": world * args.steps / elapsed, "unit": "steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "rccl_ranks_seen": ranks_seen, "visible_devices": torch.cuda.device_count(),
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: one 180000-point scan (bundled scan FPS 18000 x10), voxel 0.05 m, "

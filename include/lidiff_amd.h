@@ -13,7 +13,8 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
  *     synchronises, nothing allocates: outputs and workspaces are caller-allocated;
  *   - coordinates are int32 rows (b, x, y, z); every column must lie in [-32768, 32767]
- *     (64-bit packed hash key, 16 bits per column); violations set bit 0 of *d_status;
+ *     (64-bit packed hash key, 16 bits per column; the single row (32767,32767,32767,32767) is reserved as
+ *     the table's empty marker and counts as out of range); violations set bit 0 of *d_status;
  *   - return value 0 = enqueued; != 0 = rejected on the host (bad argument / launch error),
  *     text available from lidiff_last_error() (thread-local);
  *   - row-major, fp32 features, int32 row indices, int64 only where torch indexing wants it.

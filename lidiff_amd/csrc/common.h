@@ -37,8 +37,9 @@ void set_error(const char* fmt, ...);
 __device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z, bool& ok) {
     const unsigned ub = (unsigned)(b + kKeyOff), ux = (unsigned)(x + kKeyOff),
                    uy = (unsigned)(y + kKeyOff), uz = (unsigned)(z + kKeyOff);
-    ok = ((ub | ux | uy | uz) >> 16) == 0;
-    return ((uint64_t)ub << 48) | ((uint64_t)ux << 32) | ((uint64_t)uy << 16) | (uint64_t)uz;
+    const uint64_t key = ((uint64_t)ub << 48) | ((uint64_t)ux << 32) | ((uint64_t)uy << 16) | (uint64_t)uz;
+    ok = ((ub | ux | uy | uz) >> 16) == 0 && key != kEmptyKey;      // (32767,32767,32767,32767) is the empty marker
+    return key;
 }
 
 // murmur3 fmix64

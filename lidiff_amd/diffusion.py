@@ -99,11 +99,12 @@ class DiffusionPoints(nn.Module):
                           "train/loss_std": loss_std.detach(), "train/loss": loss.detach()}
         return loss
 
-    # models.py:337-346
+    # models.py:337-346: Adam + ExponentialLR(gamma 0.5) that Lightning steps every 5th EPOCH
+    # ({'interval': 'epoch', 'frequency': 5}); train_loop applies the same interval / frequency.
     def configure_optimizers(self):
         optimizer = torch.optim.Adam(self.parameters(), lr=self.hparams["train"]["lr"], betas=(0.9, 0.999))
-        scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, 0.999)
-        return optimizer, scheduler
+        scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, 0.5)
+        return optimizer, {"scheduler": scheduler, "interval": "epoch", "frequency": 5}
 
 
 def chamfer_distance(pred: torch.Tensor, target: torch.Tensor):
@@ -147,32 +148,59 @@ class RefineDiffusion(nn.Module):
         return torch.optim.Adam(self.parameters(), lr=self.hparams["train"]["lr"], betas=(0.9, 0.999))
 
 
-def train_loop(module, batches, steps: int, sync_bn: bool = True, transport_dtype=None, log=None):
+def train_loop(module, batches, steps: int, sync_bn: bool = True, transport_dtype=None, log=None,
+               steps_per_epoch: int | None = None, log_every: int = 100):
     """Thin replacement of ``Trainer(gpus=n, accelerator='ddp').fit`` (train.py:88-121): per step
-    forward + backward + bucketed gradient all-reduce (RCCL) + Adam."""
+    forward + backward + bucketed gradient all-reduce (RCCL) + Adam.
+
+    `batches` is the whole (not pre-sharded) sequence of batches: like Lightning's DistributedSampler, rank r of a
+    world of W takes batch (step * W + r) mod len(batches), so the ranks see disjoint data and an epoch is
+    len(batches) // W steps (override with steps_per_epoch).  The LR scheduler follows the interval / frequency
+    that configure_optimizers returns (models.py:340-344: every 5th epoch), never per iteration.  Losses stay on
+    the device and are read back every `log_every` steps and at the end (no host sync per step)."""
     import torch.distributed as tdist
 
     from . import dist as ldist
     world = tdist.get_world_size() if tdist.is_initialized() else 1
+    rank = tdist.get_rank() if tdist.is_initialized() else 0
     if world > 1 and sync_bn:
         ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(module)
     ldist.broadcast_parameters(module)
     opt = module.configure_optimizers()
-    sched = None
+    sched, interval, frequency = None, "epoch", 1
     if isinstance(opt, tuple):
         opt, sched = opt
+    if isinstance(sched, dict):
+        sched, interval, frequency = sched["scheduler"], sched.get("interval", "epoch"), sched.get("frequency", 1)
+    if steps_per_epoch is None:
+        steps_per_epoch = max(1, len(batches) // world)
     reducer = ldist.GradAllReducer(module.parameters(), transport_dtype=transport_dtype)
     module.train()
-    losses = []
+    losses, pending = [], []
+
+    def drain():
+        if pending:
+            vals = torch.stack(pending).tolist()            # one read-back for all pending steps
+            for v in vals:
+                losses.append(v)
+                if log:
+                    log(len(losses) - 1, v)
+            pending.clear()
+
     for step in range(steps):
-        loss = module.training_step(batches[step % len(batches)], step)
+        loss = module.training_step(batches[(step * world + rank) % len(batches)], step)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         reducer.all_reduce()
         opt.step()
         if sched is not None:
-            sched.step()
-        losses.append(float(loss.detach()))
-        if log:
-            log(step, losses[-1])
+            if interval == "step":
+                if (step + 1) % frequency == 0:
+                    sched.step()
+            elif (step + 1) % steps_per_epoch == 0 and ((step + 1) // steps_per_epoch) % frequency == 0:
+                sched.step()
+        pending.append(loss.detach())
+        if len(pending) >= log_every:
+            drain()
+    drain()
     return losses

@@ -111,8 +111,16 @@ class GradAllReducer:
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
-    """Rank 0's weights and buffers to everyone (what DDP does at construction)."""
+    """Rank 0's weights and buffers to everyone (what DDP does at construction).  A collective writes its tensor
+    behind autograd's back (neither ``dist.broadcast(t)`` nor a write through ``t.data`` bumps ``t._version``, which
+    keys the packed-weight and folded-BatchNorm caches), so the received values are copied in with ``copy_`` -- an
+    ordinary in-place op -- and the derived caches are dropped explicitly on top of that."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            buf = t.detach().clone()
+            dist.broadcast(buf, src=src)
+            t.copy_(buf)
+    from .ops import invalidate_caches
+    invalidate_caches(module)

@@ -328,15 +328,12 @@ class MinkUNetDiff(_Base):
         """minkunet.py:427-428 etc.: ``repeat_interleave(t, rows per batch)`` -- rows of a coordinate map are grouped
         by ascending batch index, so the backward is one column sum per batch segment (torch's own backward of
         repeat_interleave is an index_add of M_l x C atomics into B rows: 5 ms per call at 360k rows)."""
-        cache = self.__dict__.setdefault("_segment_cache", {})
-        key = (id(x.coordinate_manager), x.tensor_stride)
-        hit = cache.get(key)
-        if hit is None or hit[0] is not x.coordinate_manager:
-            if len(cache) > 16:
-                cache.clear()
-            hit = (x.coordinate_manager, self._rows_per_batch(x).tolist())
-            cache[key] = hit
-        return _RepeatSegments.apply(t, hit[1])
+        aux = x.coordinate_manager.aux                  # lives and dies with the step's coordinate manager
+        key = ("rows_per_batch", x.tensor_stride)
+        counts = aux.get(key)
+        if counts is None:
+            counts = aux[key] = self._rows_per_batch(x).tolist()
+        return _RepeatSegments.apply(t, counts)
 
     def _condition_terms(self, name, part_feats, temp_emb):
         """The two summands of lin1(cat(latent(match), temp)) before the gather (fused plan): the row-wise MLPs run on

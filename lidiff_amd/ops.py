@@ -214,6 +214,19 @@ def packed_weights(w: torch.Tensor) -> torch.Tensor:
     return hit[1]
 
 
+def invalidate_caches(module: torch.nn.Module) -> None:
+    """Drop everything derived from a module's tensors: the packed conv weights (keyed on the Parameter's
+    data_ptr / _version) and the folded eval-BatchNorm scale / shift of the fused plan (keyed on _version).  Both
+    keys follow ordinary in-place updates (optimizer steps, load_state_dict, copy_); writes THROUGH ``.data``
+    (``p.data.mul_(...)``: an EMA, weight clipping) do not bump ``_version`` -- call this after such writes."""
+    for p in module.parameters():
+        if hasattr(p, "_lidiff_packed"):
+            del p._lidiff_packed
+    for m in module.modules():
+        if hasattr(m, "_affine_cache"):
+            del m._affine_cache
+
+
 def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
                relu: bool = False, sparse_map: bool = False, replicas: int = 1,

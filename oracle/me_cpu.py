@@ -53,7 +53,8 @@ def quantize_floor(coords_f: np.ndarray) -> np.ndarray:
 
 def in_key_range(c: np.ndarray) -> np.ndarray:
     c = np.asarray(c, dtype=np.int64)
-    return np.all((c >= -KEY_OFF) & (c < KEY_OFF), axis=1)
+    # the row whose packed key is all ones is the device table's empty marker: out of range by definition
+    return np.all((c >= -KEY_OFF) & (c < KEY_OFF), axis=1) & ~np.all(c == KEY_OFF - 1, axis=1)
 
 
 def pack_keys(c: np.ndarray) -> np.ndarray:

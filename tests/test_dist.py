@@ -26,7 +26,13 @@ def _worker(rank, world, port, result_q):
     # data-parallel step: same init everywhere after broadcast, different data per rank
     torch.manual_seed(100 + rank)
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    model(torch.zeros(1, 6))                                       # a forward BEFORE the broadcast ...
+    model[0].weight._lidiff_packed = ("stale",)                     # ... leaves derived caches behind
+    model[1]._affine_cache = ("stale",)
+    v0 = model[0].weight._version
     ldist.broadcast_parameters(model)
+    out["caches_dropped"] = not hasattr(model[0].weight, "_lidiff_packed") and not hasattr(model[1], "_affine_cache")
+    out["version_bumped"] = model[0].weight._version > v0
     out["w0"] = model[0].weight.detach().clone()
     x = torch.randn(4, 6)
     model(x).pow(2).sum().backward()
@@ -41,6 +47,30 @@ def _worker(rank, world, port, result_q):
     model(x).pow(2).sum().backward()
     ldist.GradAllReducer(model.parameters(), transport_dtype=torch.bfloat16).all_reduce()
     out["avg_bf16"] = [p.grad.clone() for p in model.parameters()]
+    # train_loop: rank r takes batch (step * world + r) mod len -- disjoint data per rank (DistributedSampler), the
+    # LR follows Lightning's {'interval': 'epoch', 'frequency': 5} (models.py:340-344), losses are read back lazily
+    from lidiff_amd.diffusion import train_loop
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3, 1)
+            self.seen = []
+
+        def training_step(self, batch, idx):
+            self.seen.append(int(batch["id"]))
+            return self.lin(batch["x"]).pow(2).mean()
+
+        def configure_optimizers(self):
+            opt = torch.optim.SGD(self.parameters(), lr=1e-3)
+            return opt, {"scheduler": torch.optim.lr_scheduler.ExponentialLR(opt, 0.5), "interval": "epoch", "frequency": 5}
+
+    toy = Toy()
+    data = [{"id": i, "x": torch.full((2, 3), float(i))} for i in range(8)]
+    losses = train_loop(toy, data, steps=40, sync_bn=False, log_every=16)     # 8 batches / 2 ranks = 4 steps per epoch
+    out["seen"] = toy.seen[:6]
+    out["n_losses"] = len(losses)
+    out["toy_w"] = toy.lin.weight.detach().clone()
     ldist.barrier()
     plain = lambda v: v.tolist() if isinstance(v, torch.Tensor) else ([plain(e) for e in v] if isinstance(v, list) else v)
     result_q.put((rank, {k: plain(v) for k, v in out.items()}))   # plain lists: no shared-memory handles
@@ -63,6 +93,9 @@ def test_two_rank_gloo():
     for r in range(world):
         assert results[r]["max"] == 2.0 and results[r]["sum"] == 30.0
         assert results[r]["w0"] == results[0]["w0"]
+        assert results[r]["caches_dropped"] and results[r]["version_bumped"]
+        assert results[r]["seen"] == [(s * 2 + r) % 8 for s in range(6)] and results[r]["n_losses"] == 40
+        assert results[r]["toy_w"] == results[0]["toy_w"]                    # averaged gradients: ranks stay in step
         for got, want, got16 in zip(results[r]["avg"], results[r]["want"], results[r]["avg_bf16"]):
             assert torch.allclose(torch.tensor(got), torch.tensor(want), atol=1e-6)
             assert torch.allclose(torch.tensor(got16), torch.tensor(want), rtol=2e-2, atol=2e-2)
@@ -78,3 +111,32 @@ def test_single_process_is_a_noop():
     g = m.weight.grad.clone()
     ldist.GradAllReducer(m.parameters()).all_reduce()
     assert torch.equal(m.weight.grad, g)
+
+
+def test_lr_schedule_follows_the_reference_interval():
+    """models.py:337-346: ExponentialLR(0.5) stepped every 5th epoch -- not per iteration."""
+    from lidiff_amd.diffusion import DiffusionPoints, train_loop
+    opt, sched = DiffusionPoints.configure_optimizers(
+        type("M", (), {"parameters": lambda self: [torch.nn.Parameter(torch.zeros(1))],
+                       "hparams": {"train": {"lr": 1e-4}}})())
+    assert sched["interval"] == "epoch" and sched["frequency"] == 5 and sched["scheduler"].gamma == 0.5
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(2, 1)
+            self.lrs = []
+
+        def training_step(self, batch, idx):
+            self.lrs.append(self.opt.param_groups[0]["lr"])
+            return self.lin(batch).pow(2).mean()
+
+        def configure_optimizers(self):
+            self.opt = torch.optim.Adam(self.parameters(), lr=1e-4)
+            return self.opt, {"scheduler": torch.optim.lr_scheduler.ExponentialLR(self.opt, 0.5), "interval": "epoch",
+                              "frequency": 5}
+
+    toy = Toy()
+    train_loop(toy, [torch.ones(1, 2)] * 3, steps=3 * 11)                    # 11 epochs of 3 steps
+    assert toy.lrs[:15] == [1e-4] * 15                                       # epochs 1-5 untouched
+    assert toy.lrs[15] == 0.5e-4 and toy.lrs[29] == 0.5e-4 and toy.lrs[30] == 0.25e-4

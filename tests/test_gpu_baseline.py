@@ -1,0 +1,222 @@
+"""GPU parity at BASELINE.json's own configuration (pytest -m gpu): the workload bench.py times -- the bundled scan
+(FPS 18 000, tiled x10 = 180 000 points) plus sigma * N(0, I), voxel 0.05 m -- checked against the CPU oracle, not
+only through size-independent properties:
+
+  (a) coordinate maps at sigma in {1.0, 0.2, 0.05}: unique voxels / inverse / first index, the four strided maps and
+      parents, ks3 / ks2 / transposed neighbour tables and the ME-layout rulebook -- BIT-EXACT;
+  (b) one sparse convolution per (level x channel pair) the networks really run on those maps, with the sparse-map
+      hint the host really passes (the packed-stage / KS = 64 / 16-bit-list kernel variants that the real sparsity
+      selects), against the oracle in float64 -- rtol / atol 1e-4;
+  (c) BASELINE configs[0] (C1): ONE classifier-free-guided denoising step (timesteps = [999]) on the 180 000-point
+      scan against oracle/minkunet_cpu.py -- rtol 1e-3 / atol 2e-3 for every point;
+  (d) a T = 50 trajectory on a small scene with both sides starting every step from the SAME points (teacher
+      forcing), so that voxel-boundary flips cannot hide real error: every point of every step within tolerance.
+
+The oracle legs of (b), (c) take a few minutes of host CPU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_seeded_models, diffusion_state_dict, noisy_scan_points, small_scene
+from oracle import me_cpu as me
+from oracle import minkunet_cpu as net
+from oracle.dpm_solver import DpmSolverSdeOracle
+from test_gpu_kernels import check_maps, dev_i32
+from test_gpu_network import NET_ATOL, NET_RTOL, to_field
+
+pytestmark = pytest.mark.gpu
+
+RES = 0.05
+
+
+def scan_coords(fps_scan, sigma, seed=0):
+    """int32 [180000, 4] voxel coordinates of the noisy scan, rounded on the CPU as the oracle does (App. E)."""
+    pts = noisy_scan_points(fps_scan, sigma, seed)
+    c = torch.round(torch.from_numpy(pts) / RES).to(torch.int32).numpy()
+    return np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], axis=1)
+
+
+# ---------------------------------------------------------------------------------------- (a)
+@pytest.mark.parametrize("sigma", [1.0, 0.2, 0.05])
+def test_maps_bit_exact_on_the_bench_scan(device, fps_scan, sigma):
+    from lidiff_amd import ops
+    coords = scan_coords(fps_scan, sigma)
+    nbr3 = check_maps(coords, device)           # unique / inverse / first, 4 strided maps, parents, all tables
+    uniq, _, _ = me.voxelize(coords)
+    assert 160000 < uniq.shape[0] <= 180000
+    pin, pout, ptr = ops.rulebook_compact(nbr3)
+    o_in, o_out, o_ptr = me.rulebook_from_nbr(nbr3.cpu().numpy())
+    assert np.array_equal(ptr.cpu().numpy(), o_ptr)
+    assert np.array_equal(pin.cpu().numpy(), o_in) and np.array_equal(pout.cpu().numpy(), o_out)
+
+
+# ---------------------------------------------------------------------------------------- (b)
+# (level, kind, c_in, c_out, split of c_in for a fused ME.cat | 0): the convolutions of MinkUNetDiff / MinkGlobalEnc /
+# MinkUNet (minkunet.py:155-368) per level; level l = tensor stride 2^l
+LAYERS = [
+    (0, "k3", 3, 32, 0), (0, "k3", 32, 32, 0), (0, "down", 32, 32, 0),
+    (1, "k3", 32, 32, 0), (1, "k3", 32, 64, 0), (1, "down", 32, 32, 0), (1, "k1", 32, 64, 0),
+    (2, "k3", 64, 64, 0), (2, "k3", 64, 128, 0), (2, "down", 64, 64, 0),
+    (3, "k3", 128, 128, 0), (3, "k3", 128, 256, 0), (3, "k3", 256, 256, 0), (3, "down", 128, 128, 0),
+    (4, "k3", 256, 256, 0),
+    (3, "up", 256, 256, 0), (3, "k3", 384, 256, 256), (3, "k1", 384, 256, 256),
+    (2, "up", 256, 128, 0), (2, "k3", 192, 128, 128), (2, "k3", 128, 128, 0),
+    (1, "up", 128, 96, 0), (1, "k3", 128, 96, 96), (1, "k3", 96, 96, 0), (1, "k1", 128, 96, 96),
+    (0, "up", 96, 96, 0), (0, "k3", 128, 96, 96), (0, "k3", 96, 96, 0),
+]
+
+
+class SceneMaps:
+    """Coordinate maps of one noisy scan on the device (product manager: its own sparse-map hints) and on the CPU."""
+
+    def __init__(self, fps_scan, sigma, device):
+        import lidiff_amd.MinkowskiEngine as ME
+        coords = scan_coords(fps_scan, sigma)
+        field = ME.TensorField(features=torch.zeros(coords.shape[0], 3, device=device),
+                               coordinates=dev_i32(coords, device), device=device)
+        field.sparse()
+        self.mgr = field.coordinate_manager
+        ts = 1
+        for _ in range(4):
+            ts = self.mgr.stride(ts, 2)
+        self.mgr.check()
+
+    def table(self, level, kind):
+        """(nbr on the device, m_in, m_out, sparse hint) exactly as _ConvBase.maps / sparse_hint produce them."""
+        mgr, ts = self.mgr, 1 << level
+        m = lambda t: mgr.maps[t].coords.shape[0]
+        if kind == "k3":
+            return mgr.kernel_map(ts, ts, 3), m(ts), m(ts), mgr.is_sparse_map(ts, ts, 3)
+        if kind == "down":
+            return mgr.kernel_map(ts, 2 * ts, 2), m(ts), m(2 * ts), mgr.is_sparse_map(ts, 2 * ts, 2)
+        if kind == "up":
+            return mgr.kernel_map(2 * ts, ts, 2, True), m(2 * ts), m(ts), mgr.is_sparse_map(2 * ts, ts, 2, True)
+        return None, m(ts), m(ts), False
+
+
+@pytest.fixture(scope="module")
+def scenes(device, fps_scan):
+    cache = {}
+
+    def get(sigma):
+        if sigma not in cache:
+            cache[sigma] = SceneMaps(fps_scan, sigma, device)
+        return cache[sigma]
+    return get
+
+
+def _layer_case(device, scene, level, kind, cin, cout, split, replicas=1):
+    from lidiff_amd import ops
+    nbr, m_in, m_out, hint = scene.table(level, kind)
+    g = torch.Generator().manual_seed(1000 * level + cin + cout)
+    k = 1 if nbr is None else nbr.shape[0]
+    x = torch.randn(replicas * m_in, cin, generator=g)
+    w = torch.randn(k, cin, cout, generator=g) / np.sqrt(cin * max(1, k // 3))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn(replicas * m_out, cout, generator=g)
+    nbr_np = None if nbr is None else nbr.cpu().numpy()
+    xd = x.to(device)
+    got = ops.spconv_fwd(xd[:, :split].contiguous() if split else xd, w.to(device), nbr, m_out,
+                         in_b=xd[:, split:].contiguous() if split else None, scale=scale.to(device),
+                         shift=shift.to(device), residual=res.to(device), relu=True, sparse_map=hint,
+                         replicas=replicas).cpu().double()
+    for r in range(replicas):
+        want = me.conv_forward(x[r * m_in:(r + 1) * m_in].double(), (w if k > 1 else w[0]).double(), nbr_np)
+        want = torch.relu(want * scale.double() + shift.double() + res[r * m_out:(r + 1) * m_out].double())
+        err = (got[r * m_out:(r + 1) * m_out] - want).abs().max().item()
+        assert torch.allclose(got[r * m_out:(r + 1) * m_out], want, rtol=1e-4, atol=1e-4), \
+            f"level {level} {kind} {cin}->{cout} hint={hint} replica {r}: max err {err}"
+    return hint
+
+
+@pytest.mark.parametrize("level,kind,cin,cout,split", LAYERS)
+def test_every_network_conv_on_the_bench_maps_sigma1(device, scenes, level, kind, cin, cout, split):
+    _layer_case(device, scenes(1.0), level, kind, cin, cout, split)
+
+
+@pytest.mark.parametrize("sigma", [0.2, 0.05])
+@pytest.mark.parametrize("level,kind,cin,cout,split", [
+    (0, "k3", 32, 32, 0), (0, "k3", 128, 96, 96), (1, "k3", 96, 96, 0), (1, "k3", 32, 64, 0), (2, "k3", 128, 128, 0),
+    (2, "k3", 192, 128, 128), (3, "k3", 256, 256, 0), (4, "k3", 256, 256, 0), (1, "up", 128, 96, 0), (0, "down", 32, 32, 0)])
+def test_network_convs_on_the_bench_maps_late_trajectory(device, scenes, sigma, level, kind, cin, cout, split):
+    """The same layers where the sparsity regime differs from sigma = 1 (stride 1 gets dense, stride 8/16 small)."""
+    _layer_case(device, scenes(sigma), level, kind, cin, cout, split)
+
+
+def test_cfg_pair_replicas_on_the_bench_maps(device, scenes):
+    """The stacked conditional / unconditional pair (two replicas per launch) as bench.py runs every conv."""
+    for level, kind, cin, cout, split in [(3, "k3", 256, 256, 0), (0, "k3", 96, 96, 0), (1, "k3", 128, 96, 96),
+                                          (2, "down", 64, 64, 0)]:
+        _layer_case(device, scenes(1.0), level, kind, cin, cout, split, replicas=2)
+
+
+def test_sparse_hint_covers_both_kernel_families(device, scenes):
+    """The hint really changes along the trajectory (so both the dense and the packed-stage kernels are exercised
+    above with the host's own decision)."""
+    hints = {(s, l): scenes(s).table(l, "k3")[3] for s in (1.0, 0.05) for l in (0, 3)}
+    assert hints[(1.0, 0)] and not hints[(1.0, 3)] and not hints[(0.05, 0)]
+
+
+# ---------------------------------------------------------------------------------------- (c)
+def test_c1_one_denoising_step_on_the_180k_scan_vs_oracle(device, fps_scan):
+    """BASELINE configs[0]: T = 1 (timesteps = [999]) classifier-free-guided forward on the 180 000-point scan."""
+    from lidiff_amd.pipeline import DiffCompletion
+    enc, unet, refine = build_seeded_models(42)
+    sd = diffusion_state_dict(enc, unet)
+    pipe = DiffCompletion(denoising_steps=1, cond_weight=6.0, device=device)
+    pipe.partial_enc, pipe.model = enc.to(device), unet.to(device)
+    assert pipe.dpm_scheduler.host_timesteps == [999]
+    scan = np.tile(fps_scan.astype(np.float32), (10, 1))
+    noisy = noisy_scan_points(fps_scan, 1.0, 0)
+    t = torch.tensor([999])
+    with torch.no_grad():
+        got = pipe.classfree_forward(to_field(noisy, device), to_field(scan, device),
+                                     to_field(np.zeros_like(scan), device), t.to(device)).cpu()
+        want = net.classfree_forward(sd, net.points_to_field(torch.from_numpy(noisy)[None]),
+                                     net.points_to_field(torch.from_numpy(scan)[None]),
+                                     net.points_to_field(torch.zeros(1, scan.shape[0], 3)), t, w=6.0)
+    assert got.shape == want.shape == (1, 180000, 3)
+    err = (got - want).abs()
+    assert torch.allclose(got, want, rtol=NET_RTOL, atol=NET_ATOL), (err.max().item(), err.mean().item())
+
+
+# ---------------------------------------------------------------------------------------- (d)
+def test_t50_trajectory_teacher_forced_every_point(device):
+    """completion_loop (pipeline:155-169), all 50 steps of the sde-dpmsolver++ trajectory on a 2 000-point scene.
+    Both sides start step i from the oracle's points of step i - 1 (identical voxel coordinates), so the comparison
+    is free of voxel-boundary flips and holds for 100 % of the points at every step."""
+    from lidiff_amd.pipeline import DiffCompletion
+    enc, unet, refine = build_seeded_models(42)
+    sd = diffusion_state_dict(enc, unet)
+    pipe = DiffCompletion(denoising_steps=50, cond_weight=6.0, device=device)
+    pipe.partial_enc, pipe.model = enc.to(device), unet.to(device)
+    scan_np, noisy_np = small_scene(seed=21, n=2000)
+    rng = np.random.default_rng(4)
+    o = DpmSolverSdeOracle()
+    ts = o.set_timesteps(50)
+    assert pipe.dpm_scheduler.host_timesteps == [int(t) for t in ts] and len(ts) == 50
+    x_init = scan_np.astype(np.float64)[None]
+    x = noisy_np.astype(np.float64)[None]
+    scan_d = torch.from_numpy(x_init).to(device)
+    cond_o = net.points_to_field(torch.from_numpy(scan_np)[None])
+    zero_o = net.points_to_field(torch.zeros(1, scan_np.shape[0], 3))
+    worst_eps = worst_x = 0.0
+    with torch.no_grad():
+        for i, t in enumerate(ts):
+            z = rng.standard_normal(x.shape)
+            xf = net.points_to_field(torch.from_numpy(x).float())
+            eps_o = net.classfree_forward(sd, xf, cond_o, zero_o, torch.tensor([int(t)]), w=6.0)
+            x_next = x_init + o.step(eps_o.numpy(), int(t), xf.F.numpy().reshape(1, -1, 3) - x_init, z)
+            x_t = to_field(x.astype(np.float32)[0], device)                     # the SAME points, CPU-rounded coords
+            eps_d = pipe.classfree_forward(x_t, to_field(scan_np, device), to_field(np.zeros_like(scan_np), device),
+                                           torch.tensor([int(t)], device=device))
+            assert torch.allclose(eps_d.cpu(), eps_o, rtol=NET_RTOL, atol=NET_ATOL), (i, (eps_d.cpu() - eps_o).abs().max())
+            x_dev = scan_d + pipe.dpm_scheduler.step(eps_d, int(t), x_t.F.reshape(1, -1, 3) - scan_d,
+                                                     noise=torch.from_numpy(z).to(device))["prev_sample"]
+            dx = np.abs(x_dev.cpu().numpy() - x_next).max()
+            worst_eps = max(worst_eps, (eps_d.cpu() - eps_o).abs().max().item())
+            worst_x = max(worst_x, dx)
+            assert dx < 5e-3, (i, dx)                                            # every point, metres
+            x = x_next                                                           # teacher forcing
+    print(f"T=50 teacher-forced: worst |eps| error {worst_eps:.2e}, worst |x| error {worst_x:.2e} m")

@@ -218,3 +218,27 @@ def test_repeat_segments_matches_repeat_interleave_autograd():
     (out * up).sum().backward()
     (ref * up).sum().backward()
     assert torch.allclose(t.grad, ref_in.grad, rtol=1e-12, atol=0)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with WORLD_SIZE unset (how the driver starts the N = 1 line, and how a SCALE run in
+    the same form would start N > 1) spawns N ranks itself: the --dry-run leg runs the launcher, the rendezvous on
+    127.0.0.1, one all-reduce and the barrier / max-over-ranks timing on the CPU over gloo.  Without GPUs the real
+    run is refused with a clear message instead of a stack trace."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # ONE line, from rank 0
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["rccl_ranks_seen"] == 2 and js["dry_run"] and js["shards"] == [[0], [1]]
+    assert js["elapsed_s"] >= 0.02                                # the max over ranks (rank 1 sleeps 20 ms)
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "only 0 GPU(s) visible" in r.stderr

@@ -6,6 +6,7 @@ container, where /root/reference exists):
 The reference ships no golden vectors and none of its native dependencies can be imported
 (SURVEY.md 4, 8c), so these vectors come from the CPU oracle under oracle/ -- PARITY UNPINNED.
 They pin the oracle against regressions and give the GPU parity tests fixed inputs/outputs.
+  scan_000123_range_filtered.npy : bundled scan -> 3.5 m < |p| < 50 m, float32 [119035,3] (exact)
   scan_000123_fps18000.npy : bundled scan lidiff/Datasets/test/000123.ply -> 3.5 m < |p| < 50 m
                              -> greedy farthest-point sampling of 18 000 points (index 0 first),
                              float32 [18000,3]  (the preprocessing of pipeline:92-99)
@@ -44,11 +45,14 @@ def fps_numpy(pts, n):
 
 
 def make_scan():
+    """The bundled scan through preprocess_scan (pipeline:92-99): range filter (119 035 points, committed as
+    scan_000123_range_filtered.npy -- the file's float64 values are exactly float32) and FPS to 18 000."""
     from lidiff_amd.pipeline import read_ply_points
-    pts = read_ply_points("/root/reference/lidiff/Datasets/test/000123.ply")
-    d = np.sqrt((pts ** 2).sum(-1))
-    pts = pts[(d < 50.0) & (d > 3.5)]
-    keep = fps_numpy(pts, 18000)
+    from oracle.fps_cpu import farthest_point_sample, range_filter
+    pts = range_filter(read_ply_points("/root/reference/lidiff/Datasets/test/000123.ply"))
+    assert np.array_equal(pts.astype(np.float32).astype(np.float64), pts)
+    np.save(os.path.join(HERE, "scan_000123_range_filtered.npy"), pts.astype(np.float32))
+    keep = farthest_point_sample(pts, 18000)
     np.save(os.path.join(HERE, "scan_000123_fps18000.npy"), pts[keep].astype(np.float32))
     print("scan:", pts.shape, "->", keep.shape)
 

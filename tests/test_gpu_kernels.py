@@ -407,3 +407,44 @@ def test_nn_match(device):
     f = np.array([[0, 0, 0, 0]], np.int32)                             # exact tie -> lowest index
     p = np.array([[0, 2, 0, 0], [0, -2, 0, 0], [0, 0, 2, 0]], np.int32)
     assert ops.nn_match(dev_i32(f, device), dev_i32(p, device)).item() == 0
+
+
+def test_fps_reproduces_the_committed_scan_from_the_range_filtered_input(device, fps_scan):
+    """preprocess_scan's FPS (pipeline:97-99) on the range-filtered bundled scan (119 035 points)
+    through the HIP kernel selects exactly the committed 18 000 points, in order; spot-checked against the FPS oracle."""
+    from lidiff_amd import ops
+    from oracle.fps_cpu import farthest_point_sample as fps_oracle
+    pts = np.load(os.path.join(GOLDEN, "scan_000123_range_filtered.npy")).astype(np.float64)
+    sel = ops.farthest_point_sample(torch.from_numpy(pts).to(device), 18000).cpu().numpy()
+    assert np.array_equal(pts[sel].astype(np.float32), fps_scan)
+    assert np.array_equal(sel[:300], fps_oracle(pts, 300))
+
+
+def test_sparse_quantize_vs_oracle(device):
+    """ME.utils.sparse_quantize (map_from_scans.py:91: float64 world coordinates / 0.1 m; SemanticKITTITemporalAggr.py:87):
+    unique voxels in first-occurrence order, kept-row index, inverse map; numpy in -> numpy out, torch in -> torch out;
+    floor in the SOURCE dtype (a float32 detour changes voxels at map scale)."""
+    import lidiff_amd.MinkowskiEngine as ME
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-400.0, 400.0, size=(50000, 3))                       # metres, float64, map scale
+    pts[1000:2000] = pts[:1000] + 1e-9                                      # duplicates inside a voxel
+    q = 0.1
+    k = np.arange(3000)
+    pts[5000:8000, 0] = (k - 1500) * q - 1e-12                              # just BELOW voxel boundaries: float32 would
+    c_want = np.floor(pts / q).astype(np.int32)                             # round them up into the next voxel
+    assert (np.floor((pts / q).astype(np.float32)).astype(np.int32) != c_want).any()
+    uniq_o, inv_o, first_o = me.voxelize(np.concatenate([np.zeros((len(pts), 1), np.int32), c_want], 1))
+    coords, index, inverse = ME.utils.sparse_quantize(pts, return_index=True, return_inverse=True, quantization_size=q)
+    assert isinstance(coords, np.ndarray) and coords.dtype == np.int32
+    assert np.array_equal(coords, uniq_o[:, 1:]) and np.array_equal(index, first_o) and np.array_equal(inverse, inv_o)
+    # already-quantised integer coordinates, torch in -> torch out, features follow the kept rows
+    ci = torch.from_numpy(c_want[:4000])
+    feats = torch.arange(4000, dtype=torch.float32)[:, None]
+    c2, f2, i2 = ME.utils.sparse_quantize(ci, features=feats, return_index=True)
+    u2, _, first2 = me.voxelize(np.concatenate([np.zeros((4000, 1), np.int32), c_want[:4000]], 1))
+    assert torch.is_tensor(c2) and np.array_equal(c2.cpu().numpy(), u2[:, 1:])
+    assert np.array_equal(i2.cpu().numpy(), first2) and np.array_equal(f2.cpu().numpy()[:, 0], first2.astype(np.float32))
+    only = ME.utils.sparse_quantize(pts[:100], quantization_size=q)
+    assert isinstance(only, np.ndarray) and only.shape[1] == 3
+    with pytest.raises(RuntimeError):
+        ME.utils.sparse_quantize(np.array([[0.0, 0.0, 40000.0]]))

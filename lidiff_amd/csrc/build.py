@@ -12,8 +12,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["coords.hip", "spconv.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "lidiff_amd.h")]
+SOURCES = ["coords.hip", "spconv.hip", "spconv_dense.hip"]
+HEADERS = ["common.h", "spconv.h", os.path.join("..", "..", "include", "lidiff_amd.h")]
 LIB = os.path.join(HERE, "liblidiff_amd.so")
 ARCH = "gfx950"
 

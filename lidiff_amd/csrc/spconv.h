@@ -1,0 +1,50 @@
+// Shared declarations of the sparse-convolution kernels (spconv.hip: tile kernels for every shape;
+// spconv_dense.hip: the one-wave-per-SIMD kernel of the dense 128-column layers).
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+namespace lidiff {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int kChunk = 128;   // pair rows per stage
+constexpr int kWorkInts = 27 * 8 + 8;   // work list capacity: 27 offsets x up to 8 segments of 16 rows
+
+struct ConvParams {
+    const float* in_a;
+    const float* in_b;
+    const float* wp;          // packed weights (lidiff_spconv_pack_weights)
+    const int32_t* nbr;
+    const int32_t* row_order;   // nullable: tile rows -> output rows
+    float* out;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    int64_t m_in, m_out;
+    int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
+    int tiles_m, tiles_n, flags, replicas;
+    int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
+                              // 2 = no barrier, 4 = no flush
+    long long* timeline;      // LIDIFF_CONV_PROBE builds only: 8 cycle counters per workgroup (tools/conv_probe.py)
+};
+
+#ifdef LIDIFF_CONV_PROBE
+#define PROBE(bit) (p.probe & (bit))
+#define STAMP(var) const long long var = __builtin_readcyclecounter()
+#else
+#define PROBE(bit) false
+#define STAMP(var)
+#endif
+
+
+template <int I>
+using ic = std::integral_constant<int, I>;
+
+// spconv_dense.hip: can this convolution take the dense kernel / launch it.
+bool dense_kernel_applies(const ConvParams& p);
+int launch_fwd_dense(const ConvParams& p, hipStream_t st);
+
+}  // namespace lidiff

@@ -34,43 +34,9 @@
 #include <type_traits>
 
 #include "common.h"
+#include "spconv.h"
 
 namespace lidiff {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-constexpr int kChunk = 128;   // pair rows per stage
-constexpr int kWorkInts = 27 * 8 + 8;   // work list capacity: 27 offsets x up to 8 segments of 16 rows
-
-struct ConvParams {
-    const float* in_a;
-    const float* in_b;
-    const float* wp;          // packed weights (lidiff_spconv_pack_weights)
-    const int32_t* nbr;
-    const int32_t* row_order;   // nullable: tile rows -> output rows
-    float* out;
-    const float* scale;
-    const float* shift;
-    const float* residual;
-    int64_t m_in, m_out;
-    int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
-    int tiles_m, tiles_n, flags, replicas;
-    int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
-                              // 2 = no barrier, 4 = no flush
-    long long* timeline;      // LIDIFF_CONV_PROBE builds only: 8 cycle counters per workgroup (tools/conv_probe.py)
-};
-
-#ifdef LIDIFF_CONV_PROBE
-#define PROBE(bit) (p.probe & (bit))
-#define STAMP(var) const long long var = __builtin_readcyclecounter()
-#else
-#define PROBE(bit) false
-#define STAMP(var)
-#endif
-
-template <int I>
-using ic = std::integral_constant<int, I>;
 
 template <int BM, int WN, int WM, int KS>
 struct ConvCfg {
@@ -749,6 +715,9 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % 32 == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
     const bool vec = c_in_a % 32 == 0 && c_in_b % 32 == 0 && al16(in_a) && al16(in_b);   // else: scalar gather
     hipStream_t st = (hipStream_t)stream;
+    // dense 128-column layers: the one-wave-per-SIMD pipelined kernel (spconv_dense.hip), unless the caller pins the
+    // tile kernels below (A/B measurements; the results are bit-identical)
+    if (!(flags & LIDIFF_CONV_TILE_KERNEL) && dense_kernel_applies(p)) return launch_fwd_dense(p, st);
     if (c_out % 128 == 0) return dispatch_fwd<128, 8, 1>(p, vec, st);
     if (c_out % 96 == 0) {
         // low-density maps: two 48-column tiles of 3 x 2 waves -- their packed stages hold 8 offsets (own W

@@ -84,3 +84,36 @@ def diffusion_state_dict(enc, unet):
     sd = {"partial_enc." + k: v for k, v in enc.state_dict().items()}
     sd.update({"model." + k: v for k, v in unet.state_dict().items()})
     return sd
+
+
+def oracle_cached(name: str, key_arrays, compute):
+    """Memo of an expensive ORACLE result (a dict of numpy arrays) under tests/.oracle_cache/ (git-ignored, it does
+    travel to the GPU box with the snapshot): keyed on the oracle's source files and the exact input bytes, so a hit
+    is the value the oracle would compute.  Absent / stale cache -> computed in place (the driver's fresh boxes).
+    Only slow whole-network oracle legs use it; it saves GPU-box minutes, it never replaces the comparison."""
+    import glob
+    import hashlib
+    h = hashlib.sha1(name.encode())
+    for src in sorted(glob.glob(os.path.join(ROOT, "oracle", "*.py"))):
+        h.update(open(src, "rb").read())
+    for a in key_arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode() + a.tobytes())
+    path = os.path.join(ROOT, "tests", ".oracle_cache", f"{name}_{h.hexdigest()[:20]}.npz")
+    if os.path.exists(path):
+        with np.load(path) as z:
+            return {k: z[k] for k in z.files}
+    out = compute()
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        np.savez(path + ".tmp.npz", **out)
+        os.replace(path + ".tmp.npz", path)
+    except OSError:
+        pass
+    return out
+
+
+def state_dict_arrays(sd):
+    """A few weight tensors as cache-key material (seeded models: the seed decides all of them)."""
+    keys = sorted(sd.keys())
+    return [sd[k].detach().cpu().numpy() for k in (keys[0], keys[len(keys) // 2], keys[-1])]

@@ -18,7 +18,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import build_seeded_models, diffusion_state_dict, noisy_scan_points, small_scene
+from conftest import (build_seeded_models, diffusion_state_dict, noisy_scan_points, oracle_cached, small_scene,
+                      state_dict_arrays)
 from oracle import me_cpu as me
 from oracle import minkunet_cpu as net
 from oracle.dpm_solver import DpmSolverSdeOracle
@@ -121,8 +122,12 @@ def _layer_case(device, scene, level, kind, cin, cout, split, replicas=1):
                          in_b=xd[:, split:].contiguous() if split else None, scale=scale.to(device),
                          shift=shift.to(device), residual=res.to(device), relu=True, sparse_map=hint,
                          replicas=replicas).cpu().double()
+    # oracle in float64; the heaviest layers (> 5e10 multiply-adds: seconds of host time each) in float32 -- its own
+    # rounding (~1e-6 relative) is far inside the tolerance
+    pairs = m_out if nbr_np is None else int((nbr_np >= 0).sum())
+    odt = torch.float64 if float(pairs) * cin * cout < 5e10 else torch.float32
     for r in range(replicas):
-        want = me.conv_forward(x[r * m_in:(r + 1) * m_in].double(), (w if k > 1 else w[0]).double(), nbr_np)
+        want = me.conv_forward(x[r * m_in:(r + 1) * m_in].to(odt), (w if k > 1 else w[0]).to(odt), nbr_np).double()
         want = torch.relu(want * scale.double() + shift.double() + res[r * m_out:(r + 1) * m_out].double())
         err = (got[r * m_out:(r + 1) * m_out] - want).abs().max().item()
         assert torch.allclose(got[r * m_out:(r + 1) * m_out], want, rtol=1e-4, atol=1e-4), \
@@ -159,64 +164,96 @@ def test_sparse_hint_covers_both_kernel_families(device, scenes):
 
 
 # ---------------------------------------------------------------------------------------- (c)
+def c1_inputs(fps_scan):
+    scan = np.tile(fps_scan.astype(np.float32), (10, 1))
+    return scan, noisy_scan_points(fps_scan, 1.0, 0)
+
+
+def c1_oracle(fps_scan):
+    """eps [1, 180000, 3] of the oracle for C1 (memoised: tests/conftest.py oracle_cached; tools/warm_oracle_cache.py)."""
+    enc, unet, _ = build_seeded_models(42)
+    sd = diffusion_state_dict(enc, unet)
+    scan, noisy = c1_inputs(fps_scan)
+
+    def compute():
+        with torch.no_grad():
+            return {"eps": net.classfree_forward(sd, net.points_to_field(torch.from_numpy(noisy)[None]),
+                                                 net.points_to_field(torch.from_numpy(scan)[None]),
+                                                 net.points_to_field(torch.zeros(1, scan.shape[0], 3)),
+                                                 torch.tensor([999]), w=6.0).numpy()}
+    return torch.from_numpy(oracle_cached("c1_t999", [noisy, scan] + state_dict_arrays(sd), compute)["eps"])
+
+
 def test_c1_one_denoising_step_on_the_180k_scan_vs_oracle(device, fps_scan):
     """BASELINE configs[0]: T = 1 (timesteps = [999]) classifier-free-guided forward on the 180 000-point scan."""
     from lidiff_amd.pipeline import DiffCompletion
     enc, unet, refine = build_seeded_models(42)
-    sd = diffusion_state_dict(enc, unet)
     pipe = DiffCompletion(denoising_steps=1, cond_weight=6.0, device=device)
     pipe.partial_enc, pipe.model = enc.to(device), unet.to(device)
     assert pipe.dpm_scheduler.host_timesteps == [999]
-    scan = np.tile(fps_scan.astype(np.float32), (10, 1))
-    noisy = noisy_scan_points(fps_scan, 1.0, 0)
-    t = torch.tensor([999])
+    scan, noisy = c1_inputs(fps_scan)
     with torch.no_grad():
         got = pipe.classfree_forward(to_field(noisy, device), to_field(scan, device),
-                                     to_field(np.zeros_like(scan), device), t.to(device)).cpu()
-        want = net.classfree_forward(sd, net.points_to_field(torch.from_numpy(noisy)[None]),
-                                     net.points_to_field(torch.from_numpy(scan)[None]),
-                                     net.points_to_field(torch.zeros(1, scan.shape[0], 3)), t, w=6.0)
+                                     to_field(np.zeros_like(scan), device), torch.tensor([999], device=device)).cpu()
+    want = c1_oracle(fps_scan)
     assert got.shape == want.shape == (1, 180000, 3)
     err = (got - want).abs()
     assert torch.allclose(got, want, rtol=NET_RTOL, atol=NET_ATOL), (err.max().item(), err.mean().item())
+    print(f"C1: max |eps| error {err.max().item():.2e}, mean {err.mean().item():.2e}")
 
 
 # ---------------------------------------------------------------------------------------- (d)
+def t50_oracle():
+    """The oracle's own closed loop over all 50 steps on a 2 000-point scene: eps and points of every step."""
+    enc, unet, _ = build_seeded_models(42)
+    sd = diffusion_state_dict(enc, unet)
+    scan_np, noisy_np = small_scene(seed=21, n=2000)
+    zs = np.random.default_rng(4).standard_normal((50, 1) + scan_np.shape)
+    o = DpmSolverSdeOracle()
+    ts = o.set_timesteps(50)
+    x_init = scan_np.astype(np.float64)[None]
+
+    def compute():
+        cond_o = net.points_to_field(torch.from_numpy(scan_np)[None])
+        zero_o = net.points_to_field(torch.zeros(1, scan_np.shape[0], 3))
+        xo = noisy_np.astype(np.float64)[None]
+        xs, eps_all = [xo], []
+        with torch.no_grad():
+            for i, t in enumerate(ts):
+                xf = net.points_to_field(torch.from_numpy(xo).float())
+                eps = net.classfree_forward(sd, xf, cond_o, zero_o, torch.tensor([int(t)]), w=6.0)
+                xo = x_init + o.step(eps.numpy(), int(t), xf.F.numpy().reshape(1, -1, 3) - x_init, zs[i])
+                eps_all.append(eps.numpy())
+                xs.append(xo)
+        return {"eps": np.stack(eps_all), "x": np.stack(xs)}
+
+    traj = oracle_cached("t50_small", [scan_np, noisy_np, zs[0]] + state_dict_arrays(sd), compute)
+    return scan_np, zs, [int(t) for t in ts], traj
+
+
 def test_t50_trajectory_teacher_forced_every_point(device):
     """completion_loop (pipeline:155-169), all 50 steps of the sde-dpmsolver++ trajectory on a 2 000-point scene.
-    Both sides start step i from the oracle's points of step i - 1 (identical voxel coordinates), so the comparison
+    The device starts step i from the oracle's points of step i - 1 (identical voxel coordinates), so the comparison
     is free of voxel-boundary flips and holds for 100 % of the points at every step."""
     from lidiff_amd.pipeline import DiffCompletion
     enc, unet, refine = build_seeded_models(42)
-    sd = diffusion_state_dict(enc, unet)
     pipe = DiffCompletion(denoising_steps=50, cond_weight=6.0, device=device)
     pipe.partial_enc, pipe.model = enc.to(device), unet.to(device)
-    scan_np, noisy_np = small_scene(seed=21, n=2000)
-    rng = np.random.default_rng(4)
-    o = DpmSolverSdeOracle()
-    ts = o.set_timesteps(50)
-    assert pipe.dpm_scheduler.host_timesteps == [int(t) for t in ts] and len(ts) == 50
-    x_init = scan_np.astype(np.float64)[None]
-    x = noisy_np.astype(np.float64)[None]
-    scan_d = torch.from_numpy(x_init).to(device)
-    cond_o = net.points_to_field(torch.from_numpy(scan_np)[None])
-    zero_o = net.points_to_field(torch.zeros(1, scan_np.shape[0], 3))
+    scan_np, zs, ts, traj = t50_oracle()
+    assert pipe.dpm_scheduler.host_timesteps == ts and len(ts) == 50
+    scan_d = torch.from_numpy(scan_np.astype(np.float64)[None]).to(device)
     worst_eps = worst_x = 0.0
     with torch.no_grad():
         for i, t in enumerate(ts):
-            z = rng.standard_normal(x.shape)
-            xf = net.points_to_field(torch.from_numpy(x).float())
-            eps_o = net.classfree_forward(sd, xf, cond_o, zero_o, torch.tensor([int(t)]), w=6.0)
-            x_next = x_init + o.step(eps_o.numpy(), int(t), xf.F.numpy().reshape(1, -1, 3) - x_init, z)
+            x, x_next, eps_o = traj["x"][i], traj["x"][i + 1], torch.from_numpy(traj["eps"][i])
             x_t = to_field(x.astype(np.float32)[0], device)                     # the SAME points, CPU-rounded coords
             eps_d = pipe.classfree_forward(x_t, to_field(scan_np, device), to_field(np.zeros_like(scan_np), device),
-                                           torch.tensor([int(t)], device=device))
+                                           torch.tensor([t], device=device))
             assert torch.allclose(eps_d.cpu(), eps_o, rtol=NET_RTOL, atol=NET_ATOL), (i, (eps_d.cpu() - eps_o).abs().max())
-            x_dev = scan_d + pipe.dpm_scheduler.step(eps_d, int(t), x_t.F.reshape(1, -1, 3) - scan_d,
-                                                     noise=torch.from_numpy(z).to(device))["prev_sample"]
+            x_dev = scan_d + pipe.dpm_scheduler.step(eps_d, t, x_t.F.reshape(1, -1, 3) - scan_d,
+                                                     noise=torch.from_numpy(zs[i]).to(device))["prev_sample"]
             dx = np.abs(x_dev.cpu().numpy() - x_next).max()
             worst_eps = max(worst_eps, (eps_d.cpu() - eps_o).abs().max().item())
             worst_x = max(worst_x, dx)
             assert dx < 5e-3, (i, dx)                                            # every point, metres
-            x = x_next                                                           # teacher forcing
     print(f"T=50 teacher-forced: worst |eps| error {worst_eps:.2e}, worst |x| error {worst_x:.2e} m")

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--ordered", action="store_true", help="Morton-ordered tiles (row_order + permuted table)")
     ap.add_argument("--lpt", action="store_true", help="128-row tiles in descending pair-count order (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
+    ap.add_argument("--tile-kernel", action="store_true", help="keep the dense layers on the tile kernels of spconv.hip (A/B)")
     ap.add_argument("--timeline", action="store_true",
                     help="diagnostic build: per-workgroup cycle counters (prologue / main loop / epilogue / barrier / flush)")
     ap.add_argument("--probe", type=int, default=None,
@@ -48,6 +49,7 @@ def main():
         _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))
     from lidiff_amd import ops
     import lidiff_amd.MinkowskiEngine as ME
+    ops.FORCE_TILE_KERNEL = args.tile_kernel
     dev = torch.device("cuda:0")
     scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_fps18000.npy"))
     rng = np.random.default_rng(0)

@@ -33,7 +33,8 @@ extern "C" {
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
-#define LIDIFF_CONV_TILE_KERNEL 2   /* lidiff_spconv_fwd flags: never take the dense pipelined kernel (A/B runs) */
+#define LIDIFF_CONV_DENSE_KERNEL 2  /* lidiff_spconv_fwd flags: software-pipelined kernel for the dense 128-column layers */
+#define LIDIFF_CONV_DENSE_ONE_WAVE 4 /* ... in its four-wave form (one wave per SIMD, 32 columns per wave) */
 
 int lidiff_abi_version(void);
 const char* lidiff_last_error(void);
@@ -133,8 +134,10 @@ int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int3
  *   (pipeline:148-153) in one launch; m_in / m_out are per replica.
  * flags: LIDIFF_CONV_SPARSE_MAP = the kernel map is expected to hold only a few pairs per offset and
  *   128-row tile (a performance hint, results are identical): such tiles pack several offsets into
- *   one 128-row stage.  LIDIFF_CONV_TILE_KERNEL = keep the convolution on the tile kernels even where the
- *   one-wave-per-SIMD pipelined kernel of the dense 128-column layers applies (measurement aid; same results). */
+ *   one 128-row stage.  LIDIFF_CONV_DENSE_KERNEL = run layers with c_out % 128 == 0 and 64 | c_in on the
+ *   software-pipelined kernel (spconv_dense.hip: ring of four LDS-DMA images requested three stages ahead, counted
+ *   vmcnt barrier, fragments read one stage ahead); bit-identical results, same speed as the tile kernels on the
+ *   bench workload -- kept selectable, not the default. */
 int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
                       const float* w_packed, const int32_t* nbr, int32_t k_vol,
                       int64_t m_in, int64_t m_out, int32_t c_out, float* out,

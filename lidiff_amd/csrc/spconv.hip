@@ -715,9 +715,9 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % 32 == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
     const bool vec = c_in_a % 32 == 0 && c_in_b % 32 == 0 && al16(in_a) && al16(in_b);   // else: scalar gather
     hipStream_t st = (hipStream_t)stream;
-    // dense 128-column layers: the one-wave-per-SIMD pipelined kernel (spconv_dense.hip), unless the caller pins the
-    // tile kernels below (A/B measurements; the results are bit-identical)
-    if (!(flags & LIDIFF_CONV_TILE_KERNEL) && dense_kernel_applies(p)) return launch_fwd_dense(p, st);
+    // dense 128-column layers: the software-pipelined kernel of spconv_dense.hip on request (bit-identical results,
+    // measured equal to the tile kernels below on the bench workload: DESIGN.md section 4.2)
+    if ((flags & LIDIFF_CONV_DENSE_KERNEL) && dense_kernel_applies(p)) return launch_fwd_dense(p, st);
     if (c_out % 128 == 0) return dispatch_fwd<128, 8, 1>(p, vec, st);
     if (c_out % 96 == 0) {
         // low-density maps: two 48-column tiles of 3 x 2 waves -- their packed stages hold 8 offsets (own W

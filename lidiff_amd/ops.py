@@ -181,8 +181,9 @@ class ConvProfiler:
 
 
 PROFILER: ConvProfiler | None = None
-# A/B switch: keep every convolution on the tile kernels of spconv.hip (flag LIDIFF_CONV_TILE_KERNEL; results identical)
-FORCE_TILE_KERNEL = os.environ.get("LIDIFF_CONV_TILE_KERNEL", "0") == "1"
+# Kernel choice for the dense 128-column layers: "tile" (spconv.hip, default), "dense" (spconv_dense.hip, eight waves),
+# "dense1" (its four-wave form).  Results are bit-identical; DESIGN.md section 4.2 has the measurements.
+DENSE_KERNEL = os.environ.get("LIDIFF_CONV_KERNEL", "tile")
 
 
 def conv_variant(c_out: int) -> str:
@@ -234,7 +235,7 @@ def invalidate_caches(module: torch.nn.Module) -> None:
 def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
                relu: bool = False, sparse_map: bool = False, replicas: int = 1,
-               row_order: torch.Tensor | None = None, tile_kernel: bool = False) -> torch.Tensor:
+               row_order: torch.Tensor | None = None, kernel: str | None = None) -> torch.Tensor:
     """Sparse convolution forward with fused epilogue (MinkowskiConvolution[Transpose];
     minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1).  sparse_map: hint that
     the kernel map has only a few pairs per offset and 128-row tile (CoordinateManager.is_sparse_map).
@@ -242,7 +243,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     [R * M_in, C], the result [R * m_out, C_out].
     row_order: int32 permutation of the output rows (tile_order()); `nbr` must then hold its columns in that
     order (nbr[:, row_order]).  Results do not depend on it.
-    tile_kernel: keep the launch on the tile kernels even where the dense pipelined kernel applies (same results)."""
+    kernel: "tile" | "dense" | "dense1" (default: DENSE_KERNEL) -- which kernel runs a dense 128-column layer."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
     wp = packed_weights(w)
     if w.dim() == 2:
@@ -275,7 +276,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
          c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas),
-         int(bool(sparse_map)) | (2 if (tile_kernel or FORCE_TILE_KERNEL) else 0), stream_ptr())
+         int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6}[kernel or DENSE_KERNEL], stream_ptr())
     if prof is not None:
         end.record()
         prof.launches.append((conv_variant(c_out), start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))

@@ -448,3 +448,36 @@ def test_sparse_quantize_vs_oracle(device):
     assert isinstance(only, np.ndarray) and only.shape[1] == 3
     with pytest.raises(RuntimeError):
         ME.utils.sparse_quantize(np.array([[0.0, 0.0, 40000.0]]))
+
+
+@pytest.mark.parametrize("kernel", ["dense", "dense1"])
+def test_spconv_dense_kernel_is_bit_identical_to_the_tile_kernel(device, kernel):
+    """spconv_dense.hip (software-pipelined: ring of four LDS-DMA images, counted vmcnt barrier, fragments one stage
+    ahead; eight-wave and four-wave forms) on every shape class it accepts -- full / ragged tiles, 1..8 row blocks per
+    offset, fused ME.cat with both split positions, identity map, epilogue, replicas -- against the oracle AND bit for
+    bit against the tile kernel (same MFMA order, same flush order)."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for cloud, kind in ((random_cloud(2000, 5, 23), "k3"), (random_cloud(4000, 30, 7, dup=0.0), "k3"),
+                        (random_cloud(700, 3, 9), "k3"), (random_cloud(3000, 9, 4, batch=2), "k1")):
+        uniq, _, _ = me.voxelize(cloud)
+        nbr_np = me.kernel_map(uniq, uniq, 3, 1) if kind == "k3" else None
+        nbr = None if nbr_np is None else dev_i32(nbr_np, device)
+        m = uniq.shape[0]
+        for cin, split, cout in ((64, 0, 128), (128, 64, 128), (192, 128, 128), (256, 0, 256), (384, 256, 256)):
+            k = 27 if kind == "k3" else 1
+            x = torch.randn(2 * m, cin, generator=g)
+            w = torch.randn(k, cin, cout, generator=g) / np.sqrt(cin * max(1, k // 3))
+            sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+            res = torch.randn(2 * m, cout, generator=g)
+            xd = x.to(device)
+            args = dict(in_b=xd[:, split:].contiguous() if split else None, scale=sc.to(device), shift=sh.to(device),
+                        residual=res.to(device), relu=True, replicas=2)
+            a = xd[:, :split].contiguous() if split else xd
+            got = ops.spconv_fwd(a, w.to(device), nbr, m, kernel=kernel, **args)
+            ref = ops.spconv_fwd(a, w.to(device), nbr, m, kernel="tile", **args)
+            assert torch.equal(got, ref), (kind, cin, split, cout, (got - ref).abs().max().item())
+            assert torch.equal(got, ops.spconv_fwd(a, w.to(device), nbr, m, kernel=kernel, **args))      # deterministic
+            want = me.conv_forward(x[:m].double(), (w if k > 1 else w[0]).double(), nbr_np)
+            want = torch.relu(want * sc.double() + sh.double() + res[:m].double())
+            assert torch.allclose(got[:m].cpu().double(), want, rtol=RTOL, atol=ATOL), (kind, cin, split, cout)

@@ -242,3 +242,26 @@ def test_bench_launches_its_own_ranks():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "only 0 GPU(s) visible" in r.stderr
+
+
+def test_dense_kernel_isa_never_reads_an_in_flight_register(tmp_path):
+    """spconv_dense.hip requests its LDS fragments with inline asm and waits for them with counted s_waitcnt, so the
+    compiler believes the destination registers valid the moment they are requested.  tools/check_asm_regs.py scans
+    the generated gfx950 ISA for any instruction that reads such a register between its request and its wait (a copy
+    or spill placed there by the register allocator silently multiplies stale data) -- and for spills at all."""
+    import subprocess
+    import sys
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "lidiff_amd", "csrc", "spconv_dense.hip")
+    out = os.path.join(tmp_path, "dense.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--cuda-device-only", "-S", src,
+                        "-o", out, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ScratchSize [bytes/lane]: 0" in r.stderr and "VGPRs Spill: 0" in r.stderr
+    assert not re.search(r"(ScratchSize \[bytes/lane\]|VGPRs Spill): [1-9]", r.stderr)
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_regs.py"), out], capture_output=True,
+                         text=True, timeout=120)
+    assert chk.returncode == 0 and chk.stdout.startswith("0 suspicious"), chk.stdout[:2000]

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--ordered", action="store_true", help="Morton-ordered tiles (row_order + permuted table)")
     ap.add_argument("--lpt", action="store_true", help="128-row tiles in descending pair-count order (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
-    ap.add_argument("--tile-kernel", action="store_true", help="keep the dense layers on the tile kernels of spconv.hip (A/B)")
+    ap.add_argument("--kernel", default="tile", choices=["tile", "dense", "dense1"], help="kernel of the dense 128-column layers")
     ap.add_argument("--timeline", action="store_true",
                     help="diagnostic build: per-workgroup cycle counters (prologue / main loop / epilogue / barrier / flush)")
     ap.add_argument("--probe", type=int, default=None,
@@ -42,14 +42,16 @@ def main():
         from lidiff_amd import _lib
         csrc = os.path.join(ROOT, "lidiff_amd", "csrc")
         lib = os.path.join(csrc, "liblidiff_amd_probe.so")
-        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(csrc, "spconv.hip")):
+        if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(csrc, f)) for f in
+                                                                 ("spconv.hip", "spconv_dense.hip", "spconv.h")):
             subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-DLIDIFF_CONV_PROBE",
-                            "-shared", os.path.join(csrc, "spconv.hip"), os.path.join(csrc, "coords.hip"), "-o", lib], check=True)
+                            "-shared", os.path.join(csrc, "spconv.hip"), os.path.join(csrc, "spconv_dense.hip"),
+                            os.path.join(csrc, "coords.hip"), "-o", lib], check=True)
         _lib.LIB_PATH = lib
         _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))
     from lidiff_amd import ops
     import lidiff_amd.MinkowskiEngine as ME
-    ops.FORCE_TILE_KERNEL = args.tile_kernel
+    ops.DENSE_KERNEL = args.kernel
     dev = torch.device("cuda:0")
     scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_fps18000.npy"))
     rng = np.random.default_rng(0)
@@ -132,6 +134,12 @@ def main():
                   f"slabs {t[:, 0, 6].mean():.0f} = {stages:.0f} stages")
             for wv, name in ((0, "wave 0"), (1, f"wave NW/2")):
                 q = t[:, wv]
+                if args.kernel != "tile" and cout % 128 == 0 and cin % 64 == 0 and not hint:      # dense kernel: other fields
+                    print(f"  wave {wv}: prologue {q[:, 0].mean():.0f}  main loop {q[:, 1].mean():.0f}  epilogue {q[:, 2].mean():.0f} | "
+                          f"per stage: loop {q[:, 1].mean() / stages:.0f} = barrier+vmcnt {q[:, 3].mean() / stages:.0f} + "
+                          f"P2 wait {q[:, 8].mean() / stages:.0f} + flush {q[:, 4].mean() / stages:.0f} + rest "
+                          f"{(q[:, 1] - q[:, 3] - q[:, 8] - q[:, 4]).mean() / stages:.0f}")
+                    continue
                 print(f"  {name}: prologue {q[:, 0].mean():.0f}  main loop {q[:, 1].mean():.0f}  epilogue {q[:, 2].mean():.0f} | per stage: "
                       f"loop {q[:, 1].mean() / stages:.0f} = issue {q[:, 8].mean() / stages:.0f} + mma {q[:, 9].mean() / stages:.0f} + "
                       f"flush {q[:, 4].mean() / stages:.0f} + barrier {q[:, 3].mean() / stages:.0f} + rest "

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 9
+#define LIDIFF_ABI_VERSION 10
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -108,6 +108,18 @@ int lidiff_rulebook_compact(const int32_t* nbr, int32_t k_vol, int64_t m_out,
                             void* workspace, void* stream);
 int64_t lidiff_rulebook_workspace_bytes(int32_t k_vol, int64_t m_out);
 
+/* Tail map of a kernel_size-3 / stride-1 kernel map, for the two-pass convolution of low-density maps (see the `tail`
+ * arguments of lidiff_spconv_fwd): the pairs of every offset but `skip` (13, the centre: the identity on such a map) as P
+ * rows sorted by (offset, output row).  Two phases on one workspace (lidiff_tail_map_workspace_bytes):
+ *   phase 1 (tail_nbr == NULL): offset_ptr[k_vol + 1] (pairs before each offset; [k_vol] = P) and row_ptr[m_out + 1]
+ *     (CSR over the map's output rows) -- the host reads P = offset_ptr[k_vol];
+ *   phase 2: tail_nbr [k_vol, P] (row p: the pair's input row at its own offset, -1 elsewhere: a kernel map whose output
+ *     rows are the pairs) and idx [P] (the pairs of output row o, ascending offset: idx[row_ptr[o] .. row_ptr[o+1])).
+ * No reference counterpart: ME walks its per-offset in/out lists once per convolution (minkunet.py:53-66). */
+int64_t lidiff_tail_map_workspace_bytes(int32_t k_vol, int64_t m_out);
+int lidiff_tail_map(const int32_t* nbr, int32_t k_vol, int64_t m_out, int32_t skip, int32_t* offset_ptr,
+                    int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx, void* workspace, void* stream);
+
 /* Weight layout of the sparse convolution.  MinkowskiConvolution.kernel is [K, c_in, c_out] row-major
  * (minkunet.py:17,36,53,61; [c_in, c_out] for kernel_size 1, :72).  The HIP kernel consumes it in MFMA
  * fragment order: [K][slab = ceil(c_in/32)][c_out/16][j 0..1][lane 0..63][e 0..3] with
@@ -137,12 +149,22 @@ int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int3
  *   one 128-row stage.  LIDIFF_CONV_DENSE_KERNEL = run layers with c_out % 128 == 0 and 64 | c_in on the
  *   software-pipelined kernel (spconv_dense.hip: ring of four LDS-DMA images requested three stages ahead, counted
  *   vmcnt barrier, fragments read one stage ahead); bit-identical results, same speed as the tile kernels on the
- *   bench workload -- kept selectable, not the default. */
+ *   bench workload -- kept selectable, not the default.
+ * tail / tail_ptr / tail_idx (all null, or all set): rows added to the convolution sum BEFORE the epilogue through a
+ *   CSR over the output rows: out[o] += sum over q in [tail_ptr[o], tail_ptr[o+1]) of tail[tail_idx[q], :]
+ *   (tail [replicas * tail_rows, c_out]).  This is how a low-density kernel_size-3 map (stride-1 / 2 levels of a noisy
+ *   scan: ~1.1-1.5 neighbours per voxel) is convolved: the centre offset is the identity map -- one dense
+ *   [M, c_in] x [c_in, c_out] pass over contiguous rows, launched with nbr == NULL and W[13] -- and the few pairs of
+ *   the other 26 offsets are multiplied beforehand, grouped by offset (weight stationary: W[k] is read once per 128
+ *   pairs instead of once per output tile that has a single pair of offset k), into `tail`, one row per pair
+ *   (lidiff_amd/MinkowskiEngine CoordinateManager.tail_map).  Fixed summation order: deterministic. */
 int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
                       const float* w_packed, const int32_t* nbr, int32_t k_vol,
                       int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                       const float* ep_scale, const float* ep_shift, const float* residual,
-                      int32_t relu, const int32_t* row_order, int32_t replicas, int32_t flags, void* stream);
+                      int32_t relu, const int32_t* row_order, int32_t replicas, int32_t flags,
+                      const float* tail, const int32_t* tail_ptr, const int32_t* tail_idx, int64_t tail_rows,
+                      void* stream);
 
 /* Weight gradient of lidiff_spconv_fwd (training path, models.py:180-217; ME: ConvolutionBackwardGPU):
  * dw[k] += gather(in)[pairs_in of offset k]^T @ grad_out[pairs_out of offset k], in = [in_a | in_b], over the

@@ -91,6 +91,13 @@ class CoordinateManager:
             self.kmaps[key] = nbr
         return nbr
 
+    def tail_map(self, ts: int):
+        """ops.TailMap of the kernel_size-3 map on stride ts (non-centre pairs by offset + CSR by output row); cached."""
+        key = ("tail", ts)
+        if key not in self.aux:
+            self.aux[key] = ops.TailMap(self.kernel_map(ts, ts, 3))
+        return self.aux[key]
+
     ORDER_MIN_ROWS = 30000      # smaller maps fit the L2 anyway
 
     def tile_order(self, ts: int):

@@ -30,9 +30,12 @@ SIGNATURES = {
     "lidiff_kernel_map_up": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_rulebook_compact": (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _p]),
     "lidiff_rulebook_workspace_bytes": (_i64, [_i32, _i64]),
+    "lidiff_tail_map_workspace_bytes": (_i64, [_i32, _i64]),
+    "lidiff_tail_map": (_i32, [_p, _i32, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p]),
     "lidiff_spconv_packed_weight_floats": (_i64, [_i32, _i32, _i32]),
     "lidiff_spconv_pack_weights": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
-    "lidiff_spconv_fwd": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p]),
+    "lidiff_spconv_fwd": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i32, _i32,
+                                 _p, _p, _p, _i64, _p]),
     "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p]),
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
@@ -48,7 +51,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 

@@ -349,6 +349,111 @@ __global__ void rb_fill_kernel(const int32_t* __restrict__ nbr, int64_t m_out,
 }
 
 // ---------------------------------------------------------------------------------------
+// Tail map of a kernel_size-3 / stride-1 kernel map (include/lidiff_amd.h, lidiff_tail_map): the pairs of all offsets
+// but `skip` (the centre = identity) as P output rows sorted by (offset, output row) -- tail_nbr[k][p] = input row of pair p
+// at its own offset, -1 elsewhere -- plus a CSR over the map's output rows listing each row's pairs in ascending offset.
+__global__ void tail_count_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int skip, int32_t* __restrict__ counts) {
+    __shared__ int wave_cnt[kWavesPerBlock];
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = (int)blockIdx.y != skip && o < m_out && nbr[(int64_t)blockIdx.y * m_out + o] >= 0;
+    const unsigned long long m = __ballot(valid);
+    if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) t += wave_cnt[w];
+        counts[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// per-row pair counts of the tail map: FINAL == false: per-block sums only; FINAL == true: row_ptr[o] = blk_base[block] +
+// exclusive scan inside the block, row_ptr[m_out] = total (the block sums are scanned in between by scan_i32_kernel)
+template <bool FINAL>
+__global__ void tail_rowcnt_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int k_vol, int skip,
+                                   int32_t* __restrict__ blk_sums, int32_t* __restrict__ row_ptr) {
+    __shared__ int wave_tot[kWavesPerBlock];
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (o < m_out)
+        for (int k = 0; k < k_vol; ++k) c += (k != skip && nbr[(int64_t)k * m_out + o] >= 0) ? 1 : 0;
+    int incl = c;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane_id() >= off) incl += t;
+    }
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == kWave - 1) wave_tot[w] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int q = 0; q < kWavesPerBlock; ++q) {
+        if (q < w) wbase += wave_tot[q];
+        tot += wave_tot[q];
+    }
+    if constexpr (!FINAL) {
+        if (threadIdx.x == 0) blk_sums[blockIdx.x] = tot;
+    } else {
+        const int base = blk_sums[blockIdx.x];
+        if (o < m_out) row_ptr[o] = base + wbase + incl - c;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) row_ptr[m_out] = base + tot;
+    }
+}
+
+// single block: in-place exclusive scan of data[0..n), data[n] = total
+__global__ void scan_i32_kernel(int32_t* __restrict__ data, int64_t n) {
+    __shared__ int wave_tot[1024 / kWave];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int nw = blockDim.x / kWave;
+    for (int64_t base = 0; base < n; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < n ? data[i] : 0;
+        int incl = v;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane_id() >= off) incl += t;
+        }
+        if (lane_id() == kWave - 1) wave_tot[threadIdx.x / kWave] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w = 0; w < nw; ++w) {
+            if (w < (int)(threadIdx.x / kWave)) wbase += wave_tot[w];
+            tot += wave_tot[w];
+        }
+        const int carry = carry_s;
+        if (i < n) data[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) data[n] = carry_s;
+}
+
+__global__ void tail_fill_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int skip, int64_t n_pairs,
+                                 const int32_t* __restrict__ scanned, const int32_t* __restrict__ row_ptr,
+                                 int32_t* __restrict__ tail_nbr, int32_t* __restrict__ idx) {
+    __shared__ int wave_cnt[kWavesPerBlock];
+    const int k = blockIdx.y;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = -1;
+    if (k != skip && o < m_out) v = nbr[(int64_t)k * m_out + o];
+    const bool valid = v >= 0;
+    const unsigned long long m = __ballot(valid);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < w; ++q) wbase += wave_cnt[q];
+    if (valid) {
+        const int pos = scanned[(int64_t)k * gridDim.x + blockIdx.x] + wbase + popc_below(m);
+        tail_nbr[(int64_t)k * n_pairs + pos] = v;
+        int rank = 0;                                            // pairs of this output row at lower offsets
+        for (int q = 0; q < k; ++q) rank += (q != skip && nbr[(int64_t)q * m_out + o] >= 0) ? 1 : 0;
+        idx[row_ptr[o] + rank] = pos;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // row gather / scatter-add
 template <bool VEC4>
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
@@ -816,6 +921,40 @@ int lidiff_rulebook_compact(const int32_t* nbr, int32_t k_vol, int64_t m_out, in
     rb_scan_kernel<<<1, 1024, 0, st>>>(counts, nblk * k_vol, nblk, k_vol, offset_ptr);
     if (pairs_in != nullptr)
         rb_fill_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, counts, pairs_in, pairs_out);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int64_t lidiff_tail_map_workspace_bytes(int32_t k_vol, int64_t m_out) {
+    return ((int64_t)(k_vol + 1) * ceil_div(m_out > 0 ? m_out : 1, kBlock) + 32) * (int64_t)sizeof(int32_t);
+}
+
+int lidiff_tail_map(const int32_t* nbr, int32_t k_vol, int64_t m_out, int32_t skip, int32_t* offset_ptr,
+                    int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx, void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && m_out >= 0, "bad shape");
+    LIDIFF_CHECK_ARG(nbr != nullptr && offset_ptr != nullptr && row_ptr != nullptr && workspace != nullptr, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)ceil_div(m_out > 0 ? m_out : 1, kBlock);
+    int32_t* counts = (int32_t*)workspace;
+    if (tail_nbr == nullptr) {                       // phase 1: counts, offset_ptr[k_vol + 1], row_ptr[m_out + 1]
+        if (m_out == 0) {
+            LIDIFF_CHECK_HIP(hipMemsetAsync(offset_ptr, 0, (size_t)(k_vol + 1) * sizeof(int32_t), st));
+            LIDIFF_CHECK_HIP(hipMemsetAsync(row_ptr, 0, sizeof(int32_t), st));
+            return 0;
+        }
+        tail_count_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, skip, counts);
+        rb_scan_kernel<<<1, 1024, 0, st>>>(counts, nblk * k_vol, nblk, k_vol, offset_ptr);
+        int32_t* blk_sums = counts + (int64_t)k_vol * nblk + 8;       // behind the per-offset block counts
+        tail_rowcnt_kernel<false><<<nblk, kBlock, 0, st>>>(nbr, m_out, k_vol, skip, blk_sums, row_ptr);
+        scan_i32_kernel<<<1, 1024, 0, st>>>(blk_sums, nblk);
+        tail_rowcnt_kernel<true><<<nblk, kBlock, 0, st>>>(nbr, m_out, k_vol, skip, blk_sums, row_ptr);
+        LIDIFF_CHECK_LAUNCH();
+        return 0;
+    }
+    LIDIFF_CHECK_ARG(idx != nullptr && n_pairs >= 0, "phase 2 needs tail_nbr, idx and the pair count of phase 1");
+    if (n_pairs == 0 || m_out == 0) return 0;
+    LIDIFF_CHECK_HIP(hipMemsetAsync(tail_nbr, 0xFF, (size_t)k_vol * n_pairs * sizeof(int32_t), st));
+    tail_fill_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, skip, n_pairs, counts, row_ptr, tail_nbr, idx);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

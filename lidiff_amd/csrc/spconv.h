@@ -23,6 +23,10 @@ struct ConvParams {
     const float* scale;
     const float* shift;
     const float* residual;
+    const float* tail;          // nullable: rows added to the sum BEFORE the epilogue, through a CSR over output rows:
+    const int32_t* tail_ptr;    //   out[o] += sum of tail[tail_idx[q]] for q in [tail_ptr[o], tail_ptr[o+1])
+    const int32_t* tail_idx;
+    int64_t tail_rows;          //   rows of `tail` per replica
     int64_t m_in, m_out;
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
     int tiles_m, tiles_n, flags, replicas;

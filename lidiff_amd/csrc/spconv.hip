@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     if (p.in_b) p.in_b += (int64_t)rep * p.m_in * p.c_in_b;
     p.out += (int64_t)rep * p.m_out * p.c_out;
     if (p.residual) p.residual += (int64_t)rep * p.m_out * p.c_out;
+    if (p.tail) p.tail += (int64_t)rep * p.tail_rows * p.c_out;
     const int64_t row0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
     const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
@@ -180,12 +181,18 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     constexpr int SEGR = kChunk / SEG, BPS = SEGR / 16;               // rows / row blocks per segment
     bool packed = false;
     if constexpr (SEG > 1) {
+        // stages per channel slab: one per active offset unpacked, ceil(#segments / SEG) packed (an offset with n pairs
+        // takes ceil(n / SEGR) segments).  A packed stage costs about 4/3 of a plain one (W registers per segment,
+        // ordered flush), so pack when that still wins -- e.g. the stride-1 level of a noisy scan: the centre offset
+        // (128 pairs = SEG segments) plus ~7 offsets with one pair each are 2 packed stages instead of 8 plain ones
+        // (the former rule, mean pairs per active offset <= 3/4 segment, kept such tiles unpacked: 21 of their 25
+        // stages multiplied a single pair, profiles/r02_lowdensity_timeline.txt).
         const int c = lane < p.k_vol ? cnt[lane] : 0;
-        int tot = c, act = c > 0;
-        for (int off = 32; off > 0; off >>= 1) { tot += __shfl_down(tot, off); act += __shfl_down(act, off); }
-        tot = __builtin_amdgcn_readfirstlane(tot);
+        int nseg = (c + SEGR - 1) / SEGR, act = c > 0;
+        for (int off = 32; off > 0; off >>= 1) { nseg += __shfl_down(nseg, off); act += __shfl_down(act, off); }
+        nseg = __builtin_amdgcn_readfirstlane(nseg);
         act = __builtin_amdgcn_readfirstlane(act);
-        packed = p.nbr != nullptr && 4 * tot <= 3 * SEGR * act;       // mean pairs per active offset <= 3/4 segment
+        packed = p.nbr != nullptr && 4 * ((nseg + SEG - 1) / SEG) <= 3 * act;
     }
     const int segr = packed ? SEGR : kChunk;
     // ---- work list: (offset, segment of <= segr pairs), ascending k: wave 0, exclusive scan ------
@@ -582,6 +589,13 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         const int r = e / (BN / 4), cq = e % (BN / 4);
         const int col = n0 + 4 * cq;
         float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + cq];
+        if (p.tail) {                              // contributions computed elsewhere (the non-centre offsets), fixed order
+            const int orw = orow[r];
+            for (int q = p.tail_ptr[orw], qe = p.tail_ptr[orw + 1]; q < qe; ++q) {
+                const float4 s = *reinterpret_cast<const float4*>(p.tail + (int64_t)p.tail_idx[q] * p.c_out + col);
+                v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+            }
+        }
         if (p.scale) {
             const float4 s = *reinterpret_cast<const float4*>(p.scale + col);
             v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
@@ -691,8 +705,11 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
                                  const float* w_packed, const int32_t* nbr, int32_t k_vol, int64_t m_in,
                                  int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
                                  const float* ep_shift, const float* residual, int32_t relu,
-                                 const int32_t* row_order, int32_t replicas, int32_t flags, void* stream) {
+                                 const int32_t* row_order, int32_t replicas, int32_t flags, const float* tail,
+                                 const int32_t* tail_ptr, const int32_t* tail_idx, int64_t tail_rows, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0, "in_a / c_in_a");
+    LIDIFF_CHECK_ARG((tail == nullptr) == (tail_ptr == nullptr) && (tail == nullptr) == (tail_idx == nullptr),
+                     "tail, tail_ptr and tail_idx must be all set or all null");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
     LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
@@ -704,12 +721,13 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     ConvParams p{};
     p.in_a = in_a; p.in_b = in_b; p.wp = w_packed; p.nbr = nbr; p.row_order = row_order; p.out = out;
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
+    p.tail = tail; p.tail_ptr = tail_ptr; p.tail_idx = tail_idx; p.tail_rows = tail_rows;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
     p.k_vol = k_vol; p.relu = relu; p.flags = flags; p.replicas = replicas; p.probe = g_conv_probe; p.timeline = g_conv_timeline;
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
-    LIDIFF_CHECK_ARG(al16(w_packed) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
-                     "w_packed/out/epilogue pointers must be 16-byte aligned");
+    LIDIFF_CHECK_ARG(al16(w_packed) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual) && al16(tail),
+                     "w_packed/out/epilogue/tail pointers must be 16-byte aligned");
     const bool fits32 = m_in * (int64_t)c_in_a * 4 < (1ll << 31) && m_in * (int64_t)c_in_b * 4 < (1ll << 31);
     LIDIFF_CHECK_ARG(fits32, "a feature matrix exceeds the 2 GiB buffer-descriptor range");
     LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % 32 == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");

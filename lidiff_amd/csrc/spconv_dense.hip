@@ -84,6 +84,7 @@ void spconv_fwd_dense_kernel(const ConvParams p_launch) {
     if (p.in_b) p.in_b += (int64_t)rep * p.m_in * p.c_in_b;
     p.out += (int64_t)rep * p.m_out * p.c_out;
     if (p.residual) p.residual += (int64_t)rep * p.m_out * p.c_out;
+    if (p.tail) p.tail += (int64_t)rep * p.tail_rows * p.c_out;
     const int64_t row0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
     const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
@@ -472,6 +473,13 @@ void spconv_fwd_dense_kernel(const ConvParams p_launch) {
         const int r = e / (BN / 4), cq = e % (BN / 4);
         const int col = n0 + 4 * cq;
         float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + cq];
+        if (p.tail) {                              // contributions computed elsewhere (the non-centre offsets), fixed order
+            const int orw = orow[r];
+            for (int q = p.tail_ptr[orw], qe = p.tail_ptr[orw + 1]; q < qe; ++q) {
+                const float4 s = *reinterpret_cast<const float4*>(p.tail + (int64_t)p.tail_idx[q] * p.c_out + col);
+                v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+            }
+        }
         if (p.scale) {
             const float4 s = *reinterpret_cast<const float4*>(p.scale + col);
             v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;

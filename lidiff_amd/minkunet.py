@@ -84,6 +84,10 @@ def _fusable(*mods) -> bool:
 # the L2 hits it buys do not pay for that), so it is off; the knob stays for maps with other statistics.
 _ORDERED_TILES = False
 
+# kernel_size-3 convolutions on low-density maps (the host's sparse-map hint) as centre pass + tail rows (ops.TailMap):
+# the centre offset of a stride-1 map is the identity, the other offsets bring ~0.1-0.5 pairs per voxel
+_CENTRE_TAIL = True
+
 
 def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=None) -> ME.SparseTensor:
     """relu?( bn(conv([x | extra])) + residual ) as ONE kernel launch (eval mode only)."""
@@ -94,9 +98,13 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
     if nbr is not None and _ORDERED_TILES:
         nbr, order = mgr.kernel_map_ordered(x.tensor_stride, ts_out, conv.kernel_size, conv.transposed)
     scale, shift = _bn_affine(bn)
-    f = ops.spconv_fwd(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift,
-                       residual=residual, relu=relu, sparse_map=conv.sparse_hint(x, ts_out), replicas=x.replicas,
-                       row_order=order)
+    hint = conv.sparse_hint(x, ts_out)
+    if _CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None:
+        f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
+                                   residual=residual, relu=relu, replicas=x.replicas)
+    else:
+        f = ops.spconv_fwd(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift,
+                           residual=residual, relu=relu, sparse_map=hint, replicas=x.replicas, row_order=order)
     out = ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
     out.replicas = x.replicas
     return out

@@ -203,17 +203,18 @@ def pack_weights(w: torch.Tensor) -> torch.Tensor:
     return wp
 
 
-def packed_weights(w: torch.Tensor) -> torch.Tensor:
-    """pack_weights(w), cached on the tensor object (a module's Parameter) until it is modified in
-    place, reallocated or moved: the pack costs one pass over the weights per optimizer step, not
-    per forward."""
+def packed_weights(w: torch.Tensor, offset: int | None = None) -> torch.Tensor:
+    """pack_weights(w) -- or, with `offset`, of the single kernel offset w[offset] as a K = 1 kernel -- cached on the
+    tensor object (a module's Parameter) until it is modified in place, reallocated or moved: the pack costs one pass
+    over the weights per optimizer step, not per forward."""
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
     key = (w.data_ptr(), w._version, tuple(w3.shape), w.device)
-    hit = getattr(w, "_lidiff_packed", None)
+    attr = "_lidiff_packed" if offset is None else f"_lidiff_packed_k{offset}"
+    hit = getattr(w, attr, None)
     if hit is None or hit[0] != key:
-        hit = (key, pack_weights(w3))
+        hit = (key, pack_weights(w3 if offset is None else w3[offset:offset + 1]))
         try:
-            w._lidiff_packed = hit
+            setattr(w, attr, hit)
         except AttributeError:      # not attachable: pack every call
             pass
     return hit[1]
@@ -225,8 +226,8 @@ def invalidate_caches(module: torch.nn.Module) -> None:
     keys follow ordinary in-place updates (optimizer steps, load_state_dict, copy_); writes THROUGH ``.data``
     (``p.data.mul_(...)``: an EMA, weight clipping) do not bump ``_version`` -- call this after such writes."""
     for p in module.parameters():
-        if hasattr(p, "_lidiff_packed"):
-            del p._lidiff_packed
+        for attr in [a for a in vars(p) if a.startswith("_lidiff_packed")]:
+            delattr(p, attr)
     for m in module.modules():
         if hasattr(m, "_affine_cache"):
             del m._affine_cache
@@ -235,7 +236,8 @@ def invalidate_caches(module: torch.nn.Module) -> None:
 def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
                relu: bool = False, sparse_map: bool = False, replicas: int = 1,
-               row_order: torch.Tensor | None = None, kernel: str | None = None) -> torch.Tensor:
+               row_order: torch.Tensor | None = None, kernel: str | None = None, tail=None,
+               offset: int | None = None) -> torch.Tensor:
     """Sparse convolution forward with fused epilogue (MinkowskiConvolution[Transpose];
     minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1).  sparse_map: hint that
     the kernel map has only a few pairs per offset and 128-row tile (CoordinateManager.is_sparse_map).
@@ -243,13 +245,19 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     [R * M_in, C], the result [R * m_out, C_out].
     row_order: int32 permutation of the output rows (tile_order()); `nbr` must then hold its columns in that
     order (nbr[:, row_order]).  Results do not depend on it.
-    kernel: "tile" | "dense" | "dense1" (default: DENSE_KERNEL) -- which kernel runs a dense 128-column layer."""
+    kernel: "tile" | "dense" | "dense1" (default: DENSE_KERNEL) -- which kernel runs a dense 128-column layer.
+    offset: convolve with the single kernel offset w[offset] over the identity map (nbr must be None): the centre of a
+    kernel_size-3 map.  tail = (rows [R * P, C_out], ptr int32 [m_out + 1], idx int32 [P]): rows added to the sum before
+    the epilogue, out[o] += sum(rows[idx[ptr[o]:ptr[o + 1]]]) -- the other offsets' contributions (TailMap)."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
-    wp = packed_weights(w)
+    wp = packed_weights(w, offset)
     if w.dim() == 2:
         k, (c_in, c_out) = 1, w.shape
     else:
         k, c_in, c_out = w.shape
+    if offset is not None:
+        assert nbr is None and 0 <= offset < k
+        k = 1
     in_a = in_a.contiguous()
     c_a = in_a.shape[1]
     c_b = 0
@@ -267,6 +275,13 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert residual.shape == (replicas * m_out, c_out)
     if row_order is not None:
         assert row_order.dtype == torch.int32 and row_order.shape == (m_out,) and row_order.is_contiguous()
+    t_rows = t_ptr = t_idx = None
+    n_tail = 0
+    if tail is not None:
+        t_rows, t_ptr, t_idx = tail
+        n_tail = t_idx.shape[0]
+        assert t_rows.shape == (replicas * n_tail, c_out) and t_rows.is_contiguous() and t_rows.dtype == torch.float32
+        assert t_ptr.dtype == torch.int32 and t_ptr.shape == (m_out + 1,) and t_idx.dtype == torch.int32
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
     prof = PROFILER
     if prof is not None and not prof.wants(conv_variant(c_out)):
@@ -276,7 +291,8 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
          c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas),
-         int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6}[kernel or DENSE_KERNEL], stream_ptr())
+         int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6}[kernel or DENSE_KERNEL],
+         ptr(t_rows), ptr(t_ptr), ptr(t_idx), n_tail, stream_ptr())
     if prof is not None:
         end.record()
         prof.launches.append((conv_variant(c_out), start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
@@ -437,3 +453,42 @@ def argmin_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     idx = torch.empty(a4.shape[0], dtype=torch.int64, device=a.device)
     call("lidiff_argmin_rows_f32", ptr(a4), a4.shape[0], ptr(b4), b4.shape[0], ptr(idx), stream_ptr())
     return idx
+
+
+class TailMap:
+    """The non-centre pairs of a kernel_size-3 / stride-1 kernel map, laid out for the two-pass convolution of
+    low-density maps (include/lidiff_amd.h, lidiff_spconv_fwd `tail`):
+      nbr [27, P]   kernel map of the P pairs as output rows: row p (pairs sorted by offset, then output row) has its input
+                    row at its own offset and -1 elsewhere -- lidiff_spconv_fwd over it multiplies every pair with its
+                    W[k], 128 pairs of (mostly) ONE offset per tile;
+      ptr [M + 1], idx [P]   CSR over the map's output rows: the pairs landing on output row o, in ascending offset.
+    Built once per coordinate map from its neighbour table (shared by every convolution on the map)."""
+
+    def __init__(self, nbr: torch.Tensor):
+        require_device(nbr)
+        k, m = nbr.shape
+        assert k == 27 and nbr.dtype == torch.int32 and nbr.is_contiguous()
+        dev = nbr.device
+        ws = torch.empty(_lib.load().lidiff_tail_map_workspace_bytes(k, m), dtype=torch.uint8, device=dev)
+        off = torch.empty(k + 1, dtype=torch.int32, device=dev)
+        self.ptr = torch.empty(m + 1, dtype=torch.int32, device=dev)
+        call("lidiff_tail_map", ptr(nbr), k, m, 13, ptr(off), ptr(self.ptr), 0, None, None, ptr(ws), stream_ptr())
+        self.n = int(off[-1].item())                                     # the one host read of this map
+        self.nbr = self.idx = None
+        if self.n:
+            self.nbr = torch.empty((k, self.n), dtype=torch.int32, device=dev)
+            self.idx = torch.empty(self.n, dtype=torch.int32, device=dev)
+            call("lidiff_tail_map", ptr(nbr), k, m, 13, ptr(off), ptr(self.ptr), self.n, ptr(self.nbr), ptr(self.idx),
+                 ptr(ws), stream_ptr())
+
+
+def spconv_centre_tail(in_a, w, tmap: TailMap, m_out, **kw):
+    """A kernel_size-3 / stride-1 convolution on a low-density map as two launches: the pairs of the 26 non-centre
+    offsets multiplied offset by offset (weight stationary) into one row per pair, then the centre offset as a dense pass
+    over contiguous rows that adds those rows through the map's CSR in its epilogue.  Same arguments as spconv_fwd."""
+    replicas = kw.get("replicas", 1)
+    tail = None
+    if tmap.n > 0:
+        rows = spconv_fwd(in_a, w, tmap.nbr, tmap.n, in_b=kw.get("in_b"), replicas=replicas)
+        tail = (rows, tmap.ptr, tmap.idx)
+    return spconv_fwd(in_a, w, None, m_out, tail=tail, offset=13, **kw)

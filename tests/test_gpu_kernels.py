@@ -481,3 +481,48 @@ def test_spconv_dense_kernel_is_bit_identical_to_the_tile_kernel(device, kernel)
             want = me.conv_forward(x[:m].double(), (w if k > 1 else w[0]).double(), nbr_np)
             want = torch.relu(want * sc.double() + sh.double() + res[:m].double())
             assert torch.allclose(got[:m].cpu().double(), want, rtol=RTOL, atol=ATOL), (kind, cin, split, cout)
+
+
+@pytest.mark.parametrize("cin,cout,split", [(32, 32, 0), (96, 96, 0), (128, 96, 96), (3, 32, 0), (64, 128, 0)])
+def test_spconv_centre_tail_vs_oracle(device, cin, cout, split):
+    """Low-density kernel_size-3 maps as centre pass + tail rows (ops.TailMap / spconv_centre_tail): the pairs of the 26
+    non-centre offsets multiplied offset by offset into one row per pair, added through the CSR of the map in the epilogue
+    of the dense centre pass -- against the oracle (rtol / atol 1e-4), against the one-launch kernel, run-to-run identical,
+    with epilogue, fused ME.cat and replicas; a map with NO non-centre pair and a dense map included."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    clouds = [random_cloud(6000, 40, 11, batch=2, dup=0.05), random_cloud(300, 200, 12, dup=0.0), random_cloud(1500, 4, 13)]
+    for cloud in clouds:
+        uniq, _, _ = me.voxelize(cloud)
+        nbr_np = me.kernel_map(uniq, uniq, 3, 1)
+        nbr = dev_i32(nbr_np, device)
+        m = uniq.shape[0]
+        tmap = ops.TailMap(nbr)
+        assert tmap.n == int((nbr_np >= 0).sum()) - m
+        if tmap.n:                                              # CSR: every pair once, under its output row, ascending offset
+            ptr, idx = tmap.ptr.cpu().numpy(), tmap.idx.cpu().numpy()
+            assert ptr[0] == 0 and ptr[-1] == tmap.n and sorted(idx.tolist()) == list(range(tmap.n))
+            tail_np = tmap.nbr.cpu().numpy()
+            k_of = tail_np.argmax(0)
+            assert np.all((tail_np >= 0).sum(0) == 1)
+            for o in (0, m // 2, m - 1):
+                ks = k_of[idx[ptr[o]:ptr[o + 1]]]
+                want_k = [k for k in range(27) if k != 13 and nbr_np[k, o] >= 0]
+                assert ks.tolist() == want_k
+                assert tail_np[ks, idx[ptr[o]:ptr[o + 1]]].tolist() == [nbr_np[k, o] for k in want_k]
+        x = torch.randn(2 * m, cin, generator=g)
+        w = torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)
+        sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        res = torch.randn(2 * m, cout, generator=g)
+        xd = x.to(device)
+        a = xd[:, :split].contiguous() if split else xd
+        kw = dict(in_b=xd[:, split:].contiguous() if split else None, scale=sc.to(device), shift=sh.to(device),
+                  residual=res.to(device), relu=True, replicas=2)
+        got = ops.spconv_centre_tail(a, w.to(device), tmap, m, **kw)
+        assert torch.equal(got, ops.spconv_centre_tail(a, w.to(device), tmap, m, **kw))
+        one = ops.spconv_fwd(a, w.to(device), nbr, m, sparse_map=True, **kw)
+        assert torch.allclose(got, one, rtol=1e-4, atol=1e-4)
+        for r in range(2):
+            want = me.conv_forward(x[r * m:(r + 1) * m].double(), w.double(), nbr_np)
+            want = torch.relu(want * sc.double() + sh.double() + res[r * m:(r + 1) * m].double())
+            assert torch.allclose(got[r * m:(r + 1) * m].cpu().double(), want, rtol=RTOL, atol=ATOL), (cin, cout, r)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--lpt", action="store_true", help="128-row tiles in descending pair-count order (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
     ap.add_argument("--kernel", default="tile", choices=["tile", "dense", "dense1"], help="kernel of the dense 128-column layers")
+    ap.add_argument("--centre-tail", action="store_true", help="k3 layers as centre pass + tail rows (ops.spconv_centre_tail)")
     ap.add_argument("--timeline", action="store_true",
                     help="diagnostic build: per-workgroup cycle counters (prologue / main loop / epilogue / barrier / flush)")
     ap.add_argument("--probe", type=int, default=None,
@@ -100,13 +101,18 @@ def main():
                 "up": mgr.is_sparse_map(ts * 2, ts, 2, True), "k1": False}[kind]
         if args.sparse_hint >= 0:
             hint = bool(args.sparse_hint)
+        if args.centre_tail and kind == "k3":
+            tmap = ops.TailMap(nbr)
+            conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out)
+        else:
+            conv = lambda: ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
         for _ in range(3):
-            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
+            conv()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(args.iters):
-            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
+            conv()
         e.record()
         torch.cuda.synchronize()
         us = 1e3 * s.elapsed_time(e) / args.iters

@@ -97,50 +97,108 @@ def run_steps(pipe, x_init, xs, tvals, first, count, cache_condition=False):
 
 
 def cpu_baseline(scan_np, seed=42):
-    """The oracle (CPU restatement of the MinkowskiEngine/KeOps/diffusers CPU path) timed on this
-    box's host cores: ONE full denoising step at the LAST trajectory position (t=20, sigma=0.047,
-    the cheapest step) of the same 180k-point workload -- a bounded sample, not extrapolated."""
+    """The "MinkowskiEngine CPU path" timed on this box's host cores: the C++17 / OpenMP restatement
+    of ME's CPU algorithm (oracle/cpp/me_cpu_ref.cpp: hash-map coordinate maps, per-offset hash-probe kernel maps, per-offset
+    gather -> MKL SGEMM -> scatter-add in ascending kernel index) under the oracle's network code (torch-CPU Linear /
+    BatchNorm, as the reference's own Python runs them).  Sample = BASELINE configs[0] (C1): ONE full denoising step of
+    the 180k-point workload at T = 1 (t = 999, sigma = 0.985: the densest maps of the trajectory) -- CFG pair, DPM-Solver++
+    update, re-voxelisation.  A bounded sample, not extrapolated."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import build_seeded_models, diffusion_state_dict
+    from oracle import me_cpp
+    from oracle import me_cpu as me
     from oracle import minkunet_cpu as net
     from oracle.dpm_solver import DpmSolverSdeOracle
     enc, unet, _ = build_seeded_models(seed)
     sd = diffusion_state_dict(enc, unet)
     o = DpmSolverSdeOracle()
-    ts = o.set_timesteps(T_STEPS)
-    t = int(ts[-1])
+    ts = o.set_timesteps(1)
+    t = int(ts[0])
     rng = np.random.default_rng(seed)
     scan = np.tile(scan_np, (10, 1)).astype(np.float64)[None]
     x = scan + o.sigma_t[t] * rng.standard_normal(scan.shape)
     z = rng.standard_normal(scan.shape)
-    cores = torch.get_num_threads()
-    with torch.no_grad():
+    cores = me_cpp.threads()
+    model = "unknown CPU"
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    with torch.no_grad(), me.use_cpp():
         t0 = time.perf_counter()
         xf = net.points_to_field(torch.from_numpy(x).float())
         cf = net.points_to_field(torch.from_numpy(scan).float())
         uf = net.points_to_field(torch.zeros(1, scan.shape[1], 3))
         eps = net.classfree_forward(sd, xf, cf, uf, torch.tensor([t]), w=6.0).numpy()
         x_new = scan + o.step(eps, t, xf.F.numpy().reshape(1, -1, 3) - scan, z)
-        net.points_to_field(torch.from_numpy(x_new).float())
+        net.points_to_field(torch.from_numpy(x_new).float()).sparse()
         dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 full denoising step (CFG pair + DPM-Solver++ update + re-voxelisation) of the same "
-                      f"180k-point scan at trajectory position 50/50 (t={t}, sigma={o.sigma_t[t]:.3f}), "
-                      f"{dt:.1f} s wall, torch-CPU/MKL GEMMs on {cores} threads"}
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port", "cpu": model,
+            "sample": f"C1: 1 full denoising step (CFG pair + DPM-Solver++ update + re-voxelisation) of the same 180k-point "
+                      f"scan at T=1 (t={t}, sigma={o.sigma_t[t]:.3f}), {dt:.1f} s wall; C++17/OpenMP restatement of "
+                      f"MinkowskiEngine's CPU algorithm with MKL SGEMM (oracle/cpp/me_cpu_ref.cpp), torch-CPU MLPs, "
+                      f"{cores} OpenMP threads / {torch.get_num_threads()} torch threads on {model}"}
 
 
 def traffic_from_profile(variant):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_bench.sh ->
-    profiles/r01_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); None if that profile
-    is absent or belongs to another kernel.  PMC counters cannot be collected from inside this process."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    js = json.load(open(path))
+    """(HBM GB per launch of the dominant kernel, source) from the newest committed PMC passes (tools/pmc_bench.sh ->
+    profiles/rNN_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); (None, None) if no profile
+    belongs to that kernel.  PMC counters cannot be collected from inside this process, so this is a STATIC number of
+    the same kernel on the same workload, labelled as such in the line."""
+    import glob
     want = {"bn128": "<128, 8, 1", "bn96": "<128, 6, 1", "bn64": "<128, 4, 2", "bn32": "<128, 2, 4"}.get(variant)
-    if want is None or want not in js.get("kernel", ""):
-        return None
-    return js["traffic_bytes_per_launch"] / 1e9          # GB per launch (achieved/peak are TFLOP/s: see "traffic_unit")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        js = json.load(open(path))
+        if want is not None and want in js.get("kernel", ""):
+            return js["traffic_bytes_per_launch"] / 1e9, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def coords_roofline(scan_np, device, iters=5):
+    """The coordinate pipeline of ONE 180k-point x_t on its own, timed with HIP events on the launch stream: voxel hash
+    (unique / inverse / mean), four strided maps, five kernel_size-3 tables, four kernel_size-2 tables and their four
+    transposed tables -- the HBM-bound integer part of a step.  Algorithmic bytes: voxelise 16N + 12N +
+    8N + 28M0; strided map 16 M_l + 16 M_(l+1) + 4 M_l; kernel map 16 (M_in + M_out) + 8 P."""
+    import lidiff_amd.MinkowskiEngine as ME
+    rng = np.random.default_rng(0)
+    pts = torch.from_numpy(np.tile(scan_np, (10, 1)) + rng.standard_normal((N_POINTS, 3)).astype(np.float32)).to(device)
+    coord = torch.cat([torch.zeros(N_POINTS, 1, device=device), torch.round(pts / 0.05)], 1)
+
+    def build():
+        f = ME.TensorField(features=pts, coordinates=coord, device=device)
+        f.sparse()
+        mgr = f.coordinate_manager
+        ts = 1
+        for _ in range(4):
+            mgr.kernel_map(ts, ts, 3)
+            nxt = mgr.stride(ts, 2)
+            mgr.kernel_map(ts, nxt, 2)
+            mgr.kernel_map(nxt, ts, 2, True)
+            ts = nxt
+        mgr.kernel_map(ts, ts, 3)
+        return mgr
+    mgr = build()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        build()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    m = [mgr.maps[1 << l].coords.shape[0] for l in range(5)]
+    nbytes = 36.0 * N_POINTS + 28.0 * m[0]
+    for l in range(5):
+        p3 = int((mgr.kernel_map(1 << l, 1 << l, 3) >= 0).sum())
+        nbytes += 32.0 * m[l] + 8.0 * p3
+        if l < 4:
+            nbytes += 36.0 * m[l] + 16.0 * m[l + 1]                      # strided map
+            nbytes += 2 * (16.0 * (m[l] + m[l + 1]) + 8.0 * m[l])        # ks2 table and its transpose (P = M_l)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "coordinate pipeline of one 180000-point x_t (sigma 1): voxel hash + mean, 4 strided maps, 5 ks3 / 4 ks2 / "
+                      "4 transposed kernel maps (coords.hip; includes the host reads of the map sizes)",
+            "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "traffic": None, "ms": ms, "algorithmic_mbytes": nbytes / 1e6, "voxels_per_level": m}
 
 
 def spawn_ranks(args, argv):
@@ -192,6 +250,7 @@ def main():
     ap.add_argument("--all-variants", action="store_true",
                     help="time every sparse-conv launch, not only the dominant (BN=128) variant: more events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-coords-roofline", action="store_true", help="skip the coordinate-pipeline (HBM-bound) roofline leg")
     ap.add_argument("--cached-condition", action="store_true",
                     help="also time the same steps with the step-invariant conditions encoded once (reported beside the metric)")
     ap.add_argument("--dry-run", action="store_true",
@@ -275,20 +334,29 @@ def main():
         dom = max(summ, key=lambda v: summ[v]["ms"])
         d = summ[dom]
         tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = traffic_from_profile(dom)
+        step_flops = sum(v["flops"] for v in summ.values()) / args.steps
         out["roofline"] = {
             "kernel": f"spconv_fwd_kernel, BN={dom[2:]} output-channel tile ({dom})", "bound": "mfma",
             "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
-            "traffic": traffic_from_profile(dom), "launches": d["launches"], "avg_us": 1e3 * d["ms"] / d["launches"],
-            "traffic_unit": "GB per launch (HBM, rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+            "traffic": traffic, "launches": d["timed"], "avg_us": 1e3 * d["ms"] / max(1, d["timed"]),
+            "traffic_unit": "GB per launch (HBM-side, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": None if traffic is None else f"static: {traffic_src} (tools/pmc_bench.sh over this bench "
+                                                            "command; counters cannot be read inside the timed process)",
+            "step_frac": step_flops / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "step_conv_gflop": step_flops / 1e9,
             "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_gbytes_per_launch": d["bytes"] / d["launches"] / 1e9,
             "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
-            "timed_variants": sorted(summ),
+            "timed_variants": sorted(k for k, v in summ.items() if v["timed"]),
             "conv_ms_per_step_timed_variants": sum(v["ms"] for v in summ.values()) / args.steps,
             "variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                              "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
-                             "alg_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in summ.items()},
+                             "alg_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in summ.items() if v["timed"]},
         }
+    if world == 1 and not args.no_coords_roofline:
+        with torch.no_grad():
+            out["roofline_hbm"] = coords_roofline(scan_np, device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scan_np)
     print(json.dumps(out))

@@ -153,13 +153,15 @@ class ConvProfiler:
 
     def __init__(self, variants=None):
         self.variants = None if variants is None else set(variants)
-        self.launches = []          # (variant, start, end, m_in, m_out, c_in, c_out, k, nbr|None, replicas)
+        self.launches = []          # (variant, start|None, end|None, m_in, m_out, c_in, c_out, k, nbr|None, replicas)
 
     def wants(self, variant: str) -> bool:
         return self.variants is None or variant in self.variants
 
     def summary(self):
-        """{variant: dict(launches, ms, flops, bytes)} -- synchronises."""
+        """{variant: dict(launches, ms, flops, bytes, timed)} -- synchronises.  EVERY launch is counted (shapes are
+        host data, pair counts are taken after the run from the kept tables); `ms` covers the launches that carried
+        events (`timed` of them) -- all launches of the variants asked for."""
         torch.cuda.synchronize()
         counts = {}
         out = {}
@@ -172,9 +174,11 @@ class ConvProfiler:
                     counts[key] = int((nbr >= 0).sum().item())
                 p = counts[key]
             p, m_in, m_out = reps * p, reps * m_in, reps * m_out
-            d = out.setdefault(variant, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d = out.setdefault(variant, {"launches": 0, "timed": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
-            d["ms"] += start.elapsed_time(end)
+            if start is not None:
+                d["timed"] += 1
+                d["ms"] += start.elapsed_time(end)
             d["flops"] += 2.0 * p * c_in * c_out
             d["bytes"] += 4.0 * (m_in * c_in + m_out * c_out) + 4.0 * k * c_in * c_out + 8.0 * p
         return out
@@ -284,17 +288,18 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert t_ptr.dtype == torch.int32 and t_ptr.shape == (m_out + 1,) and t_idx.dtype == torch.int32
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
     prof = PROFILER
-    if prof is not None and not prof.wants(conv_variant(c_out)):
-        prof = None
-    if prof is not None:
+    timed = prof is not None and prof.wants(conv_variant(c_out))
+    start = end = None
+    if timed:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
          c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas),
          int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6}[kernel or DENSE_KERNEL],
          ptr(t_rows), ptr(t_ptr), ptr(t_idx), n_tail, stream_ptr())
-    if prof is not None:
+    if timed:
         end.record()
+    if prof is not None:
         prof.launches.append((conv_variant(c_out), start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
     return out
 

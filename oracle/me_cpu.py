@@ -30,6 +30,26 @@ import torch
 
 KEY_OFF = 32768  # each of (b,x,y,z) must lie in [-32768, 32767]
 
+# Backend of the primitives below: the numpy / torch-CPU restatement in this file, or -- inside ``with use_cpp():`` -- the
+# C++ / OpenMP restatement of ME's CPU algorithm (oracle/cpp/me_cpu_ref.cpp through oracle/me_cpp.py: hash-map maps,
+# per-offset gather -> MKL SGEMM -> scatter-add).  Both are cross-checked in tests/test_oracle.py; the C++ one is the
+# "MinkowskiEngine CPU path" bench.py times beside the GPU numbers (fp32 features only; no autograd).
+_CPP = False
+
+
+class use_cpp:
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _CPP
+        self.prev, _CPP = _CPP, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _CPP
+        _CPP = self.prev
+
 
 # --------------------------------------------------------------------------------------
 # coordinates
@@ -67,6 +87,9 @@ def voxelize(coords: np.ndarray):
     """``TensorField.sparse()`` coordinate part (pipeline:149; models.py:99,202;
     minkunet.py:135,597): unique voxel rows in first-occurrence order, the inverse map
     (point -> voxel row, int64) and the index of the first point of every voxel."""
+    if _CPP:
+        from . import me_cpp
+        return me_cpp.voxelize(coords)
     coords = np.asarray(coords, dtype=np.int32)
     if coords.shape[0] == 0:
         return coords.reshape(0, 4), np.zeros(0, np.int64), np.zeros(0, np.int32)
@@ -84,6 +107,9 @@ def voxelize(coords: np.ndarray):
 def voxel_mean(feats: torch.Tensor, inverse: np.ndarray, n_vox: int) -> torch.Tensor:
     """UNWEIGHTED_AVERAGE quantisation (pipeline:77; Appendix A.3): per-voxel mean of the
     member points' features (fp32 accumulation in point order, then divide)."""
+    if _CPP:
+        from . import me_cpp
+        return me_cpp.voxel_mean(feats, inverse, n_vox)
     inv = torch.as_tensor(inverse, dtype=torch.int64)
     out = torch.zeros(n_vox, feats.shape[1], dtype=feats.dtype)
     out.index_add_(0, inv, feats)
@@ -102,6 +128,9 @@ def stride_map(coords: np.ndarray, s_out: int):
     """Coordinate map of a strided convolution (minkunet.py:13-29 used at 103-121,
     184-259, 521-539; Appendix A.5): c_out = floor(c/s_out)*s_out, deduplicated in order
     of first occurrence over the finer rows.  Returns (coarse rows, parent[M_fine])."""
+    if _CPP:
+        from . import me_cpp
+        return me_cpp.stride_map(coords, s_out)
     coarse, parent, _ = voxelize(floor_to_stride(coords, s_out))
     return coarse, parent.astype(np.int32)
 
@@ -120,6 +149,9 @@ def kernel_map(in_coords: np.ndarray, out_coords: np.ndarray, ks: int, ts_in: in
     nbr[k, o] = row of in_coords equal to out_coords[o] + offset_k * ts_in, else -1.
     ks=3/stride 1: in == out map (minkunet.py:53-66,94,97,156,159,512,515);
     ks=2/stride 2: out = coarse map, in = fine map (minkunet.py:13-29)."""
+    if _CPP:
+        from . import me_cpp
+        return me_cpp.kernel_map(in_coords, out_coords, ks, ts_in)
     in_coords = np.asarray(in_coords, np.int32)
     out_coords = np.asarray(out_coords, np.int32)
     offs = kernel_offsets(ks)
@@ -173,6 +205,9 @@ def conv_forward(feats: torch.Tensor, kernel: torch.Tensor, nbr: np.ndarray | No
     A.6): for k ascending: gather rows -> buf @ W[k] -> out[out_row] += res.
     ``kernel`` is [K,Cin,Cout], or [Cin,Cout] for kernel_size=1 (``F.mm(kernel)``,
     minkunet.py:72)."""
+    if _CPP and feats.dtype == torch.float32 and not (feats.requires_grad or kernel.requires_grad):
+        from . import me_cpp
+        return me_cpp.conv_forward(feats, kernel, nbr)
     if kernel.dim() == 2:
         return feats @ kernel
     K, _, cout = kernel.shape
@@ -196,6 +231,9 @@ def argmin_match(full_c: np.ndarray, part_c: np.ndarray) -> np.ndarray:
     index of the nearest part voxel by squared L2 over (b*2*max_coord, x, y, z); ties go
     to the lowest index (KeOps argKmin, Appendix A.9).  Exact integer arithmetic (the
     reference's fp32 is exact for |c| < 2^12, which LiDiff's coordinates satisfy)."""
+    if _CPP:
+        from . import me_cpp
+        return me_cpp.argmin_match(full_c, part_c)
     f = np.asarray(full_c, np.int64).copy()
     p = np.asarray(part_c, np.int64).copy()
     scale = int(f.max()) * 2

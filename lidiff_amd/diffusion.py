@@ -78,13 +78,19 @@ class DiffusionPoints(nn.Module):
         return TF.mse_loss(y, noise)
 
     # models.py:180-217
-    def training_step(self, batch: dict, batch_idx=0, generator=None):
+    def training_step(self, batch: dict, batch_idx=0, generator=None, noise=None, t=None, drop=None):
+        """noise / t / drop: the step's random draws, injectable (parity tests share them with the CPU oracle, whose RNG
+        is not the device's); None = drawn here as the reference does."""
         pcd_full = batch["pcd_full"].to(self.device)
-        noise = torch.randn(pcd_full.shape, device=self.device, generator=generator)
-        t = torch.randint(0, self.t_steps, size=(pcd_full.shape[0],), device=self.device, generator=generator)
+        if noise is None:
+            noise = torch.randn(pcd_full.shape, device=self.device, generator=generator)
+        if t is None:
+            t = torch.randint(0, self.t_steps, size=(pcd_full.shape[0],), device=self.device, generator=generator)
+        noise, t = noise.to(self.device), t.to(self.device)
         t_sample = pcd_full + self.q_sample(torch.zeros_like(pcd_full), t, noise)
         x_full = self.points_to_tensor(t_sample)
-        drop = torch.rand(1, generator=generator, device=self.device).item() <= self.hparams["train"]["uncond_prob"]
+        if drop is None:
+            drop = torch.rand(1, generator=generator, device=self.device).item() <= self.hparams["train"]["uncond_prob"]
         pcd_part = batch["pcd_part"].to(self.device)
         if not drop or pcd_full.shape[0] == 1:
             x_part = self.points_to_tensor(pcd_part)

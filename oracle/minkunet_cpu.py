@@ -18,7 +18,26 @@ import torch.nn.functional as TF
 from . import me_cpu as me
 
 
+_TRAIN = False
+
+
+class train_mode:
+    """``with train_mode():`` -- BatchNorm uses the statistics of the batch (nn.BatchNorm1d in training mode on the rows
+    of F, eps 1e-5; Appendix A.8) instead of the running ones: the forward of DiffusionPoints.training_step
+    (models.py:180-217).  The running statistics in `sd` are left untouched (the tests compare losses and gradients)."""
+
+    def __enter__(self):
+        global _TRAIN
+        self.prev, _TRAIN = _TRAIN, True
+
+    def __exit__(self, *exc):
+        global _TRAIN
+        _TRAIN = self.prev
+
+
 def _bn(sd, p, x):
+    if _TRAIN:
+        return TF.batch_norm(x, None, None, sd[p + ".bn.weight"], sd[p + ".bn.bias"], training=True, eps=1e-5)
     return me.batch_norm_eval(x, sd[p + ".bn.weight"], sd[p + ".bn.bias"],
                               sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"])
 
@@ -162,3 +181,22 @@ def classfree_forward(sd, x_field, cond_field, uncond_field, t, w=6.0):
     e_c = denoise_forward(sd, x_field, xs, cond_field, t)
     e_u = denoise_forward(sd, x_field, xs, uncond_field, t)
     return e_u + w * (e_c - e_u)
+
+
+
+def training_loss(sd, pcd_full: torch.Tensor, pcd_part: torch.Tensor, noise: torch.Tensor, t: torch.Tensor,
+                  drop_condition: bool = False, reg_weight: float = 5.0, beta_start=3.5e-5, beta_end=0.007, t_steps=1000):
+    """DiffusionPoints.training_step (lidiff/models/models.py:180-217) as a function of the state dict, differentiable by
+    torch autograd through the oracle's operators: t_sample = pcd_full + sqrt(1 - acp[t]) * noise (q_sample of zeros,
+    :94-96,189), points_to_tensor without dividing the batch column (:162-178), single forward with the condition zeroed
+    when `drop_condition` (:195-200), loss = mse + reg_weight * (mean^2 + (std - 1)^2) (:203-206).  Train-mode BatchNorm."""
+    betas = torch.linspace(beta_start, beta_end, t_steps)                                    # scheduling.py:15-16
+    acp = torch.tensor(np.cumprod((1.0 - betas).numpy(), axis=0), dtype=torch.float32)       # models.py:37-39
+    t_sample = pcd_full + torch.sqrt(1.0 - acp)[t][:, None, None] * noise
+    x_full = points_to_field(t_sample, divide_batch_col=False)
+    x_part = points_to_field(torch.zeros_like(pcd_part) if drop_condition else pcd_part, divide_batch_col=False)
+    with train_mode():
+        denoise_t = denoise_forward(sd, x_full, x_full.sparse(), x_part, t)
+    loss_mse = TF.mse_loss(denoise_t, noise)
+    loss = loss_mse + reg_weight * (denoise_t.mean() ** 2 + (denoise_t.std() - 1.0) ** 2)
+    return loss, denoise_t

@@ -526,3 +526,32 @@ def test_spconv_centre_tail_vs_oracle(device, cin, cout, split):
             want = me.conv_forward(x[r * m:(r + 1) * m].double(), w.double(), nbr_np)
             want = torch.relu(want * sc.double() + sh.double() + res[r * m:(r + 1) * m].double())
             assert torch.allclose(got[r * m:(r + 1) * m].cpu().double(), want, rtol=RTOL, atol=ATOL), (cin, cout, r)
+
+
+def test_voxel_mean_and_slice_backward_vs_autograd(device):
+    """The backward of TensorField.sparse() (UNWEIGHTED_AVERAGE: lidiff_vox_mean_bwd) and of SparseTensor.slice
+    (scatter-add of the point gradients into the voxel rows) against torch autograd through the oracle's formulation."""
+    import lidiff_amd.MinkowskiEngine as ME
+    from lidiff_amd import ops
+    coords = random_cloud(5000, 8, 77, batch=2)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(coords.shape[0], 3, generator=g)
+    r = torch.randn(coords.shape[0], 7, generator=g)
+    fd = feats.to(device).requires_grad_(True)
+    field = ME.TensorField(features=fd, coordinates=torch.from_numpy(coords).float().to(device), device=device)
+    sp = field.sparse()
+    w = torch.randn(3, 7, generator=g)
+    y = ME.SparseTensor(sp.F @ w.to(device), tensor_stride=1, coordinate_manager=sp.coordinate_manager).slice(field).F
+    (y * r.to(device)).sum().backward()
+    uniq, inv, _ = me.voxelize(coords)
+    fo = feats.clone().requires_grad_(True)
+    vox = me.voxel_mean(fo, inv, uniq.shape[0])
+    yo = (vox @ w)[torch.from_numpy(inv)]
+    (yo * r).sum().backward()
+    assert torch.allclose(y.detach().cpu(), yo.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(fd.grad.cpu(), fo.grad, rtol=1e-4, atol=1e-5)
+    # the two kernels directly
+    gv = torch.randn(uniq.shape[0], 3, generator=g)
+    counts = torch.from_numpy(np.bincount(inv, minlength=uniq.shape[0]).astype(np.float32))
+    got = ops.vox_mean_bwd(gv.to(device), torch.from_numpy(inv).to(device), counts.to(device)).cpu()
+    assert torch.allclose(got, gv[torch.from_numpy(inv)] / counts[torch.from_numpy(inv)][:, None], rtol=1e-6, atol=1e-7)

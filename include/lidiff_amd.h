@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 10
+#define LIDIFF_ABI_VERSION 11
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -169,13 +169,17 @@ int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int3
 /* Weight gradient of lidiff_spconv_fwd (training path, models.py:180-217; ME: ConvolutionBackwardGPU):
  * dw[k] += gather(in)[pairs_in of offset k]^T @ grad_out[pairs_out of offset k], in = [in_a | in_b], over the
  * ME-layout rulebook of the kernel map (lidiff_rulebook_compact: pairs sorted by offset, offset_ptr [K+1] on the
- * device, n_pairs = offset_ptr[K] known to the host); all three null = identity map (K = 1).  dw [K, c_in, c_out]
- * must be zeroed by the caller (pair slices are summed with fp32 atomics).  Channel counts multiples of 4.  The
- * input gradient needs no entry point of its own: it is lidiff_spconv_fwd over the swapped map with W^T. */
+ * device, n_pairs = offset_ptr[K] known to the host); all three null = identity map (K = 1).  The pairs of an offset are
+ * cut into slices, one workgroup each.  With `workspace` (lidiff_spconv_bwd_w_workspace_floats floats) every slice stores
+ * its partial tile and a second kernel sums them in slice order: dw is DETERMINISTIC and need not be zeroed.  With
+ * workspace == NULL the slices meet in dw by fp32 atomics (as ME's GPU path does): dw must be zeroed by the caller and is
+ * reproducible only up to the order of those adds.  Channel counts multiples of 4.  The input gradient needs no entry
+ * point of its own: it is lidiff_spconv_fwd over the swapped map with W^T. */
+int64_t lidiff_spconv_bwd_w_workspace_floats(int32_t c_in, int32_t c_out, int32_t k_vol, int64_t n_pairs);
 int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
                         const float* grad_out, const int32_t* pairs_in, const int32_t* pairs_out,
                         const int32_t* offset_ptr, int64_t n_pairs, int32_t k_vol,
-                        int64_t m_in, int64_t m_out, int32_t c_out, float* dw, void* stream);
+                        int64_t m_in, int64_t m_out, int32_t c_out, float* dw, float* workspace, void* stream);
 
 /* Row gather / scatter-add -- SparseTensor.slice(field).F minkunet.py:497,619 and the
  * x_part.F[idx] of match_part_to_full minkunet.py:418; scatter-add is their backward. */

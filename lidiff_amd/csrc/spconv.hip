@@ -770,7 +770,8 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
                                                            const float* __restrict__ g, const int32_t* __restrict__ pairs_in,
                                                            const int32_t* __restrict__ pairs_out,
                                                            const int32_t* __restrict__ offset_ptr, int64_t m_out,
-                                                           int c_out, int slices, float* __restrict__ dw) {
+                                                           int c_out, int slices, float* __restrict__ dw,
+                                                           float* __restrict__ part, int k_vol) {
     constexpr int CIT = 16 * NBI, COT = 128 * CB;        // tile extents
     constexpr int PA = CIT + 16, PG = COT + 16;          // LDS row pitches (words): = 16 mod 32
     constexpr int A4 = kDwPairs * (CIT / 4), G4 = kDwPairs * (COT / 4);   // float4 pieces per chunk
@@ -815,15 +816,15 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
         for (int t = 0; t < NA; ++t) {
             const int e = tid + 512 * t, ec = min(e, A4 - 1), pr = ec / (CIT / 4), ci = ci0 + (ec % (CIT / 4)) * 4;
             const int cic = min(ci, c_in - 4);
-            const float* src = cic < c_in_a ? in_a + (int64_t)ra[t] * c_in_a + cic
-                                            : in_b + (int64_t)ra[t] * c_in_b + (cic - c_in_a);
+            const float* src = cic < c_in_a ? in_a + (unsigned)(ra[t] * c_in_a + cic)
+                                            : in_b + (unsigned)(ra[t] * c_in_b + (cic - c_in_a));
             pa[t] = *reinterpret_cast<const float4*>(src);
             keep |= (e < A4 && base + pr < s_hi && ci < c_in) ? 1u << t : 0u;
         }
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
             const int e = tid + 512 * t, ec = min(e, G4 - 1), pr = ec / (COT / 4), co = co0 + (ec % (COT / 4)) * 4;
-            pg[t] = *reinterpret_cast<const float4*>(g + (int64_t)rg[t] * c_out + min(co, c_out - 4));
+            pg[t] = *reinterpret_cast<const float4*>(g + (unsigned)(rg[t] * c_out + min(co, c_out - 4)));
             keep |= (e < G4 && base + pr < s_hi && co < c_out) ? 1u << (16 + t) : 0u;
         }
     };
@@ -872,8 +873,9 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
             }
         }
     }
-    // D layout: col = lane & 15 (co), row = 4 (lane >> 4) + reg (ci)
-    float* dwk = dw + (int64_t)k * c_in * c_out;
+    // D layout: col = lane & 15 (co), row = 4 (lane >> 4) + reg (ci).  With a workspace every pair slice stores its partial
+    // tile (summed in slice order by dw_reduce_kernel: deterministic); without one the slices meet in dw by fp32 atomics.
+    float* dwk = part ? part + ((int64_t)blockIdx.z * k_vol + k) * c_in * c_out : dw + (int64_t)k * c_in * c_out;
 #pragma unroll
     for (int b = 0; b < NBI; ++b)
 #pragma unroll
@@ -881,15 +883,34 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci0 + 16 * b + 4 * lq + r, co = co0 + 16 * (CB * wave + c) + li;
-                if (ci < c_in && co < c_out && acc[b][c][r] != 0.f)
-                    atomicAdd(dwk + (int64_t)ci * c_out + co, acc[b][c][r]);
+                if (ci < c_in && co < c_out) {
+                    if (part) dwk[(int64_t)ci * c_out + co] = acc[b][c][r];
+                    else if (acc[b][c][r] != 0.f) atomicAdd(dwk + (int64_t)ci * c_out + co, acc[b][c][r]);
+                }
             }
+}
+
+// dw[e] = sum over the pair slices, in slice order (slices that held no pairs of an offset were pre-zeroed)
+__global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n, int slices, float* __restrict__ dw) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float v = 0.f;
+    for (int s = 0; s < slices; ++s) v += part[(int64_t)s * n + e];
+    dw[e] = v;
+}
+
+static int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot) {
+    const int tiles = (int)(ceil_div(c_in, cit) * ceil_div(c_out, cot));
+    // pair slices: a few workgroups per CU, but at least 4 chunks each (pairs spread evenly over the offsets)
+    int64_t slices = ceil_div((int64_t)1024, (int64_t)tiles * k_vol);
+    const int64_t max_slices = max((int64_t)1, n_pairs / k_vol / (4 * kDwPairs));
+    return max((int64_t)1, min(slices, max_slices));
 }
 
 template <int NBI, int CB, bool IDENT>
 static int launch_bwd_w(const float* in_a, int c_in_a, const float* in_b, int c_in_b, const float* g,
                         const int32_t* pin, const int32_t* pout, const int32_t* off, int k_vol, int64_t m_out,
-                        int64_t n_pairs, int c_out, float* dw, hipStream_t st) {
+                        int64_t n_pairs, int c_out, float* dw, float* workspace, hipStream_t st) {
     constexpr int CIT = 16 * NBI, COT = 128 * CB;
     const size_t lds = (size_t)kDwPairs * ((CIT + 16) + (COT + 16)) * 4;
     auto kern = spconv_bwd_w_kernel<NBI, CB, IDENT>;
@@ -901,22 +922,29 @@ static int launch_bwd_w(const float* in_a, int c_in_a, const float* in_b, int c_
     }
     const int c_in = c_in_a + c_in_b;
     const int tiles = (int)(ceil_div(c_in, CIT) * ceil_div(c_out, COT));
-    // pair slices: a few workgroups per CU, but at least 4 chunks each (pairs spread evenly over the offsets)
-    int64_t slices = ceil_div((int64_t)1024, (int64_t)tiles * k_vol);
-    const int64_t max_slices = max((int64_t)1, n_pairs / k_vol / (4 * kDwPairs));
-    slices = max((int64_t)1, min(slices, max_slices));
+    const int64_t slices = dw_slices(c_in, c_out, k_vol, n_pairs, CIT, COT);
+    const int64_t n = (int64_t)k_vol * c_in * c_out;
+    float* part = (workspace != nullptr && slices > 1) ? workspace : nullptr;
+    if (part) LIDIFF_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)slices * n * sizeof(float), st));
     hipLaunchKernelGGL(kern, dim3((unsigned)k_vol, (unsigned)tiles, (unsigned)slices), dim3(512), lds, st, in_a, c_in_a,
-                       in_b, c_in_b, g, pin, pout, off, m_out, c_out, (int)slices, dw);
+                       in_b, c_in_b, g, pin, pout, off, m_out, c_out, (int)slices, dw, part, k_vol);
+    if (part) dw_reduce_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(part, n, (int)slices, dw);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
 
 }  // namespace lidiff
 
+extern "C" int64_t lidiff_spconv_bwd_w_workspace_floats(int32_t c_in, int32_t c_out, int32_t k_vol, int64_t n_pairs) {
+    const int nbi = c_in > 128 ? 16 : c_in > 64 ? 8 : c_in > 32 ? 4 : 2;
+    const int64_t slices = dw_slices(c_in, c_out, k_vol, n_pairs > 0 ? n_pairs : 1, 16 * nbi, c_out > 128 ? 256 : 128);
+    return slices > 1 ? slices * k_vol * (int64_t)c_in * c_out : 0;
+}
+
 extern "C" int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
                                    const float* grad_out, const int32_t* pairs_in, const int32_t* pairs_out,
                                    const int32_t* offset_ptr, int64_t n_pairs, int32_t k_vol, int64_t m_in,
-                                   int64_t m_out, int32_t c_out, float* dw, void* stream) {
+                                   int64_t m_out, int32_t c_out, float* dw, float* workspace, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && grad_out != nullptr && dw != nullptr, "null pointer");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
@@ -926,6 +954,8 @@ extern "C" int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const floa
     LIDIFF_CHECK_ARG(c_in_a % 4 == 0 && c_in_b % 4 == 0 && c_out % 4 == 0, "channel counts must be multiples of 4");
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(in_a) && al16(in_b) && al16(grad_out), "feature pointers must be 16-byte aligned");
+    LIDIFF_CHECK_ARG(m_in * (int64_t)(c_in_a > c_in_b ? c_in_a : c_in_b) < (1ll << 31) && m_out * (int64_t)c_out < (1ll << 31),
+                     "a feature matrix exceeds 2^31 elements (32-bit row offsets)");
     if (identity) n_pairs = m_out;
     if (m_out == 0 || n_pairs <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -933,9 +963,9 @@ extern "C" int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const floa
     const int nbi = c_in > 128 ? 16 : c_in > 64 ? 8 : c_in > 32 ? 4 : 2;      // ci blocks of the tile (<= 256 channels)
 #define LIDIFF_DW(NBI, CB)                                                                                          \
     return identity ? launch_bwd_w<NBI, CB, true>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr,  \
-                                                  k_vol, m_out, n_pairs, c_out, dw, st)                                \
+                                                  k_vol, m_out, n_pairs, c_out, dw, workspace, st)                     \
                     : launch_bwd_w<NBI, CB, false>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr, \
-                                                   k_vol, m_out, n_pairs, c_out, dw, st)
+                                                   k_vol, m_out, n_pairs, c_out, dw, workspace, st)
     if (c_out > 128) {
         if (nbi == 16) LIDIFF_DW(16, 2);
         if (nbi == 8) LIDIFF_DW(8, 2);

@@ -185,6 +185,8 @@ class ConvProfiler:
 
 
 PROFILER: ConvProfiler | None = None
+# weight gradients: pair slices summed in slice order through a workspace (bit-reproducible); False = fp32 atomics
+DETERMINISTIC_DW = True
 # Kernel choice for the dense 128-column layers: "tile" (spconv.hip, default), "dense" (spconv_dense.hip, eight waves),
 # "dense1" (its four-wave form).  Results are bit-identical; DESIGN.md section 4.2 has the measurements.
 DENSE_KERNEL = os.environ.get("LIDIFF_CONV_KERNEL", "tile")
@@ -327,10 +329,15 @@ def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None) -> torch.Tensor:
     if c_a % 4 == 0 and c_b % 4 == 0 and c_out % 4 == 0:
         if in_b is not None:
             in_b = in_b.contiguous()
-        dw = torch.zeros((k, c_a + c_b, c_out), dtype=torch.float32, device=in_a.device)
         pin, pout, off, n_pairs = (None, None, None, m_out) if nbr is None else rulebook_of(nbr)
+        ws = None
+        if DETERMINISTIC_DW:            # pair slices summed in a fixed order through a workspace (no atomics)
+            nws = _lib.load().lidiff_spconv_bwd_w_workspace_floats(c_a + c_b, c_out, k, n_pairs)
+            ws = torch.empty(nws, dtype=torch.float32, device=in_a.device) if nws else None
+        alloc = torch.empty if ws is not None else torch.zeros
+        dw = alloc((k, c_a + c_b, c_out), dtype=torch.float32, device=in_a.device)
         call("lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out), ptr(pin), ptr(pout), ptr(off),
-             n_pairs, k, in_a.shape[0], m_out, c_out, ptr(dw), stream_ptr())
+             n_pairs, k, in_a.shape[0], m_out, c_out, ptr(dw), ptr(ws), stream_ptr())
         return dw
     x = in_a if in_b is None else torch.cat([in_a, in_b], dim=1)
     if nbr is None:                                   # kernel_size 1: identity map

@@ -200,3 +200,22 @@ def training_loss(sd, pcd_full: torch.Tensor, pcd_part: torch.Tensor, noise: tor
     loss_mse = TF.mse_loss(denoise_t, noise)
     loss = loss_mse + reg_weight * (denoise_t.mean() ** 2 + (denoise_t.std() - 1.0) ** 2)
     return loss, denoise_t
+
+
+def refine_training_loss(sd, pcd_noise: torch.Tensor, pcd_full: torch.Tensor, up_factor: int = 6):
+    """RefineDiffusion.training_step (lidiff/models/models_refine.py:53-76) as a function of the state dict: voxelise the
+    noisy cloud with the batch column divided too (:54-56, App. D.2), MinkUNet -> 6 offsets per point (:69-70), pytorch3d
+    chamfer_distance defaults against pcd_full (:72: squared K=1 distances, mean over points, both directions added, batch
+    mean).  The nearest-neighbour indices come from an exact KD-tree (oracle/metrics_cpu.py), the distances are re-formed
+    from the matched rows in torch, so the loss is differentiable as pytorch3d's knn_gather formulation is."""
+    from scipy.spatial import cKDTree
+    field = points_to_field(pcd_noise, divide_batch_col=True)
+    with train_mode():
+        offset = unet_refine_forward(sd, field).reshape(-1, up_factor, 3)
+    pred = (field.F[:, None, :] + offset).reshape(pcd_full.shape[0], -1, 3)
+    total = pred.new_zeros(())
+    for p, q in zip(pred, pcd_full.float()):
+        j = torch.from_numpy(cKDTree(q.numpy().astype(np.float64)).query(p.detach().numpy().astype(np.float64))[1])
+        i = torch.from_numpy(cKDTree(p.detach().numpy().astype(np.float64)).query(q.numpy().astype(np.float64))[1])
+        total = total + (p - q[j]).square().sum(1).mean() + (q - p[i]).square().sum(1).mean()
+    return total / pred.shape[0]

@@ -320,6 +320,20 @@ def test_spconv_backward_vs_oracle_autograd(device, kind, ks, stride, cin, cout)
     (yo * r.double()).sum().backward()
     assert torch.allclose(x.F.grad.cpu().double(), xo.grad, rtol=1e-4, atol=1e-4), "dX"
     assert torch.allclose(mod.kernel.grad.cpu().double(), wo.grad, rtol=1e-4, atol=1e-3), "dW"
+    # dW is bit-reproducible (pair slices summed in slice order through a workspace), and the atomic form agrees with it
+    from lidiff_amd import ops
+    g1 = mod.kernel.grad.clone()
+    mod.kernel.grad = None
+    x.F.grad = None
+    (mod(x).F * r.to(device)).sum().backward()
+    assert torch.equal(mod.kernel.grad, g1), "dW not deterministic"
+    ops.DETERMINISTIC_DW = False
+    try:
+        mod.kernel.grad = None
+        (mod(x).F * r.to(device)).sum().backward()
+        assert torch.allclose(mod.kernel.grad, g1, rtol=1e-4, atol=1e-4), "atomic dW"
+    finally:
+        ops.DETERMINISTIC_DW = True
 
 
 def test_gather_scatter_rows(device):

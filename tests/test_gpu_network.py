@@ -366,3 +366,102 @@ def test_training_step_loss_and_gradients_vs_oracle(device, drop):
     assert compared >= (150 if drop else 300), compared
     print(f"training step drop={drop}: loss {l_d:.7f} vs oracle {l_o:.7f}; {compared} gradients; worst cosine "
           f"{worst_cos[1]:.6f} ({worst_cos[0]}), worst norm deviation {worst_norm[1]:.2e} ({worst_norm[0]})")
+
+
+def test_refine_training_step_loss_and_gradients_vs_oracle(device):
+    """RefineDiffusion.training_step (models_refine.py:53-76): voxelisation with the divided batch column, MinkUNet in
+    training mode, Chamfer loss on the HIP nearest-neighbour kernel -- loss and every gradient against the oracle
+    (KD-tree matches, torch autograd).  Same bars as the diffusion step."""
+    import lidiff_amd.MinkowskiEngine as ME
+    from lidiff_amd.diffusion import RefineDiffusion
+    torch.manual_seed(5)
+    ref = RefineDiffusion(device=device)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.8, 1.2)
+            m.bias.data.normal_(0, 0.1)
+    ref.train()
+    sd = {k[len("model_refine."):]: v.detach().cpu().clone() for k, v in ref.state_dict().items()}
+    for k, v in sd.items():
+        v.requires_grad_(v.is_floating_point() and "running" not in k)
+    scan, noisy = small_scene(seed=13, n=1500)
+    pcd_noise = torch.from_numpy(np.stack([noisy, noisy[::-1].copy() + np.float32(0.21)]))
+    pcd_full = torch.from_numpy(np.stack([scan, scan[::-1].copy() + np.float32(0.21)]))
+    # CPU-rounded coordinates on both sides (App. E): patch the module's field construction for the test
+    orig = ME.TensorField
+
+    class field_cpu_rounded(orig):
+        def __init__(self, features, coordinates, **kw):
+            cpu = net.points_to_field(pcd_noise, divide_batch_col=True)
+            super().__init__(features=features, coordinates=cpu.coords_f.to(device), **kw)
+    ME.TensorField = field_cpu_rounded
+    try:
+        loss = ref.training_step({"pcd_noise": pcd_noise, "pcd_full": pcd_full})
+    finally:
+        ME.TensorField = orig
+    ref.zero_grad(set_to_none=True)
+    loss.backward()
+    loss_o = net.refine_training_loss(sd, pcd_noise, pcd_full)
+    names = [k for k, v in sd.items() if v.requires_grad]
+    grads_o = torch.autograd.grad(loss_o, [sd[k] for k in names], allow_unused=True)
+    l_d, l_o = float(loss.detach()), float(loss_o.detach())
+    assert abs(l_d - l_o) <= 1e-5 * abs(l_o), (l_d, l_o)
+    params = dict(ref.model_refine.named_parameters())
+    compared, worst = 0, ("", 1.0)
+    for k, go in zip(names, grads_o):
+        if go is None or float(go.norm()) <= 1e-9:
+            continue
+        gd = params[k].grad.detach().cpu()
+        cos = float((gd * go).sum() / (gd.norm() * go.norm()))
+        nrel = abs(float(gd.norm()) - float(go.norm())) / float(go.norm())
+        worst = min(worst, (k, cos), key=lambda q: q[1])
+        assert cos >= 0.9999 and nrel <= 2e-3, (k, cos, nrel)
+        compared += 1
+    assert compared >= 150, compared                              # MinkUNet: 151 parameter tensors
+    print(f"refine training step: loss {l_d:.7f} vs oracle {l_o:.7f}; {compared} gradients, worst cosine {worst[1]:.6f} ({worst[0]})")
+
+
+def _two_rank_train_worker(rank, world, port, q):
+    import torch.distributed as tdist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from lidiff_amd import dist as ldist
+    from lidiff_amd.diffusion import DiffusionPoints, train_loop
+    ldist.init_from_env("nccl")
+    dev = torch.device("cuda", rank)
+    torch.manual_seed(100 + rank)                                 # different initial weights: the broadcast must fix that
+    mod = DiffusionPoints(device=dev)
+    scan, _ = small_scene(seed=9, n=600)
+    full = torch.from_numpy(np.stack([scan, scan[::-1].copy()]))
+    batches = [{"pcd_full": full + 0.01 * i, "pcd_part": full[:, :60].contiguous() + 0.01 * i} for i in range(4)]
+    losses = train_loop(mod, batches, steps=3)
+    sync_bn = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in mod.modules())
+    w = mod.model.stage3[1].net[0].kernel.detach().float().cpu()
+    rm = mod.model.stem[1].bn.running_mean.detach().cpu()
+    q.put((rank, losses, sync_bn, w.sum().item(), w.abs().sum().item(), rm.tolist()))
+    tdist.destroy_process_group()
+
+
+def test_two_rank_train_loop_rccl_syncbn(device):
+    """train.py:88-101 on two GPUs: MinkowskiSyncBatchNorm conversion, broadcast of rank 0's weights, rank-sharded batches,
+    bucketed gradient all-reduce over RCCL, Adam -- after 3 steps both ranks hold bit-identical weights and (SyncBatchNorm:
+    statistics all-reduced) identical running means.  Skipped (and reported as skipped) on a box with one GPU."""
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs, this box shows {torch.cuda.device_count()}")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=600) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] > 50 and res[0][1] == res[1][1]              # every BatchNorm became a SyncBatchNorm
+    assert res[0][2:4] == res[1][2:4] and res[0][4] == res[1][4]  # weights and synced running statistics agree
+    assert all(np.isfinite(res[r][0]).all() for r in (0, 1))

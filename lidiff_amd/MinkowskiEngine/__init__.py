@@ -179,9 +179,13 @@ class _SparseConv(torch.autograd.Function):
     with W^T (for a centred odd kernel on one map the swap is k -> K-1-k); dW = gather^T @ g."""
 
     @staticmethod
-    def forward(ctx, x, kernel, nbr, nbr_swapped, m_out, flip):
+    def forward(ctx, x, kernel, nbr, nbr_swapped, m_out, flip, sparse_map=False):
         ctx.save_for_backward(x, kernel, nbr, nbr_swapped)
         ctx.flip = flip
+        w3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
+        ctx.bf16 = ops.TRAIN_OPERANDS == "bf16" and ops.bf16_conv_applies(w3.shape[1], 0, w3.shape[2], sparse_map)
+        if ctx.bf16:
+            return ops.spconv_fwd_bf16(x, kernel, nbr, m_out)
         return ops.spconv_fwd(x, kernel, nbr, m_out)
 
     @staticmethod
@@ -190,12 +194,14 @@ class _SparseConv(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = None
         w3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.bf16:
+            gx = ops.spconv_fwd_bf16(g, kernel, nbr_swapped, x.shape[0], transposed=True, flip=ctx.flip)
+        elif ctx.needs_input_grad[0]:
             wt = (w3.flip(0) if ctx.flip else w3).transpose(1, 2).contiguous()
             gx = ops.spconv_fwd(g, wt, nbr_swapped, x.shape[0])
         if ctx.needs_input_grad[1]:
             gw = ops.spconv_bwd_w(x, g, nbr, w3.shape[0]).reshape(kernel.shape)
-        return gx, gw, None, None, None, None
+        return gx, gw, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------
@@ -382,7 +388,7 @@ class _ConvBase(nn.Module):
         mgr = x.coordinate_manager
         m_out = mgr.maps[ts_out].coords.shape[0]
         if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad):
-            f = _SparseConv.apply(x.F, self.kernel, nbr, nbr_sw, m_out, flip)
+            f = _SparseConv.apply(x.F, self.kernel, nbr, nbr_sw, m_out, flip, self.sparse_hint(x, ts_out))
         else:
             f = ops.spconv_fwd(x.F, self.kernel, nbr, m_out, sparse_map=self.sparse_hint(x, ts_out))
         return SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)

@@ -1,0 +1,313 @@
+// Sparse convolution with bf16 operands and fp32 accumulation (v_mfma_f32_16x16x32_bf16) -- BASELINE.json configs[4]:
+// "train.py diffusion training ... bf16" (models.py:180-217 under autocast: GEMM operands in bf16, fp32 accumulate, fp32
+// master weights).  Used by the training path for the forward and -- over the swapped map with W^T -- the input gradient;
+// features stay fp32 in HBM (BatchNorm, the loss and the optimizer are fp32), the gathered rows are rounded to bf16
+// (round to nearest even, v_cvt_pk_bf16_f32) on their way from the LDS image into the MFMA operand, the weights are
+// rounded once per optimizer step when they are packed.
+//
+// Same decomposition as spconv.hip -- a workgroup owns 128 output rows x 16 * WN output channels, accumulator tile in LDS,
+// pairs compacted per offset by wave ballot, gathered rows DMA'd into a source-swizzled LDS image, 16-pair row blocks --
+// in its plainest form: one MFMA per (row block, 32 channels) is 1/15 of the fp32 MFMA time, so the kernel is bound by
+// its requests and barriers, not by the matrix pipe, and none of the fp32 kernel's MFMA-side scheduling pays here.
+#include "spconv.h"
+
+namespace lidiff {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+namespace bf16k {
+constexpr int BM = 128;
+}
+
+// W [K, c_in, c_out] fp32 row-major -> bf16 [K][slab32][c_out/16][lane 0..63][i 0..7] with
+// k_in = 32 slab + 8 (lane >> 4) + i and col = 16 nt + (lane & 15) (the B operand of v_mfma_f32_16x16x32_bf16); zero beyond c_in.
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int k_vol, int c_in, int c_out, int nslab,
+                                         __bf16* __restrict__ wp, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    int64_t rest = idx >> 9;
+    const int nt16 = c_out >> 4;
+    const int nt = (int)(rest % nt16);
+    rest /= nt16;
+    const int slab = (int)(rest % nslab);
+    const int k = (int)(rest / nslab);
+    const int kin = 32 * slab + 8 * (lane >> 4) + i;
+    const int col = 16 * nt + (lane & 15);
+    wp[idx] = (__bf16)(kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f);
+}
+
+template <int WN, int KS>
+__global__ __launch_bounds__(64 * WN) void spconv_fwd_bf16_kernel(const ConvParams p_launch) {
+    using namespace bf16k;
+    constexpr int BN = 16 * WN, NT = 64 * WN, NW = WN;
+    constexpr int AF = BM * KS;                  // floats per A image
+    constexpr int NCHK = KS / 4, RPI = 64 / NCHK, NINST = BM / RPI, T = (NINST + NW - 1) / NW;
+    constexpr int NS = KS / 32;                  // MFMAs (32-channel steps) per row block and stage
+    ConvParams p = p_launch;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* a_buf = reinterpret_cast<float*>(smem);                       // 2 images
+    float* acc_lds = a_buf + 2 * AF;                                     // (BM + 1) x BN
+    int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + (BM + 1) * BN);
+    int32_t* out_list = in_list + p.k_vol * BM;                          // float index of the accumulator row
+    int32_t* cnt = out_list + p.k_vol * BM;
+    int32_t* orow = cnt + 32;
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, g = bid >> 3;
+    const int tn = g % p.tiles_n;
+    const int tiles_all = p.tiles_m * p.replicas;
+    const int tmr = (g / p.tiles_n) * 8 + xcd;
+    if (tmr >= tiles_all) return;
+    const int rep = tmr / p.tiles_m, tm = tmr - rep * p.tiles_m;
+    p.in_a += (int64_t)rep * p.m_in * p.c_in_a;
+    if (p.in_b) p.in_b += (int64_t)rep * p.m_in * p.c_in_b;
+    p.out += (int64_t)rep * p.m_out * p.c_out;
+    if (p.residual) p.residual += (int64_t)rep * p.m_out * p.c_out;
+    const int64_t row0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+
+    // ---- pair lists ----------------------------------------------------------------------------------------
+    for (int e = tid; e < (BM + 1) * BN / 4; e += NT) reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = tid; r < rows_here; r += NT) orow[r] = (int32_t)(row0 + r);
+    if (p.nbr == nullptr) {
+        for (int r = tid; r < BM; r += NT) {
+            in_list[r] = (int32_t)min(row0 + r, p.m_out - 1);
+            out_list[r] = r < rows_here ? r * BN : BM * BN;
+        }
+        if (tid == 0) cnt[0] = rows_here;
+    } else {
+        int32_t* raw = reinterpret_cast<int32_t*>(a_buf);
+        static_assert(27 * BM * 4 <= 2 * AF * 4, "raw neighbour block must fit in the A images");
+        for (int e = tid; e < p.k_vol * BM; e += NT) {
+            const int k = e / BM, r = e % BM;
+            raw[e] = r < rows_here ? p.nbr[(int64_t)k * p.m_out + row0 + r] : -1;
+        }
+        __syncthreads();
+        for (int k = wave; k < p.k_vol; k += NW) {
+            int pos = 0;
+#pragma unroll
+            for (int c = 0; c < BM; c += 64) {
+                const int r = c + lane;
+                const int v = raw[k * BM + r];
+                const bool valid = v >= 0;
+                const unsigned long long m = __ballot(valid);
+                if (valid) {
+                    const int q = pos + popc_below(m);
+                    in_list[k * BM + q] = v;
+                    out_list[k * BM + q] = r * BN;
+                }
+                pos += __popcll(m);
+            }
+#pragma unroll
+            for (int c = 0; c < BM; c += 64)
+                if (c + lane >= pos) out_list[k * BM + c + lane] = BM * BN;      // dummy row
+            if (lane == 0) cnt[k] = pos;
+        }
+    }
+    __syncthreads();
+
+    const int nslab = (p.c_in + KS - 1) / KS;
+    const int nslab32 = (p.c_in + 31) / 32;
+    const int nt16 = p.c_out >> 4;
+    const int w_slab_bytes = nt16 * 64 * 16;                            // one 32-channel slab of one offset (bf16)
+    const int w_lane_off = (((n0 >> 4) + wave) * 64 + lane) * 16;
+    __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wp), 0, (int)((size_t)p.k_vol * nslab32 * 32 * p.c_out * 2), 0x00020000);
+    int chb[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int r = RPI * (wave + NW * j) + lane / NCHK;
+        chb[j] = 16 * ((lane % NCHK) ^ (KS == 32 ? (r >> 1) & 7 : r & 15));
+    }
+    // byte offsets of this lane's two 16-byte chunks (channels 32 s + 8 lq .. + 7 of image row li) per 32-channel step
+    int foff[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            foff[s][h] = 4 * (li * KS + 4 * ((8 * s + 2 * lq + h) ^ (KS == 32 ? (li >> 1) & 7 : li & 15)));
+
+    auto issue = [&](int img, int k, int slab, int n, uint4 (&w)[NS]) {
+        const int ws = (k * nslab32 + slab * NS) * w_slab_bytes;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            w[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_lane_off, ws + s * w_slab_bytes, 0));
+        const int k0 = slab * KS;
+        const bool from_a = k0 < p.c_in_a;
+        const float* src = from_a ? p.in_a : p.in_b;
+        const int cw4 = (from_a ? p.c_in_a : p.c_in_b) * 4;
+        const int cb4 = (from_a ? k0 : k0 - p.c_in_a) * 4;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(p.m_in * cw4), 0x00020000);
+        char* dst = reinterpret_cast<char*>(a_buf) + img;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int t = wave + NW * j;
+            if (T * NW == NINST || t < NINST) {
+                const int r = RPI * t + lane / NCHK;
+                const int row = r < n ? in_list[k * BM + r] : -1;
+                const int voff = row >= 0 ? row * cw4 + chb[j] : (int)0x80000000;          // OOB -> zero fill
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, cb4, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: (offset, slab) stages, requests one stage ahead, one barrier per stage ----------------------
+    constexpr int IMG = AF * 4;
+    int img = 0;
+    uint4 wc[NS], wn[NS];
+    int k_cur = 0;
+    while (k_cur < p.k_vol && cnt[k_cur] == 0) ++k_cur;
+    if (k_cur < p.k_vol) issue(0, k_cur, 0, cnt[k_cur], wc);
+    __syncthreads();
+    while (k_cur < p.k_vol) {
+        const int n = cnt[k_cur];
+        const int nb = (n + 15) >> 4;
+        int k_next = k_cur + 1;
+        while (k_next < p.k_vol && cnt[k_next] == 0) ++k_next;
+        f32x4 acc[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int slab = 0; slab < nslab; ++slab) {
+            if (slab + 1 < nslab) issue(img ^ IMG, k_cur, slab + 1, n, wn);
+            else if (k_next < p.k_vol) issue(img ^ IMG, k_next, 0, cnt[k_next], wn);
+            const char* As = reinterpret_cast<const char*>(a_buf) + img;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b < nb) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const float4 lo = *reinterpret_cast<const float4*>(As + b * (16 * KS * 4) + foff[s][0]);
+                        const float4 hi = *reinterpret_cast<const float4*>(As + b * (16 * KS * 4) + foff[s][1]);
+                        const f32x8 av = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        const bf16x8 a = __builtin_convertvector(av, bf16x8);              // round to nearest even
+                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, wc[s]), acc[b], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) wc[s] = wn[s];
+            img ^= IMG;
+        }
+        // flush: tile[row of pair][col] += acc (each output row at most once per offset; waves own disjoint columns)
+        const int32_t* ol = out_list + k_cur * BM + 4 * lq;
+        const int colb = 16 * wave + li;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b < nb) {
+                const int4 o = *reinterpret_cast<const int4*>(ol + 16 * b);
+                acc_lds[o.x + colb] += acc[b][0];
+                acc_lds[o.y + colb] += acc[b][1];
+                acc_lds[o.z + colb] += acc[b][2];
+                acc_lds[o.w + colb] += acc[b][3];
+            }
+        }
+        k_cur = k_next;
+    }
+    __syncthreads();
+
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    for (int e = tid; e < rows_here * (BN / 4); e += NT) {
+        const int r = e / (BN / 4), cq = e % (BN / 4);
+        const int col = n0 + 4 * cq;
+        float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + cq];
+        if (p.scale) {
+            const float4 s = *reinterpret_cast<const float4*>(p.scale + col);
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+        }
+        if (p.shift) {
+            const float4 s = *reinterpret_cast<const float4*>(p.shift + col);
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        const int64_t o = (int64_t)orow[r] * p.c_out + col;
+        if (p.residual) {
+            const float4 s = *reinterpret_cast<const float4*>(p.residual + o);
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        if (p.relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(p.out + o) = v;
+    }
+}
+
+template <int WN, int KS>
+static int launch_bf16(const ConvParams& p, hipStream_t st) {
+    using namespace bf16k;
+    constexpr int BN = 16 * WN;
+    const size_t lds = (size_t)2 * BM * KS * 4 + (size_t)(BM + 1) * BN * 4 + (size_t)p.k_vol * BM * 8 + 32 * 4 + BM * 4;
+    auto kern = spconv_fwd_bf16_kernel<WN, KS>;
+    static thread_local size_t configured = 0;
+    if (lds > configured) {
+        LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    ConvParams q = p;
+    q.tiles_m = (int)ceil_div(p.m_out, BM);
+    q.tiles_n = p.c_out / BN;
+    const unsigned grid = (unsigned)(ceil_div((int64_t)q.tiles_m * q.replicas, 8) * 8 * q.tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN), lds, st, q);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace lidiff
+
+using namespace lidiff;
+
+extern "C" int64_t lidiff_spconv_packed_weight_bf16_elems(int32_t k_vol, int32_t c_in, int32_t c_out) {
+    return (int64_t)k_vol * ((c_in + 31) / 32) * 32 * c_out;
+}
+
+extern "C" int lidiff_spconv_pack_weights_bf16(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out, void* w_packed,
+                                               void* stream) {
+    LIDIFF_CHECK_ARG(w != nullptr && w_packed != nullptr, "null pointer");
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && c_in > 0, "kernel volume must be 1..27, c_in > 0");
+    LIDIFF_CHECK_ARG(c_out > 0 && c_out % 16 == 0, "c_out must be a multiple of 16");
+    const int nslab = (c_in + 31) / 32;
+    const int64_t total = lidiff_spconv_packed_weight_bf16_elems(k_vol, c_in, c_out);
+    pack_weights_bf16_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w, k_vol, c_in, c_out, nslab,
+                                                                                             (__bf16*)w_packed, total);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b, const void* w_packed,
+                                      const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out,
+                                      float* out, const float* ep_scale, const float* ep_shift, const float* residual,
+                                      int32_t relu, int32_t replicas, void* stream) {
+    LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && w_packed != nullptr && out != nullptr, "null pointer");
+    LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
+    LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
+    LIDIFF_CHECK_ARG(c_in_a % 32 == 0 && c_in_b % 32 == 0, "the bf16 kernel needs input widths that are multiples of 32");
+    LIDIFF_CHECK_ARG(c_out % 32 == 0, "the bf16 kernel needs c_out % 32 == 0");
+    LIDIFF_CHECK_ARG(replicas >= 1 && m_out >= 0 && m_in >= 0, "bad shape");
+    if (m_out == 0) return 0;
+    LIDIFF_CHECK_ARG(m_in > 0, "outputs without inputs");
+    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+    LIDIFF_CHECK_ARG(al16(in_a) && al16(in_b) && al16(w_packed) && al16(out) && al16(ep_scale) && al16(ep_shift) && al16(residual),
+                     "pointers must be 16-byte aligned");
+    LIDIFF_CHECK_ARG(m_in * (int64_t)c_in_a * 4 < (1ll << 31) && m_in * (int64_t)c_in_b * 4 < (1ll << 31),
+                     "a feature matrix exceeds the 2 GiB buffer-descriptor range");
+    ConvParams p{};
+    p.in_a = in_a; p.in_b = in_b; p.wp = reinterpret_cast<const float*>(w_packed); p.nbr = nbr; p.out = out;
+    p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
+    p.m_in = m_in; p.m_out = m_out;
+    p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
+    p.k_vol = k_vol; p.relu = relu; p.replicas = replicas;
+    hipStream_t st = (hipStream_t)stream;
+    const bool ks64 = c_in_a % 64 == 0 && c_in_b % 64 == 0;
+#define LIDIFF_BF16(WN) return ks64 ? launch_bf16<WN, 64>(p, st) : launch_bf16<WN, 32>(p, st)
+    if (c_out % 128 == 0) LIDIFF_BF16(8);
+    if (c_out % 96 == 0) LIDIFF_BF16(6);
+    if (c_out % 64 == 0) LIDIFF_BF16(4);
+    LIDIFF_BF16(2);
+#undef LIDIFF_BF16
+}

@@ -28,8 +28,13 @@ def linear_beta_schedule(timesteps, beta_start, beta_end):
 
 
 class DiffusionPoints(nn.Module):
-    def __init__(self, hparams: dict | None = None, device="cuda"):
+    def __init__(self, hparams: dict | None = None, device="cuda", precision: str = "32"):
+        """precision: "32" | "bf16" -- Lightning's Trainer(precision=...) of train.py:107-115.  "bf16" runs the training
+        convolutions (forward and input gradient) with bf16 GEMM operands and fp32 accumulation
+        (lidiff_spconv_fwd_bf16); weights, features, BatchNorm, loss and Adam state stay fp32."""
         super().__init__()
+        assert precision in ("32", "bf16")
+        self.precision = precision
         self.hparams = _merge(DEFAULT_HPARAMS, hparams or {})
         d = self.hparams["diff"]
         if d["beta_func"] != "linear":
@@ -96,7 +101,8 @@ class DiffusionPoints(nn.Module):
             x_part = self.points_to_tensor(pcd_part)
         else:
             x_part = self.points_to_tensor(torch.zeros_like(pcd_part))
-        denoise_t = self.forward(x_full, x_full.sparse(), x_part, t)
+        with ops.train_operands("bf16" if self.precision == "bf16" else "f32"):
+            denoise_t = self.forward(x_full, x_full.sparse(), x_part, t)
         loss_mse = self.p_losses(denoise_t, noise)
         loss_mean = denoise_t.mean() ** 2
         loss_std = (denoise_t.std() - 1.0) ** 2

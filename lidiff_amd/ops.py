@@ -306,6 +306,95 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     return out
 
 
+# GEMM operand precision of the TRAINING convolutions (_SparseConv forward and input gradient): "f32" or "bf16"
+# (BASELINE.json configs[4]: train.py under bf16 autocast).  The inference path always runs fp32 (configs[1]).
+TRAIN_OPERANDS = "f32"
+
+
+class train_operands:
+    """with ops.train_operands("bf16"): ... -- the precision of the training convolutions' GEMM operands."""
+
+    def __init__(self, kind: str):
+        assert kind in ("f32", "bf16")
+        self.kind = kind
+
+    def __enter__(self):
+        global TRAIN_OPERANDS
+        self.prev, TRAIN_OPERANDS = TRAIN_OPERANDS, self.kind
+
+    def __exit__(self, *exc):
+        global TRAIN_OPERANDS
+        TRAIN_OPERANDS = self.prev
+
+
+# The bf16 kernel has no packed stages: on low-density maps (the managers' sparse-map hint) the fp32 tile kernel is the
+# faster one (profiles/r02_bf16_conv_sweep.txt), so those layers keep it unless this is set (parity tests set it to pin
+# the whole step to the oracle's every-eligible-layer emulation).
+BF16_SPARSE_MAPS = False
+
+
+def bf16_conv_applies(c_a: int, c_b: int, c_out: int, sparse_map: bool = False) -> bool:
+    """Shapes lidiff_spconv_fwd_bf16 takes (every MinkUNet layer but the 3-channel stem and the 96 -> 3 head)."""
+    return c_a % 32 == 0 and c_b % 32 == 0 and c_out % 32 == 0 and (BF16_SPARSE_MAPS or not sparse_map)
+
+
+def packed_weights_bf16(w: torch.Tensor, transposed: bool = False, flip: bool = False) -> torch.Tensor:
+    """lidiff_spconv_pack_weights_bf16 of w [K, C_in, C_out] -- or, transposed, of the input-gradient kernel
+    w[::-1 if flip].transpose(1, 2) -- cached on the Parameter like packed_weights()."""
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    key = (w.data_ptr(), w._version, tuple(w3.shape), w.device)
+    attr = "_lidiff_packed_bf16" + ("_t" if transposed else "") + ("f" if flip else "")
+    hit = getattr(w, attr, None)
+    if hit is None or hit[0] != key:
+        src = w3.detach()
+        if transposed:
+            src = (src.flip(0) if flip else src).transpose(1, 2)
+        src = src.contiguous().float()
+        k, c_in, c_out = src.shape
+        n = _lib.load().lidiff_spconv_packed_weight_bf16_elems(k, c_in, c_out)
+        wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        call("lidiff_spconv_pack_weights_bf16", ptr(src), k, c_in, c_out, ptr(wp), stream_ptr())
+        hit = (key, wp)
+        try:
+            setattr(w, attr, hit)
+        except AttributeError:
+            pass
+    return hit[1]
+
+
+def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
+                    in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None, relu: bool = False,
+                    replicas: int = 1, transposed: bool = False, flip: bool = False) -> torch.Tensor:
+    """spconv_fwd with bf16 GEMM operands and fp32 accumulation (lidiff_spconv_fwd_bf16; include/lidiff_amd.h).
+    transposed: convolve with w[::-1 if flip].transpose(1, 2) -- the input gradient over the swapped map."""
+    require_device(in_a, w, nbr, in_b, scale, shift, residual)
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    k, c_in, c_out = w3.shape
+    if transposed:
+        c_in, c_out = c_out, c_in
+    wp = packed_weights_bf16(w, transposed, flip)
+    in_a = in_a.contiguous()
+    c_a, c_b = in_a.shape[1], 0
+    if in_b is not None:
+        in_b = in_b.contiguous()
+        c_b = in_b.shape[1]
+    assert c_a + c_b == c_in, f"channel mismatch {c_a}+{c_b} != {c_in}"
+    assert in_a.dtype == torch.float32 and in_a.shape[0] % replicas == 0
+    m_in = in_a.shape[0] // replicas
+    if nbr is not None:
+        assert nbr.shape == (k, m_out) and nbr.dtype == torch.int32 and nbr.is_contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == (replicas * m_out, c_out)
+    out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
+    call("lidiff_spconv_fwd_bf16", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out, c_out, ptr(out),
+         ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), stream_ptr())
+    prof = PROFILER
+    if prof is not None:
+        prof.launches.append(("bf16", None, None, m_in, m_out, c_in, c_out, k, nbr, replicas))
+    return out
+
+
 def rulebook_of(nbr: torch.Tensor):
     """(pairs_in, pairs_out, offset_ptr, n_pairs) of a neighbour table, built once and kept on the table tensor
     (kernel maps are cached per coordinate manager, so every conv on the map shares it in backward)."""

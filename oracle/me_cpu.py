@@ -200,11 +200,57 @@ def rulebook_from_nbr(nbr: np.ndarray):
 # --------------------------------------------------------------------------------------
 # features
 # --------------------------------------------------------------------------------------
+_BF16_OPERANDS = False
+
+
+class bf16_operands:
+    """``with bf16_operands():`` -- restates the product's mixed-precision TRAINING convolution (BASELINE configs[4],
+    include/lidiff_amd.h lidiff_spconv_fwd_bf16) on the CPU: for every convolution whose channel counts are multiples of
+    32, forward = conv(bf16(x), bf16(W)), dX = conv^T(bf16(g), bf16(W)), dW = x^T g unrounded; sums in the tensors' own
+    dtype.  The reference has no such mode of its own (ME has no bf16 kernels): this is the checker of OUR bf16 path."""
+
+    def __enter__(self):
+        global _BF16_OPERANDS
+        self.prev, _BF16_OPERANDS = _BF16_OPERANDS, True
+
+    def __exit__(self, *exc):
+        global _BF16_OPERANDS
+        _BF16_OPERANDS = self.prev
+
+
+def _bf16_round(t: torch.Tensor) -> torch.Tensor:
+    return t.float().bfloat16().to(t.dtype)
+
+
+class _Bf16Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, kernel, nbr):
+        ctx.save_for_backward(feats, kernel)
+        ctx.nbr = nbr
+        return _conv_plain(_bf16_round(feats.detach()), _bf16_round(kernel.detach()), nbr)
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, kernel = ctx.saved_tensors
+        with torch.enable_grad():
+            xr = _bf16_round(feats.detach()).requires_grad_(True)
+            gx, = torch.autograd.grad(_conv_plain(xr, _bf16_round(kernel.detach()), ctx.nbr), xr, _bf16_round(g))
+            w = kernel.detach().requires_grad_(True)
+            gw, = torch.autograd.grad(_conv_plain(feats.detach(), w, ctx.nbr), w, g)
+        return gx, gw, None
+
+
 def conv_forward(feats: torch.Tensor, kernel: torch.Tensor, nbr: np.ndarray | None) -> torch.Tensor:
     """MinkowskiConvolution / ConvolutionTranspose forward, ME CPU algorithm (Appendix
     A.6): for k ascending: gather rows -> buf @ W[k] -> out[out_row] += res.
     ``kernel`` is [K,Cin,Cout], or [Cin,Cout] for kernel_size=1 (``F.mm(kernel)``,
     minkunet.py:72)."""
+    if _BF16_OPERANDS and kernel.shape[-2] % 32 == 0 and kernel.shape[-1] % 32 == 0:
+        return _Bf16Conv.apply(feats, kernel, nbr)
+    return _conv_plain(feats, kernel, nbr)
+
+
+def _conv_plain(feats: torch.Tensor, kernel: torch.Tensor, nbr: np.ndarray | None) -> torch.Tensor:
     if _CPP and feats.dtype == torch.float32 and not (feats.requires_grad or kernel.requires_grad):
         from . import me_cpp
         return me_cpp.conv_forward(feats, kernel, nbr)

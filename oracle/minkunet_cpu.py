@@ -56,7 +56,7 @@ def _residual(sd, p, x):
     y = me.conv(y, sd[p + ".net.3.kernel"], 3, 1)
     main = _bn(sd, p + ".net.4", y.F)
     if p + ".downsample.0.kernel" in sd:
-        short = _bn(sd, p + ".downsample.1", x.F @ sd[p + ".downsample.0.kernel"])
+        short = _bn(sd, p + ".downsample.1", me.conv_forward(x.F, sd[p + ".downsample.0.kernel"], None))
     else:
         short = x.F
     return y.replace(torch.relu(main + short))

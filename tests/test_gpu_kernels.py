@@ -569,3 +569,117 @@ def test_voxel_mean_and_slice_backward_vs_autograd(device):
     counts = torch.from_numpy(np.bincount(inv, minlength=uniq.shape[0]).astype(np.float32))
     got = ops.vox_mean_bwd(gv.to(device), torch.from_numpy(inv).to(device), counts.to(device)).cpu()
     assert torch.allclose(got, gv[torch.from_numpy(inv)] / counts[torch.from_numpy(inv)][:, None], rtol=1e-6, atol=1e-7)
+
+
+def _bf16r(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("kind,cin,cout,split,epilogue", [
+    ("k3", 32, 32, 0, False), ("k3", 32, 64, 0, True), ("k3", 64, 128, 0, False), ("k3", 96, 96, 0, True),
+    ("k3", 128, 256, 0, False), ("k3", 384, 256, 256, True), ("k3", 192, 128, 128, False), ("k3", 160, 96, 96, False),
+    ("down", 64, 64, 0, False), ("up", 256, 256, 0, False), ("up", 128, 96, 0, True), ("k1", 96, 32, 0, False)])
+def test_spconv_bf16_operands_vs_oracle_on_rounded_inputs(device, kind, cin, cout, split, epilogue):
+    """lidiff_spconv_fwd_bf16 (BASELINE configs[4], bf16 training): bf16 operands, fp32 accumulation.  The oracle convolves
+    the bf16-ROUNDED inputs and weights in float64, so the only difference left is the fp32 summation order -- the bar is
+    the fp32 kernel's own (rtol 1e-4 / atol 1e-4), not a bf16-sized tolerance."""
+    from lidiff_amd import ops
+    coords = random_cloud(4000, 6, 40, batch=2)
+    uniq, _, _ = me.voxelize(coords)
+    coarse, _ = me.stride_map(uniq, 2)
+    if kind == "k3":
+        nbr, m_in, m_out, K = me.kernel_map(uniq, uniq, 3, 1), uniq.shape[0], uniq.shape[0], 27
+    elif kind == "down":
+        nbr, m_in, m_out, K = me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0], coarse.shape[0], 8
+    elif kind == "up":
+        nbr = me.transpose_kernel_map(me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0])
+        m_in, m_out, K = coarse.shape[0], uniq.shape[0], 8
+    else:
+        nbr, m_in, m_out, K = None, uniq.shape[0], uniq.shape[0], 1
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(m_in, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) / np.sqrt(cin * max(1, K // 3))
+    want = me.conv_forward(_bf16r(x).double(), _bf16r(w).double() if K > 1 else _bf16r(w)[0].double(), nbr)
+    scale = shift = res = None
+    if epilogue:
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        res = torch.randn(m_out, cout, generator=g)
+        want = torch.relu(want * scale.double() + shift.double() + res.double())
+    d = lambda t: None if t is None else t.to(device)
+    nbr_d = None if nbr is None else dev_i32(nbr, device)
+    kw = dict(scale=d(scale), shift=d(shift), residual=d(res), relu=epilogue)
+    if split:
+        got = ops.spconv_fwd_bf16(d(x[:, :split].contiguous()), d(w), nbr_d, m_out, in_b=d(x[:, split:].contiguous()), **kw)
+    else:
+        got = ops.spconv_fwd_bf16(d(x), d(w), nbr_d, m_out, **kw)
+    torch.cuda.synchronize()
+    err = (got.cpu().double() - want).abs().max().item()
+    assert torch.allclose(got.cpu().double(), want, rtol=RTOL, atol=ATOL), f"{kind} {cin}->{cout}: max err {err}"
+    # ... and it is the fp32 kernel's answer on the rounded operands, and NOT its answer on the unrounded ones
+    f32 = ops.spconv_fwd(d(_bf16r(x)), d(_bf16r(w)), nbr_d, m_out, **kw) if not split else None
+    if f32 is not None:
+        assert torch.allclose(got, f32, rtol=RTOL, atol=ATOL)
+    # replicas share the map and the weights
+    if not split and not epilogue:
+        x2 = torch.cat([x, -2.0 * x])
+        got2 = ops.spconv_fwd_bf16(d(x2), d(w), nbr_d, m_out, replicas=2)
+        assert torch.equal(got2[:m_out], got)
+        # (the matrix unit's internal sum is not sign-symmetric to the last bit, so the negated replica is compared closely, not exactly)
+        assert torch.allclose(got2[m_out:], -2.0 * got, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind,ks,stride,cin,cout", [("conv", 3, 1, 32, 64), ("conv", 2, 2, 64, 64), ("tconv", 2, 2, 64, 32),
+                                                    ("conv", 1, 1, 96, 32), ("conv", 3, 1, 256, 256), ("conv", 3, 1, 32, 48)])
+def test_spconv_bf16_training_backward_vs_oracle_autograd(device, kind, ks, stride, cin, cout):
+    """The ME-shim convolution under ops.train_operands("bf16"): forward and dX through lidiff_spconv_fwd_bf16 (dX over the
+    swapped map with the transposed, flipped kernel), dW by the fp32 kernel.  Inputs and the output gradient are chosen
+    bf16-representable, so the float64 oracle under me.bf16_operands() (weights rounded there) is the exact reference of all three.  A layer whose
+    channel counts are not multiples of 32 (32 -> 48 here) keeps the fp32 kernels under the same switch."""
+    import lidiff_amd.MinkowskiEngine as ME
+    from lidiff_amd import ops
+    coords = random_cloud(1500, 5, 31, batch=2)
+    g = torch.Generator().manual_seed(7)
+    uniq, _, _ = me.voxelize(coords)
+    field = ME.TensorField(features=torch.randn(coords.shape[0], 3, generator=g).to(device),
+                           coordinates=torch.from_numpy(coords).float().to(device), device=device)
+    mgr = field.sparse().coordinate_manager
+    ts_in = 1
+    if kind == "tconv":
+        mgr.stride(1, 2)
+        ts_in = 2
+    m_in = mgr.maps[ts_in].coords.shape[0]
+    xf = _bf16r(torch.randn(m_in, cin, generator=g))
+    x = ME.SparseTensor(xf.to(device).requires_grad_(True), tensor_stride=ts_in, coordinate_manager=mgr)
+    mod = (ME.MinkowskiConvolutionTranspose if kind == "tconv" else ME.MinkowskiConvolution)(
+        cin, cout, kernel_size=ks, stride=stride, dimension=3).to(device)
+    takes_bf16 = ops.bf16_conv_applies(cin, 0, cout)
+    prof = ops.ConvProfiler()
+    ops.PROFILER = prof
+    ops.BF16_SPARSE_MAPS = True                 # this small cloud's maps carry the sparse hint
+    try:
+        with ops.train_operands("bf16"):
+            y = mod(x)
+            r = _bf16r(torch.randn(y.F.shape, generator=g))
+            (y.F * r.to(device)).sum().backward()
+    finally:
+        ops.PROFILER = None
+        ops.BF16_SPARSE_MAPS = False
+    assert [v for v, *_ in prof.launches].count("bf16") == (2 if takes_bf16 else 0)
+    coarse, _ = me.stride_map(uniq, 2)
+    if kind == "tconv":
+        nbr = me.transpose_kernel_map(me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0])
+    elif ks == 1:
+        nbr = None
+    elif stride == 2:
+        nbr = me.kernel_map(uniq, coarse, 2, 1)
+    else:
+        nbr = me.kernel_map(uniq, uniq, 3, 1)
+    w = mod.kernel.detach().cpu()
+    xo = xf.double().requires_grad_(True)
+    wo = w.double().requires_grad_(True)
+    with me.bf16_operands():            # the oracle's emulation: operands rounded to bf16 where the channel counts allow
+        yo = me.conv_forward(xo, wo, nbr)
+    assert torch.allclose(y.F.detach().cpu().double(), yo.detach(), rtol=RTOL, atol=ATOL)
+    (yo * r.double()).sum().backward()
+    assert torch.allclose(x.F.grad.cpu().double(), xo.grad, rtol=1e-4, atol=1e-4), "dX"
+    assert torch.allclose(mod.kernel.grad.cpu().double(), wo.grad, rtol=1e-4, atol=1e-3), "dW"

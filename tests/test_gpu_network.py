@@ -292,8 +292,8 @@ def test_complete_scan_end_to_end(device, fps_scan):
     assert np.isfinite(refined).all() and np.isfinite(diffused).all()
 
 
-@pytest.mark.parametrize("drop", [False, True])
-def test_training_step_loss_and_gradients_vs_oracle(device, drop):
+@pytest.mark.parametrize("drop,precision", [(False, "32"), (True, "32")])
+def test_training_step_loss_and_gradients_vs_oracle(device, drop, precision):
     """DiffusionPoints.training_step (models.py:180-217) on the HIP path -- train-mode BatchNorm, conv forward / dX / dW
     kernels, voxel-mean and slice backward, per-batch broadcast of the time embedding -- against the oracle's functional
     restatement differentiated by torch autograd on the CPU, with the step's random draws (noise, t, condition drop) shared.
@@ -302,10 +302,15 @@ def test_training_step_loss_and_gradients_vs_oracle(device, drop):
     norm 4.9e-4).  The scene is sized so that the coarse levels hold a few hundred voxels: on a 600-point scene train-mode
     BatchNorm over the ~20 voxels of stride 16 amplifies last-bit differences (atomic voxel mean / slice / dW sums, as in
     ME's own GPU path) until two runs of the SAME device step differ by 2.6e-2 in a BatchNorm bias gradient
-    (tools/debug/dbg_train_parity.py) -- a property of the step, not of either implementation."""
+    (tools/debug/dbg_train_parity.py) -- a property of the step, not of either implementation.
+    (precision "bf16" is not pinned at this level: rounding to bf16 is discontinuous, a last-bit difference that crosses a
+    rounding boundary becomes a 2^-9 one, and within ~3 layers the device and ANY emulation of it differ by the bf16 noise
+    floor itself -- measured: device vs me.bf16_operands() emulation, cosine 0.92 on the first kernel's gradient, the same as
+    bf16 vs fp32.  The bf16 kernels are pinned per layer at the fp32 bar instead: test_gpu_kernels.py, *bf16*.)"""
     from lidiff_amd.diffusion import DiffusionPoints
     torch.manual_seed(3)
-    mod = DiffusionPoints(device=device)
+    mod = DiffusionPoints(device=device, precision=precision)
+    loss_tol, cos_bar, norm_bar, head_bar = 1e-5, 0.9999, 2e-3, 1e-4
     for m in mod.modules():                                    # away from the 1 / 0 initialisation of the BatchNorm affine
         if isinstance(m, torch.nn.BatchNorm1d):
             m.weight.data.uniform_(0.8, 1.2)
@@ -335,7 +340,7 @@ def test_training_step_loss_and_gradients_vs_oracle(device, drop):
     names = [k for k, v in sd.items() if v.requires_grad]
     grads_o = torch.autograd.grad(loss_o, [sd[k] for k in names], allow_unused=True)
     l_d, l_o = float(loss.detach()), float(loss_o.detach())
-    assert abs(l_d - l_o) <= 1e-5 * abs(l_o), (l_d, l_o)
+    assert abs(l_d - l_o) <= loss_tol * abs(l_o), (l_d, l_o)
     params = dict(mod.named_parameters())
     worst_cos, worst_norm, compared = ("", 1.0), ("", 0.0), 0
     for k, go in zip(names, grads_o):
@@ -360,11 +365,11 @@ def test_training_step_loss_and_gradients_vs_oracle(device, drop):
         nrel = abs(float(gd.norm()) - n_o) / n_o
         worst_cos = min(worst_cos, (k, cos), key=lambda q: q[1])
         worst_norm = max(worst_norm, (k, nrel), key=lambda q: q[1])
-        assert cos >= 0.9999 and nrel <= 2e-3, (k, cos, nrel, n_o)
+        assert cos >= cos_bar and nrel <= norm_bar, (k, cos, nrel, n_o)
         if k.startswith("model.last."):
-            assert float((gd - go).norm()) <= 1e-4 * n_o, (k, float((gd - go).norm()) / n_o)
+            assert float((gd - go).norm()) <= head_bar * n_o, (k, float((gd - go).norm()) / n_o)
     assert compared >= (150 if drop else 300), compared
-    print(f"training step drop={drop}: loss {l_d:.7f} vs oracle {l_o:.7f}; {compared} gradients; worst cosine "
+    print(f"training step drop={drop} precision={precision}: loss {l_d:.7f} vs oracle {l_o:.7f}; {compared} gradients; worst cosine "
           f"{worst_cos[1]:.6f} ({worst_cos[0]}), worst norm deviation {worst_norm[1]:.2e} ({worst_norm[0]})")
 
 
@@ -419,6 +424,64 @@ def test_refine_training_step_loss_and_gradients_vs_oracle(device):
         compared += 1
     assert compared >= 150, compared                              # MinkUNet: 151 parameter tensors
     print(f"refine training step: loss {l_d:.7f} vs oracle {l_o:.7f}; {compared} gradients, worst cosine {worst[1]:.6f} ({worst[0]})")
+
+
+def test_bf16_training_step_tracks_the_fp32_step(device):
+    """BASELINE configs[4] (train.py, bf16): DiffusionPoints(precision="bf16") runs the convolutions of the step -- forward
+    and input gradient -- through lidiff_spconv_fwd_bf16 (all 32-channel-multiple layers on dense maps).  The kernel is
+    pinned per layer -- forward, dX, dW -- to the oracle on bf16-rounded operands at the fp32 bar (test_gpu_kernels, *bf16*);
+    a whole-step pin is not possible (see test_training_step_loss_and_gradients_vs_oracle).  This is the end-to-end sanity of the
+    mode on a full-size (2 x 18 000-point) batch against the fp32 step on the same weights and draws: the loss within 1e-2
+    relative and every gradient finite.  Gradient cosines are printed, with a loose floor only: at random initialisation
+    the step is ill-conditioned with respect to 2^-9 operand rounding -- the CPU oracle's OWN bf16-emulated step has median
+    gradient cosine 0.86 / worst 0.71 against its fp32 step on a 20 000-point scene (DESIGN.md, bf16 training)."""
+    from lidiff_amd import ops
+    from lidiff_amd.diffusion import DiffusionPoints
+    torch.manual_seed(3)
+    mod = DiffusionPoints(device=device)
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.8, 1.2)
+            m.bias.data.normal_(0, 0.1)
+    mod.train()
+    scan = np.load(os.path.join(GOLDEN, "scan_000123_fps18000.npy")).astype(np.float32)      # a real 18 000-point scan:
+    rng = np.random.default_rng(5)                     # BatchNorm statistics over thousands of voxels at every level
+    full = torch.from_numpy(np.stack([scan + np.float32(0.02) * rng.standard_normal(scan.shape).astype(np.float32)
+                                      for _ in range(2)]))
+    part = full[:, ::10].contiguous()
+    g = torch.Generator().manual_seed(1)
+    noise = torch.randn(full.shape, generator=g)
+    t = torch.tensor([700, 30])
+    out = {}
+    for precision in ("32", "bf16"):
+        mod.precision = precision
+        prof = ops.ConvProfiler(variants=())
+        ops.PROFILER = prof
+        try:
+            loss = mod.training_step({"pcd_full": full, "pcd_part": part}, noise=noise, t=t, drop=False)
+            mod.zero_grad(set_to_none=True)
+            loss.backward()
+        finally:
+            ops.PROFILER = None
+        n_bf16 = sum(1 for v, *_ in prof.launches if v == "bf16")
+        out[precision] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in mod.named_parameters()
+                                                 if p.grad is not None}, n_bf16, len(prof.launches))
+    assert out["32"][2] == 0
+    assert out["bf16"][2] >= 0.3 * out["bf16"][3] > 0, out["bf16"][2:]          # the dense-map layers
+    l32, lbf = out["32"][0], out["bf16"][0]
+    assert abs(lbf - l32) <= 1e-2 * abs(l32), (lbf, l32)
+    cosines = []
+    for k, g32 in out["32"][1].items():
+        gbf = out["bf16"][1][k]
+        if float(g32.norm()) <= 1e-7:
+            continue
+        assert bool(torch.isfinite(gbf).all()), k
+        cosines.append((float((gbf * g32).sum() / (gbf.norm() * g32.norm())), k))
+    cosines.sort()
+    med = cosines[len(cosines) // 2][0]
+    print(f"bf16 step: loss {lbf:.6f} vs fp32 {l32:.6f} ({abs(lbf - l32) / abs(l32):.2e}); {len(cosines)} gradients, "
+          f"median cosine {med:.5f}, worst {cosines[0][0]:.5f} ({cosines[0][1]}); bf16 launches {out['bf16'][2]} of {out['bf16'][3]}")
+    assert len(cosines) >= 300 and med >= 0.6, cosines[:5]
 
 
 def _two_rank_train_worker(rank, world, port, q):

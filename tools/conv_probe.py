@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--ordered", action="store_true", help="Morton-ordered tiles (row_order + permuted table)")
     ap.add_argument("--lpt", action="store_true", help="128-row tiles in descending pair-count order (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
-    ap.add_argument("--kernel", default="tile", choices=["tile", "dense", "dense1"], help="kernel of the dense 128-column layers")
+    ap.add_argument("--kernel", default="tile", choices=["tile", "dense", "dense1", "bf16"], help="kernel of the dense 128-column layers")
     ap.add_argument("--centre-tail", action="store_true", help="k3 layers as centre pass + tail rows (ops.spconv_centre_tail)")
     ap.add_argument("--timeline", action="store_true",
                     help="diagnostic build: per-workgroup cycle counters (prologue / main loop / epilogue / barrier / flush)")
@@ -52,7 +52,7 @@ def main():
         _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))
     from lidiff_amd import ops
     import lidiff_amd.MinkowskiEngine as ME
-    ops.DENSE_KERNEL = args.kernel
+    ops.DENSE_KERNEL = args.kernel if args.kernel != "bf16" else "tile"
     dev = torch.device("cuda:0")
     scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_fps18000.npy"))
     rng = np.random.default_rng(0)
@@ -104,6 +104,8 @@ def main():
         if args.centre_tail and kind == "k3":
             tmap = ops.TailMap(nbr)
             conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out)
+        elif args.kernel == "bf16" and ops.bf16_conv_applies(cin, 0, cout):
+            conv = lambda: ops.spconv_fwd_bf16(x, w, nbr, m_out)
         else:
             conv = lambda: ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
         for _ in range(3):

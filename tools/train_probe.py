@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Times the diffusion training step (models.py:180-217: forward + loss + backward + Adam) on the BASELINE
-config-5 shape per GPU: B = 2 scans of 180 000 points, 18 000-point partial scans, fp32, random-init weights.
+config-5 shape per GPU: B = 2 scans of 180 000 points, 18 000-point partial scans, fp32 or (--precision bf16) bf16 conv operands,
+random-init weights.
 
     python tools/train_probe.py [--steps 5] [--batch 2] [--points 180000]
 Prints ms per phase (HIP events on the current stream) and the peak allocated memory.
@@ -22,13 +23,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--points", type=int, default=180000)
+    ap.add_argument("--precision", default="32", choices=["32", "bf16"])
     a = ap.parse_args()
     from lidiff_amd.diffusion import DiffusionPoints
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    module = DiffusionPoints(device=dev)
+    module = DiffusionPoints(device=dev, precision=a.precision)
     module.train()
-    opt, sched = module.configure_optimizers()
+    opt, _ = module.configure_optimizers()       # the LR schedule steps per epoch (train_loop), not here
     scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_fps18000.npy")).astype(np.float32)
     rng = np.random.default_rng(0)
     rep = a.points // scan.shape[0]
@@ -50,7 +52,6 @@ def main():
         loss.backward()
         e2.record()
         opt.step()
-        sched.step()
         e3.record()
         torch.cuda.synchronize()
         if step >= a.warmup:
@@ -60,7 +61,7 @@ def main():
         print(f"step {step}: loss {float(loss):.4f}", flush=True)
     ms = {k: v / a.steps for k, v in tot.items()}
     total = sum(ms.values())
-    print(f"B={a.batch} x {a.points} points: " + "  ".join(f"{k} {v:.1f} ms" for k, v in ms.items()) +
+    print(f"precision {a.precision}  B={a.batch} x {a.points} points: " + "  ".join(f"{k} {v:.1f} ms" for k, v in ms.items()) +
           f"  | step {total:.1f} ms = {1e3 / total:.2f} steps/s, {a.batch * 1e3 / total:.2f} scans/s; "
           f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 

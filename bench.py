@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0
 N_POINTS = 180000
 T_STEPS = 50
@@ -96,7 +97,7 @@ def run_steps(pipe, x_init, xs, tvals, first, count, cache_condition=False):
     return x_t
 
 
-def cpu_baseline(scan_np, seed=42):
+def cpu_baseline(scan_np, seed=42, threads=0):
     """The "MinkowskiEngine CPU path" timed on this box's host cores: the C++17 / OpenMP restatement
     of ME's CPU algorithm (oracle/cpp/me_cpu_ref.cpp: hash-map coordinate maps, per-offset hash-probe kernel maps, per-offset
     gather -> MKL SGEMM -> scatter-add in ascending kernel index) under the oracle's network code (torch-CPU Linear /
@@ -118,6 +119,8 @@ def cpu_baseline(scan_np, seed=42):
     scan = np.tile(scan_np, (10, 1)).astype(np.float64)[None]
     x = scan + o.sigma_t[t] * rng.standard_normal(scan.shape)
     z = rng.standard_normal(scan.shape)
+    if threads:
+        me_cpp.set_threads(threads)
     cores = me_cpp.threads()
     model = "unknown CPU"
     try:
@@ -250,9 +253,12 @@ def main():
     ap.add_argument("--all-variants", action="store_true",
                     help="time every sparse-conv launch, not only the dominant (BN=128) variant: more events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all the box has)")
     ap.add_argument("--no-coords-roofline", action="store_true", help="skip the coordinate-pipeline (HBM-bound) roofline leg")
     ap.add_argument("--cached-condition", action="store_true",
                     help="also time the same steps with the step-invariant conditions encoded once (reported beside the metric)")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the 'alt' leg (the same steps with the dense layers from two bf16 pieces per operand)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / timing plumbing only, on the CPU over gloo (no kernels): CI of the N > 1 path")
     args = ap.parse_args()
@@ -304,6 +310,20 @@ def main():
             run_steps(pipe, x_init, xs, tvals, 0, args.steps, cache_condition=True)
             torch.cuda.synchronize()
             elapsed_cached = time.perf_counter() - t0
+        # beside the metric, never `value`: the same K steps with the dense 128-column layers computed from two bf16 pieces
+        # per operand (3 bf16 MFMAs per block, fp32 accumulation; ops.split_planes, lidiff_spconv_fwd_bf16 planes = 2)
+        alt = None
+        if world == 1 and not args.no_alt:
+            with ops.split_planes(2):
+                run_steps(pipe, x_init, wx, wt, 0, 1)                   # packs the bf16 weight planes
+                aprof = None if args.no_kernel_events else ops.ConvProfiler({"bf16x2"})
+                ops.PROFILER = aprof
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_steps(pipe, x_init, xs, tvals, 0, args.steps)
+                torch.cuda.synchronize()
+                alt = (time.perf_counter() - t0, aprof)
+                ops.PROFILER = None
     elapsed = ldist.max_over_ranks(elapsed, device=device)
     if args.cached_condition:
         elapsed_cached = ldist.max_over_ranks(elapsed_cached, device=device)
@@ -354,11 +374,29 @@ def main():
                              "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                              "alg_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in summ.items() if v["timed"]},
         }
+    if alt is not None:
+        a_elapsed, aprof = alt
+        out["alt"] = {
+            "dtype": "f32 from 2 bf16 pieces per operand (x1 w1 + x1 w2 + x2 w1: 3 bf16 MFMAs, fp32 accumulate) on the dense "
+                     "128-column layers; every other kernel native fp32",
+            "value": args.steps / a_elapsed, "unit": "steps/s", "ms_per_step": 1e3 * a_elapsed / args.steps,
+            "note": "opt-in (ops.split_planes(2) / LIDIFF_SPLIT_PLANES=2), never the metric: products keep 16-17 bits "
+                    "(per-layer error 10-15x the native fp32 kernel's, inside the 1e-4 parity bar; DESIGN.md 4.3)"}
+        if aprof is not None:
+            d = aprof.summary().get("bf16x2")
+            if d and d["ms"] > 0:
+                tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                out["alt"]["roofline"] = {
+                    "kernel": "spconv_fwd_bf16_kernel, planes = 2", "bound": "mfma", "achieved": tf,
+                    "peak": PEAK_BF16_MFMA_TFLOPS / 3.0, "unit": "TFLOP/s (fp32-equivalent: 2 P C_in C_out per launch)",
+                    "frac": tf / (PEAK_BF16_MFMA_TFLOPS / 3.0), "launches": d["timed"],
+                    "avg_us": 1e3 * d["ms"] / max(1, d["timed"]),
+                    "peak_note": "dense bf16 MFMA peak / 3 MFMAs per block"}
     if world == 1 and not args.no_coords_roofline:
         with torch.no_grad():
             out["roofline_hbm"] = coords_roofline(scan_np, device)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(scan_np)
+        out["cpu_baseline"] = cpu_baseline(scan_np, threads=args.cpu_threads)
     print(json.dumps(out))
 
 

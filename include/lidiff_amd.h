@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 12
+#define LIDIFF_ABI_VERSION 13
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -166,19 +166,24 @@ int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int3
                       const float* tail, const int32_t* tail_ptr, const int32_t* tail_idx, int64_t tail_rows,
                       void* stream);
 
-/* lidiff_spconv_fwd with bf16 GEMM operands and fp32 accumulation (v_mfma_f32_16x16x32_bf16): the mixed-precision
- * training configuration (train.py under bf16 autocast; models.py:180-217).  Features, BatchNorm and the epilogue stay
- * fp32 in HBM; each gathered input value is rounded to bf16 (nearest even) as it enters the matrix unit and the weights
- * when they are packed (lidiff_spconv_pack_weights_bf16: once per optimizer step from the fp32 master weights).  Equal
- * to lidiff_spconv_fwd on bf16-rounded inputs and weights up to fp32 summation order.  Input widths and c_out multiples
- * of 32; same map / epilogue / replica arguments as lidiff_spconv_fwd (no row order, no tail).  Forward and, over the
- * swapped map with W^T, the input gradient. */
-int64_t lidiff_spconv_packed_weight_bf16_elems(int32_t k_vol, int32_t c_in, int32_t c_out);
-int lidiff_spconv_pack_weights_bf16(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out, void* w_packed,
-                                    void* stream);
+/* lidiff_spconv_fwd with bf16 matrix operands and fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Features, BatchNorm and
+ * the epilogue stay fp32 in HBM; each gathered input value is cut into `planes` bf16 pieces (round to nearest even:
+ * x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)) as it enters the matrix unit, the weights likewise when they are
+ * packed (lidiff_spconv_pack_weights_bf16, once per weight version), and all products x_i w_j with i + j <= planes + 1 are
+ * summed in fp32 (1, 3 or 6 MFMAs per 16 x 16 x 32 block).
+ *   planes = 1: the mixed-precision TRAINING convolution (train.py under bf16; models.py:180-217): forward and, over the
+ *               swapped map with W^T, the input gradient.  Equal to lidiff_spconv_fwd on bf16-rounded inputs and weights up
+ *               to fp32 summation order.
+ *   planes = 2, 3: fp32-accurate results from bf16 pieces (opt-in inference mode; error of a K = 6912 dot product relative to
+ *               sum |x w|: 2.5e-7 / 1.3e-7 against 1.1e-7 of the native fp32 MFMA).
+ * Input widths and c_out multiples of 32; same map / epilogue / replica arguments as lidiff_spconv_fwd (no row order, no
+ * tail). */
+int64_t lidiff_spconv_packed_weight_bf16_elems(int32_t k_vol, int32_t c_in, int32_t c_out, int32_t planes);
+int lidiff_spconv_pack_weights_bf16(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out, int32_t planes,
+                                    void* w_packed, void* stream);
 int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b, const void* w_packed,
-                           const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* out,
-                           const float* ep_scale, const float* ep_shift, const float* residual, int32_t relu,
+                           int32_t planes, const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out,
+                           float* out, const float* ep_scale, const float* ep_shift, const float* residual, int32_t relu,
                            int32_t replicas, void* stream);
 
 /* Weight gradient of lidiff_spconv_fwd (training path, models.py:180-217; ME: ConvolutionBackwardGPU):

@@ -36,9 +36,9 @@ SIGNATURES = {
     "lidiff_spconv_pack_weights": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
     "lidiff_spconv_fwd": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i32, _i32,
                                  _p, _p, _p, _i64, _p]),
-    "lidiff_spconv_packed_weight_bf16_elems": (_i64, [_i32, _i32, _i32]),
-    "lidiff_spconv_pack_weights_bf16": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
-    "lidiff_spconv_fwd_bf16": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p]),
+    "lidiff_spconv_packed_weight_bf16_elems": (_i64, [_i32, _i32, _i32, _i32]),
+    "lidiff_spconv_pack_weights_bf16": (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "lidiff_spconv_fwd_bf16": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p]),
     "lidiff_spconv_bwd_w_workspace_floats": (_i64, [_i32, _i32, _i32, _i64]),
     "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p]),
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
@@ -55,7 +55,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 

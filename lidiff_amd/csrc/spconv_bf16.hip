@@ -1,14 +1,21 @@
-// Sparse convolution with bf16 operands and fp32 accumulation (v_mfma_f32_16x16x32_bf16) -- BASELINE.json configs[4]:
-// "train.py diffusion training ... bf16" (models.py:180-217 under autocast: GEMM operands in bf16, fp32 accumulate, fp32
-// master weights).  Used by the training path for the forward and -- over the swapped map with W^T -- the input gradient;
-// features stay fp32 in HBM (BatchNorm, the loss and the optimizer are fp32), the gathered rows are rounded to bf16
-// (round to nearest even, v_cvt_pk_bf16_f32) on their way from the LDS image into the MFMA operand, the weights are
-// rounded once per optimizer step when they are packed.
+// Sparse convolution with bf16 matrix operands and fp32 accumulation (v_mfma_f32_16x16x32_bf16), in two uses:
+//   planes = 1: the mixed-precision TRAINING convolution -- BASELINE.json configs[4] "train.py diffusion training ... bf16"
+//               (models.py:180-217 under autocast: GEMM operands in bf16, fp32 accumulate, fp32 master weights) -- forward
+//               and, over the swapped map with W^T, the input gradient;
+//   planes = 2 / 3: an fp32-accurate forward from bf16 pieces (opt-in for inference; never the benchmark's `value`):
+//               x = x1 + x2 (+ x3) and w = w1 + w2 (+ w3) in bf16, all products x_i w_j with i + j <= planes + 1 (3 or 6
+//               MFMAs) -- measured error of a K = 6912 dot product relative to sum |x w|: 2.5e-7 (two planes), 1.3e-7
+//               (three planes), native fp32 MFMA 1.1e-7 (profiles/r01_bf16_split_micro.txt).
+// Features stay fp32 in HBM (BatchNorm, the loss, the optimizer and every consumer are fp32): the gathered rows are split /
+// rounded (nearest even, v_cvt_pk_bf16_f32) on their way from the LDS image into the MFMA operand, the weights once per
+// weight version when they are packed.
 //
-// Same decomposition as spconv.hip -- a workgroup owns 128 output rows x 16 * WN output channels, accumulator tile in LDS,
-// pairs compacted per offset by wave ballot, gathered rows DMA'd into a source-swizzled LDS image, 16-pair row blocks --
-// in its plainest form: one MFMA per (row block, 32 channels) is 1/15 of the fp32 MFMA time, so the kernel is bound by
-// its requests and barriers, not by the matrix pipe, and none of the fp32 kernel's MFMA-side scheduling pays here.
+// Same decomposition as spconv.hip -- a workgroup owns 128 output rows x BN output channels, accumulator tile in LDS, pairs
+// compacted per offset by wave ballot, gathered rows DMA'd into a source-swizzled LDS image, 16-pair row blocks -- but the
+// waves form a WR x WC grid: wave (wr, wc) owns the row blocks wr, wr + WR, ... and the 32 columns [32 wc, 32 wc + 32), so
+// every converted A fragment feeds two column blocks (x planes) and the A image is read WC times per stage, not 8 times:
+// one bf16 MFMA is 1/15 of the fp32 MFMA time for the same work, so this kernel is bound by LDS reads, conversions and
+// requests, not by the matrix pipe.
 #include "spconv.h"
 
 namespace lidiff {
@@ -16,18 +23,17 @@ namespace lidiff {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-namespace bf16k {
-constexpr int BM = 128;
-}
-
-// W [K, c_in, c_out] fp32 row-major -> bf16 [K][slab32][c_out/16][lane 0..63][i 0..7] with
-// k_in = 32 slab + 8 (lane >> 4) + i and col = 16 nt + (lane & 15) (the B operand of v_mfma_f32_16x16x32_bf16); zero beyond c_in.
-__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int k_vol, int c_in, int c_out, int nslab,
+// W [K, c_in, c_out] fp32 row-major -> bf16 [K][slab32][c_out/16][plane][lane 0..63][i 0..7] with
+// k_in = 32 slab + 8 (lane >> 4) + i and col = 16 nt + (lane & 15) (the B operand of v_mfma_f32_16x16x32_bf16); zero beyond
+// c_in.  plane 0 = bf16(w), plane 1 = bf16(w - plane 0), plane 2 = bf16(w - plane 0 - plane 1) (round to nearest even).
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int k_vol, int c_in, int c_out, int nslab, int planes,
                                          __bf16* __restrict__ wp, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
     int64_t rest = idx >> 9;
+    const int plane = (int)(rest % planes);
+    rest /= planes;
     const int nt16 = c_out >> 4;
     const int nt = (int)(rest % nt16);
     rest /= nt16;
@@ -35,16 +41,25 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int k_vol,
     const int k = (int)(rest / nslab);
     const int kin = 32 * slab + 8 * (lane >> 4) + i;
     const int col = 16 * nt + (lane & 15);
-    wp[idx] = (__bf16)(kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f);
+    float v = kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f;
+    __bf16 piece = (__bf16)v;
+    for (int q = 0; q < plane; ++q) {
+        v -= (float)piece;
+        piece = (__bf16)v;
+    }
+    wp[idx] = piece;
 }
 
-template <int WN, int KS>
-__global__ __launch_bounds__(64 * WN) void spconv_fwd_bf16_kernel(const ConvParams p_launch) {
-    using namespace bf16k;
-    constexpr int BN = 16 * WN, NT = 64 * WN, NW = WN;
+// A workgroup owns BM (128 or 64) output rows x 32 WC columns; WC x WR waves: wave (wr, wc) owns the 16-row blocks
+// wr + WR j (j < RB = BM / 16 / WR) and the columns [32 wc, 32 wc + 32).  (BM = 64 -- 79 KB of LDS, two workgroups per CU --
+// was measured and takes the SAME time as BM = 128 on every layer (profiles/r02_bf16_kernel_probe.txt): the kernel is bound
+// by per-CU throughput, not by the phases of one workgroup; only BM = 128 is instantiated.)
+template <int BM, int WC, int WR, int KS, int P>
+__global__ __launch_bounds__(64 * WC * WR) void spconv_fwd_bf16_kernel(const ConvParams p_launch) {
+    constexpr int BN = 32 * WC, NW = WC * WR, NT = 64 * NW, RB = BM / 16 / WR;
     constexpr int AF = BM * KS;                  // floats per A image
     constexpr int NCHK = KS / 4, RPI = 64 / NCHK, NINST = BM / RPI, T = (NINST + NW - 1) / NW;
-    constexpr int NS = KS / 32;                  // MFMAs (32-channel steps) per row block and stage
+    constexpr int NS = KS / 32;                  // 32-channel steps per stage
     ConvParams p = p_launch;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* a_buf = reinterpret_cast<float*>(smem);                       // 2 images
@@ -70,6 +85,7 @@ __global__ __launch_bounds__(64 * WN) void spconv_fwd_bf16_kernel(const ConvPara
     const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave % WC, wr = wave / WC;
     const int li = lane & 15, lq = lane >> 4;
 
     // ---- pair lists ----------------------------------------------------------------------------------------
@@ -115,10 +131,10 @@ __global__ __launch_bounds__(64 * WN) void spconv_fwd_bf16_kernel(const ConvPara
     const int nslab = (p.c_in + KS - 1) / KS;
     const int nslab32 = (p.c_in + 31) / 32;
     const int nt16 = p.c_out >> 4;
-    const int w_slab_bytes = nt16 * 64 * 16;                            // one 32-channel slab of one offset (bf16)
-    const int w_lane_off = (((n0 >> 4) + wave) * 64 + lane) * 16;
+    const int w_slab_bytes = nt16 * P * 1024;                           // one 32-channel slab of one offset: nt16 x P planes x 1 KB
+    const int w_lane_off = (((n0 >> 4) + 2 * wc) * P * 64 + lane) * 16;
     __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.wp), 0, (int)((size_t)p.k_vol * nslab32 * 32 * p.c_out * 2), 0x00020000);
+        const_cast<float*>(p.wp), 0, (int)((size_t)p.k_vol * nslab32 * w_slab_bytes), 0x00020000);
     int chb[T];
 #pragma unroll
     for (int j = 0; j < T; ++j) {
@@ -133,11 +149,19 @@ __global__ __launch_bounds__(64 * WN) void spconv_fwd_bf16_kernel(const ConvPara
         for (int h = 0; h < 2; ++h)
             foff[s][h] = 4 * (li * KS + 4 * ((8 * s + 2 * lq + h) ^ (KS == 32 ? (li >> 1) & 7 : li & 15)));
 
-    auto issue = [&](int img, int k, int slab, int n, uint4 (&w)[NS]) {
-        const int ws = (k * nslab32 + slab * NS) * w_slab_bytes;
+    struct WRegs {
+        uint4 v[NS][2][P];         // [32-channel step][column block][plane]
+    };
+    auto issue = [&](int img, int k, int slab, int n, WRegs& w) {
+        const int ws = (p.probe & 2) ? 0 : (k * nslab32 + slab * NS) * w_slab_bytes;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            w[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_lane_off, ws + s * w_slab_bytes, 0));
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+                    w.v[s][cb][q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsrc_w, w_lane_off + (cb * P + q) * 1024, ws + s * w_slab_bytes, 0));
         const int k0 = slab * KS;
         const bool from_a = k0 < p.c_in_a;
         const float* src = from_a ? p.in_a : p.in_b;
@@ -150,67 +174,130 @@ __global__ __launch_bounds__(64 * WN) void spconv_fwd_bf16_kernel(const ConvPara
             const int t = wave + NW * j;
             if (T * NW == NINST || t < NINST) {
                 const int r = RPI * t + lane / NCHK;
-                const int row = r < n ? in_list[k * BM + r] : -1;
+                const int row = r < n && !(p.probe & 1) ? in_list[k * BM + r] : -1;
                 const int voff = row >= 0 ? row * cw4 + chb[j] : (int)0x80000000;          // OOB -> zero fill
+                if (p.probe & 16) continue;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, cb4, 0, 0);
             }
         }
     };
 
     // ---- main loop: (offset, slab) stages, requests one stage ahead, one barrier per stage ----------------------
+    // The compiler does not make s_barrier wait for LDS-DMA and puts `s_waitcnt vmcnt(0)` in front of any LDS read it can
+    // see while a DMA is in flight (which would serialise the prefetch), so the stage barrier and the fragment reads are
+    // inline asm with their own waits; tools/check_asm_regs.py checks on the listing that nothing touches a fragment
+    // register between its ds_read and the wait.
+#define LIDIFF_STAGE_BARRIER()                                                          \
+    do {                                                                                \
+        if (p.probe & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+    } while (0)
     constexpr int IMG = AF * 4;
     int img = 0;
-    uint4 wc[NS], wn[NS];
+    WRegs wcur, wnext;
     int k_cur = 0;
     while (k_cur < p.k_vol && cnt[k_cur] == 0) ++k_cur;
-    if (k_cur < p.k_vol) issue(0, k_cur, 0, cnt[k_cur], wc);
-    __syncthreads();
+    if (k_cur < p.k_vol) issue(0, k_cur, 0, cnt[k_cur], wcur);
+    LIDIFF_STAGE_BARRIER();
+    const lds_ptr_t a_lds = (lds_ptr_t)a_buf;
+
+    // all stages of one offset for a wave with NJ active row blocks (wr, wr + WR, ...), then the flush
+    auto run_offset = [&](auto nj_tag, int n, int k_next) {
+        constexpr int NJ = decltype(nj_tag)::value;
+        constexpr int NI = NJ * NS;                                   // (row block, 32-channel step) items per stage
+        f32x4 acc[NJ > 0 ? NJ : 1][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int slab = 0; slab < nslab; ++slab) {
+            if (slab + 1 < nslab) issue(img ^ IMG, k_cur, slab + 1, n, wnext);
+            else if (k_next < p.k_vol) issue(img ^ IMG, k_next, 0, cnt[k_next], wnext);
+            if (NJ > 0 && !(p.probe & 4)) {
+                const unsigned base = (unsigned)(uintptr_t)a_lds + img;
+                f32x4 f[2][2];                                        // [item parity][first / second 16-byte chunk]
+                auto read = [&](int it) {
+                    const int jj = it / NS, ss = it % NS;
+                    const unsigned a0 = base + (wr + WR * jj) * (16 * KS * 4);
+                    const unsigned x0 = a0 + foff[ss][0], x1 = a0 + foff[ss][1];
+                    f32x4 r0, r1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1));
+                    f[it & 1][0] = r0;
+                    f[it & 1][1] = r1;
+                };
+                read(0);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int jj = it / NS, ss = it % NS;
+                    if (it + 1 < NI) {
+                        read(it + 1);
+                        asm volatile("s_waitcnt lgkmcnt(2)");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x4 lo = f[it & 1][0], hi = f[it & 1][1];
+                    f32x8 rest = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bf16x8 a[P];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        a[q] = __builtin_convertvector(rest, bf16x8);              // round to nearest even
+                        if (q + 1 < P) {                                          // rest -= float(a[q]): two bit ops per packed pair
+                            const uint4 pk = __builtin_bit_cast(uint4, a[q]);
+                            const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                rest[2 * e] -= __builtin_bit_cast(float, w4[e] << 16);
+                                rest[2 * e + 1] -= __builtin_bit_cast(float, w4[e] & 0xffff0000u);
+                            }
+                        }
+                    }
+                    // all products of pieces with i + j < P, the smallest first
+#pragma unroll
+                    for (int d = P - 1; d >= 0; --d)
+#pragma unroll
+                        for (int i = 0; i <= d; ++i)
+#pragma unroll
+                            for (int cb = 0; cb < 2; ++cb)
+                                acc[jj][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    a[i], __builtin_bit_cast(bf16x8, wcur.v[ss][cb][d - i]), acc[jj][cb], 0, 0, 0);
+                }
+            }
+            LIDIFF_STAGE_BARRIER();
+            wcur = wnext;
+            img ^= IMG;
+        }
+        // flush: tile[row of pair][col] += acc.  An output row occurs at most once per offset, waves of one offset own disjoint
+        // (row block, column) pieces, and a stage barrier lies between the flushes of two offsets.
+        const int32_t* ol = out_list + k_cur * BM + 4 * lq;
+        if (p.probe & 8) return;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int4 o = *reinterpret_cast<const int4*>(ol + 16 * (wr + WR * j));
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int col = 32 * wc + 16 * cb + li;
+                acc_lds[o.x + col] += acc[j][cb][0];
+                acc_lds[o.y + col] += acc[j][cb][1];
+                acc_lds[o.z + col] += acc[j][cb][2];
+                acc_lds[o.w + col] += acc[j][cb][3];
+            }
+        }
+    };
+
     while (k_cur < p.k_vol) {
         const int n = cnt[k_cur];
         const int nb = (n + 15) >> 4;
         int k_next = k_cur + 1;
         while (k_next < p.k_vol && cnt[k_next] == 0) ++k_next;
-        f32x4 acc[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int slab = 0; slab < nslab; ++slab) {
-            if (slab + 1 < nslab) issue(img ^ IMG, k_cur, slab + 1, n, wn);
-            else if (k_next < p.k_vol) issue(img ^ IMG, k_next, 0, cnt[k_next], wn);
-            const char* As = reinterpret_cast<const char*>(a_buf) + img;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                if (b < nb) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        const float4 lo = *reinterpret_cast<const float4*>(As + b * (16 * KS * 4) + foff[s][0]);
-                        const float4 hi = *reinterpret_cast<const float4*>(As + b * (16 * KS * 4) + foff[s][1]);
-                        const f32x8 av = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                        const bf16x8 a = __builtin_convertvector(av, bf16x8);              // round to nearest even
-                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, wc[s]), acc[b], 0, 0, 0);
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < NS; ++s) wc[s] = wn[s];
-            img ^= IMG;
-        }
-        // flush: tile[row of pair][col] += acc (each output row at most once per offset; waves own disjoint columns)
-        const int32_t* ol = out_list + k_cur * BM + 4 * lq;
-        const int colb = 16 * wave + li;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if (b < nb) {
-                const int4 o = *reinterpret_cast<const int4*>(ol + 16 * b);
-                acc_lds[o.x + colb] += acc[b][0];
-                acc_lds[o.y + colb] += acc[b][1];
-                acc_lds[o.z + colb] += acc[b][2];
-                acc_lds[o.w + colb] += acc[b][3];
-            }
-        }
+        const int nj = nb > wr ? (nb - wr + WR - 1) / WR : 0;          // this wave's active row blocks: wr + WR j < nb
+        if (RB >= 4 && nj == 4) run_offset(ic<(RB >= 4 ? 4 : 0)>{}, n, k_next);
+        else if (RB >= 4 && nj == 3) run_offset(ic<(RB >= 4 ? 3 : 0)>{}, n, k_next);
+        else if (RB >= 2 && nj == 2) run_offset(ic<(RB >= 2 ? 2 : 0)>{}, n, k_next);
+        else if (nj == 1) run_offset(ic<1>{}, n, k_next);
+        else run_offset(ic<0>{}, n, k_next);
         k_cur = k_next;
     }
-    __syncthreads();
+#undef LIDIFF_STAGE_BARRIER
+    __syncthreads();                     // the last flush (no request is in flight any more)
 
     // ---- epilogue ------------------------------------------------------------------------------------------
     for (int e = tid; e < rows_here * (BN / 4); e += NT) {
@@ -237,12 +324,11 @@ __global__ __launch_bounds__(64 * WN) void spconv_fwd_bf16_kernel(const ConvPara
     }
 }
 
-template <int WN, int KS>
+template <int BM, int WC, int WR, int KS, int P>
 static int launch_bf16(const ConvParams& p, hipStream_t st) {
-    using namespace bf16k;
-    constexpr int BN = 16 * WN;
+    constexpr int BN = 32 * WC;
     const size_t lds = (size_t)2 * BM * KS * 4 + (size_t)(BM + 1) * BN * 4 + (size_t)p.k_vol * BM * 8 + 32 * 4 + BM * 4;
-    auto kern = spconv_fwd_bf16_kernel<WN, KS>;
+    auto kern = spconv_fwd_bf16_kernel<BM, WC, WR, KS, P>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -252,38 +338,52 @@ static int launch_bf16(const ConvParams& p, hipStream_t st) {
     q.tiles_m = (int)ceil_div(p.m_out, BM);
     q.tiles_n = p.c_out / BN;
     const unsigned grid = (unsigned)(ceil_div((int64_t)q.tiles_m * q.replicas, 8) * 8 * q.tiles_n);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN), lds, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WC * WR), lds, st, q);
     LIDIFF_CHECK_LAUNCH();
     return 0;
+}
+
+template <int P>
+static int dispatch_bf16(const ConvParams& p, bool ks64, hipStream_t st) {
+    // three planes: 32-channel stages only (the W registers of a 64-channel stage would not fit beside the accumulators)
+#define LIDIFF_BF16(BM, WC, WR) \
+    return ks64 && P < 3 ? launch_bf16<BM, WC, WR, (P < 3 ? 64 : 32), P>(p, st) : launch_bf16<BM, WC, WR, 32, P>(p, st)
+    if (p.c_out % 128 == 0) LIDIFF_BF16(128, 4, 2);
+    if (p.c_out % 96 == 0) LIDIFF_BF16(128, 3, 2);
+    if (p.c_out % 64 == 0) LIDIFF_BF16(128, 2, 4);
+    LIDIFF_BF16(128, 1, 8);
+#undef LIDIFF_BF16
 }
 
 }  // namespace lidiff
 
 using namespace lidiff;
 
-extern "C" int64_t lidiff_spconv_packed_weight_bf16_elems(int32_t k_vol, int32_t c_in, int32_t c_out) {
-    return (int64_t)k_vol * ((c_in + 31) / 32) * 32 * c_out;
+extern "C" int64_t lidiff_spconv_packed_weight_bf16_elems(int32_t k_vol, int32_t c_in, int32_t c_out, int32_t planes) {
+    return (int64_t)k_vol * ((c_in + 31) / 32) * 32 * c_out * planes;
 }
 
-extern "C" int lidiff_spconv_pack_weights_bf16(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out, void* w_packed,
-                                               void* stream) {
+extern "C" int lidiff_spconv_pack_weights_bf16(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out, int32_t planes,
+                                               void* w_packed, void* stream) {
     LIDIFF_CHECK_ARG(w != nullptr && w_packed != nullptr, "null pointer");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && c_in > 0, "kernel volume must be 1..27, c_in > 0");
     LIDIFF_CHECK_ARG(c_out > 0 && c_out % 16 == 0, "c_out must be a multiple of 16");
+    LIDIFF_CHECK_ARG(planes >= 1 && planes <= 3, "planes must be 1, 2 or 3");
     const int nslab = (c_in + 31) / 32;
-    const int64_t total = lidiff_spconv_packed_weight_bf16_elems(k_vol, c_in, c_out);
-    pack_weights_bf16_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w, k_vol, c_in, c_out, nslab,
+    const int64_t total = lidiff_spconv_packed_weight_bf16_elems(k_vol, c_in, c_out, planes);
+    pack_weights_bf16_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w, k_vol, c_in, c_out, nslab, planes,
                                                                                              (__bf16*)w_packed, total);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b, const void* w_packed,
-                                      const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out,
-                                      float* out, const float* ep_scale, const float* ep_shift, const float* residual,
-                                      int32_t relu, int32_t replicas, void* stream) {
+                                      int32_t planes, const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out,
+                                      int32_t c_out, float* out, const float* ep_scale, const float* ep_shift,
+                                      const float* residual, int32_t relu, int32_t replicas, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && w_packed != nullptr && out != nullptr, "null pointer");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
+    LIDIFF_CHECK_ARG(planes >= 1 && planes <= 3, "planes must be 1, 2 or 3");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
     LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
     LIDIFF_CHECK_ARG(c_in_a % 32 == 0 && c_in_b % 32 == 0, "the bf16 kernel needs input widths that are multiples of 32");
@@ -296,18 +396,22 @@ extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const f
                      "pointers must be 16-byte aligned");
     LIDIFF_CHECK_ARG(m_in * (int64_t)c_in_a * 4 < (1ll << 31) && m_in * (int64_t)c_in_b * 4 < (1ll << 31),
                      "a feature matrix exceeds the 2 GiB buffer-descriptor range");
+    LIDIFF_CHECK_ARG(lidiff_spconv_packed_weight_bf16_elems(k_vol, c_in_a + c_in_b, c_out, planes) * 2 < (1ll << 31),
+                     "packed weights exceed the 2 GiB buffer-descriptor range");
     ConvParams p{};
     p.in_a = in_a; p.in_b = in_b; p.wp = reinterpret_cast<const float*>(w_packed); p.nbr = nbr; p.out = out;
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
     p.k_vol = k_vol; p.relu = relu; p.replicas = replicas;
+    // measurement aid (tools/conv_probe.py --kernel bf16): LIDIFF_BF16_PROBE bits switch parts of the kernel off -- 1 no
+    // gather traffic (zero-filled rows), 2 one hot W slab, 4 no fragment reads / MFMAs, 8 no flush, 16 no gather requests,
+    // 32 no stage barrier.  Results are wrong with any bit set.
+    static const int probe = [] { const char* e = getenv("LIDIFF_BF16_PROBE"); return e ? atoi(e) : 0; }();
+    p.probe = probe;
     hipStream_t st = (hipStream_t)stream;
     const bool ks64 = c_in_a % 64 == 0 && c_in_b % 64 == 0;
-#define LIDIFF_BF16(WN) return ks64 ? launch_bf16<WN, 64>(p, st) : launch_bf16<WN, 32>(p, st)
-    if (c_out % 128 == 0) LIDIFF_BF16(8);
-    if (c_out % 96 == 0) LIDIFF_BF16(6);
-    if (c_out % 64 == 0) LIDIFF_BF16(4);
-    LIDIFF_BF16(2);
-#undef LIDIFF_BF16
+    if (planes == 1) return dispatch_bf16<1>(p, ks64, st);
+    if (planes == 2) return dispatch_bf16<2>(p, ks64, st);
+    return dispatch_bf16<3>(p, ks64, st);
 }

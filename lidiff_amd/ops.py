@@ -256,6 +256,11 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     kernel_size-3 map.  tail = (rows [R * P, C_out], ptr int32 [m_out + 1], idx int32 [P]): rows added to the sum before
     the epilogue, out[o] += sum(rows[idx[ptr[o]:ptr[o + 1]]]) -- the other offsets' contributions (TailMap)."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
+    if (SPLIT_PLANES and not sparse_map and row_order is None and tail is None and offset is None
+            and bf16_conv_applies(in_a.shape[1], 0 if in_b is None else in_b.shape[1], w.shape[-1])
+            and w.shape[-1] % SPLIT_MIN_COUT == 0):
+        return spconv_fwd_bf16(in_a, w, nbr, m_out, in_b=in_b, scale=scale, shift=shift, residual=residual, relu=relu,
+                               replicas=replicas, planes=SPLIT_PLANES)
     wp = packed_weights(w, offset)
     if w.dim() == 2:
         k, (c_in, c_out) = 1, w.shape
@@ -306,6 +311,29 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     return out
 
 
+# Opt-in for the INFERENCE forward (never the benchmark's `value`; bench.py reports it as "alt"): 0 = native fp32 MFMA
+# (default); 2 / 3 = the dense-map layers (no sparse hint, C_out a multiple of SPLIT_MIN_COUT) through lidiff_spconv_fwd_bf16
+# with every operand cut into 2 / 3 bf16 pieces -- 3 / 6 bf16 MFMAs per block, fp32 accumulation, fp32-accurate results.
+SPLIT_PLANES = int(os.environ.get("LIDIFF_SPLIT_PLANES", "0"))
+SPLIT_MIN_COUT = 128
+
+
+class split_planes:
+    """with ops.split_planes(2): ... -- the inference forward's dense layers from bf16 pieces."""
+
+    def __init__(self, planes: int):
+        assert planes in (0, 2, 3)
+        self.planes = planes
+
+    def __enter__(self):
+        global SPLIT_PLANES
+        self.prev, SPLIT_PLANES = SPLIT_PLANES, self.planes
+
+    def __exit__(self, *exc):
+        global SPLIT_PLANES
+        SPLIT_PLANES = self.prev
+
+
 # GEMM operand precision of the TRAINING convolutions (_SparseConv forward and input gradient): "f32" or "bf16"
 # (BASELINE.json configs[4]: train.py under bf16 autocast).  The inference path always runs fp32 (configs[1]).
 TRAIN_OPERANDS = "f32"
@@ -338,12 +366,12 @@ def bf16_conv_applies(c_a: int, c_b: int, c_out: int, sparse_map: bool = False) 
     return c_a % 32 == 0 and c_b % 32 == 0 and c_out % 32 == 0 and (BF16_SPARSE_MAPS or not sparse_map)
 
 
-def packed_weights_bf16(w: torch.Tensor, transposed: bool = False, flip: bool = False) -> torch.Tensor:
+def packed_weights_bf16(w: torch.Tensor, transposed: bool = False, flip: bool = False, planes: int = 1) -> torch.Tensor:
     """lidiff_spconv_pack_weights_bf16 of w [K, C_in, C_out] -- or, transposed, of the input-gradient kernel
-    w[::-1 if flip].transpose(1, 2) -- cached on the Parameter like packed_weights()."""
+    w[::-1 if flip].transpose(1, 2) -- in `planes` bf16 pieces, cached on the Parameter like packed_weights()."""
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
     key = (w.data_ptr(), w._version, tuple(w3.shape), w.device)
-    attr = "_lidiff_packed_bf16" + ("_t" if transposed else "") + ("f" if flip else "")
+    attr = f"_lidiff_packed_bf16x{planes}" + ("_t" if transposed else "") + ("f" if flip else "")
     hit = getattr(w, attr, None)
     if hit is None or hit[0] != key:
         src = w3.detach()
@@ -351,9 +379,9 @@ def packed_weights_bf16(w: torch.Tensor, transposed: bool = False, flip: bool = 
             src = (src.flip(0) if flip else src).transpose(1, 2)
         src = src.contiguous().float()
         k, c_in, c_out = src.shape
-        n = _lib.load().lidiff_spconv_packed_weight_bf16_elems(k, c_in, c_out)
+        n = _lib.load().lidiff_spconv_packed_weight_bf16_elems(k, c_in, c_out, planes)
         wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
-        call("lidiff_spconv_pack_weights_bf16", ptr(src), k, c_in, c_out, ptr(wp), stream_ptr())
+        call("lidiff_spconv_pack_weights_bf16", ptr(src), k, c_in, c_out, planes, ptr(wp), stream_ptr())
         hit = (key, wp)
         try:
             setattr(w, attr, hit)
@@ -364,15 +392,17 @@ def packed_weights_bf16(w: torch.Tensor, transposed: bool = False, flip: bool = 
 
 def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                     in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None, relu: bool = False,
-                    replicas: int = 1, transposed: bool = False, flip: bool = False) -> torch.Tensor:
-    """spconv_fwd with bf16 GEMM operands and fp32 accumulation (lidiff_spconv_fwd_bf16; include/lidiff_amd.h).
+                    replicas: int = 1, transposed: bool = False, flip: bool = False, planes: int = 1) -> torch.Tensor:
+    """spconv_fwd with bf16 matrix operands and fp32 accumulation (lidiff_spconv_fwd_bf16; include/lidiff_amd.h).
+    planes = 1: operands rounded to bf16 (mixed-precision training); planes = 2 / 3: every operand cut into 2 / 3 bf16
+    pieces, 3 / 6 MFMAs per block, fp32-accurate results.
     transposed: convolve with w[::-1 if flip].transpose(1, 2) -- the input gradient over the swapped map."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
     k, c_in, c_out = w3.shape
     if transposed:
         c_in, c_out = c_out, c_in
-    wp = packed_weights_bf16(w, transposed, flip)
+    wp = packed_weights_bf16(w, transposed, flip, planes)
     in_a = in_a.contiguous()
     c_a, c_b = in_a.shape[1], 0
     if in_b is not None:
@@ -387,11 +417,19 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
         residual = residual.contiguous()
         assert residual.shape == (replicas * m_out, c_out)
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
-    call("lidiff_spconv_fwd_bf16", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out, c_out, ptr(out),
-         ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), stream_ptr())
     prof = PROFILER
+    variant = "bf16" if planes == 1 else f"bf16x{planes}"
+    timed = prof is not None and prof.wants(variant)
+    start = end = None
+    if timed:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+    call("lidiff_spconv_fwd_bf16", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), int(planes), ptr(nbr), k, m_in, m_out, c_out,
+         ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), stream_ptr())
+    if timed:
+        end.record()
     if prof is not None:
-        prof.launches.append(("bf16", None, None, m_in, m_out, c_in, c_out, k, nbr, replicas))
+        prof.launches.append((variant, start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
     return out
 
 

@@ -81,6 +81,7 @@ inline int32_t floor_div(int32_t a, int32_t s) {
 extern "C" {
 
 int me_ref_threads() { return omp_get_max_threads(); }
+void me_ref_set_threads(int n) { omp_set_num_threads(n); }
 
 // unique rows in first-occurrence order after flooring columns 1..3 to multiples of s (s = 1: voxelize).
 // uniq [n,4] (first *m valid), inverse [n] (int64), first_idx [n].  Returns 0, or 1 if a coordinate leaves the key range.

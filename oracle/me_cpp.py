@@ -35,6 +35,12 @@ def threads() -> int:
     return int(lib().me_ref_threads())
 
 
+def set_threads(n: int) -> None:
+    """OpenMP threads of the C++ primitives and of torch-CPU (the oracle's MLP / BatchNorm side)."""
+    lib().me_ref_set_threads(int(n))
+    torch.set_num_threads(int(n))
+
+
 def _np(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 

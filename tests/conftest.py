@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The oracle legs are many small torch-CPU / numpy ops: on a 128-thread box the default thread count makes them ~20x
+# SLOWER than on 8 cores (measured: the T = 50 oracle trajectory 632 s on the GPU box against 29 s in the build
+# container), so the test session caps the CPU thread pool.  bench.py's cpu_baseline is not affected (own process).
+torch.set_num_threads(min(torch.get_num_threads(), 16))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

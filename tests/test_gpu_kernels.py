@@ -628,6 +628,56 @@ def test_spconv_bf16_operands_vs_oracle_on_rounded_inputs(device, kind, cin, cou
         assert torch.allclose(got2[m_out:], -2.0 * got, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("kind,cin,cout,split,epilogue", [
+    ("k3", 32, 32, 0, False), ("k3", 64, 128, 0, True), ("k3", 96, 96, 0, False), ("k3", 256, 256, 0, False),
+    ("k3", 384, 256, 256, True), ("k3", 160, 64, 96, False), ("down", 128, 128, 0, False), ("up", 256, 128, 0, True),
+    ("k1", 384, 256, 256, False)])
+def test_spconv_from_bf16_pieces_is_fp32_accurate(device, planes, kind, cin, cout, split, epilogue):
+    """lidiff_spconv_fwd_bf16 with planes = 2 / 3 (the opt-in inference mode, ops.split_planes): every operand cut into
+    bf16 pieces, 3 / 6 bf16 MFMAs per block.  Against the float64 oracle on the UNROUNDED operands the result must pass the
+    fp32 kernel's own bar (rtol / atol 1e-4), and its maximum error is held against the native fp32 kernel's on the same
+    case: three pieces are fp32-equal (within 1.5x + 1e-6); two pieces keep 16-17 bits per product (the dropped x2 w2
+    terms are 2^-18 of the products) -- measured 10-25x the fp32 kernel's error, 2-4e-5 on O(1) outputs; bar: 20x or 5e-5."""
+    from lidiff_amd import ops
+    coords = random_cloud(4000, 6, 41, batch=2)
+    uniq, _, _ = me.voxelize(coords)
+    coarse, _ = me.stride_map(uniq, 2)
+    if kind == "k3":
+        nbr, m_in, m_out, K = me.kernel_map(uniq, uniq, 3, 1), uniq.shape[0], uniq.shape[0], 27
+    elif kind == "down":
+        nbr, m_in, m_out, K = me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0], coarse.shape[0], 8
+    elif kind == "up":
+        nbr = me.transpose_kernel_map(me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0])
+        m_in, m_out, K = coarse.shape[0], uniq.shape[0], 8
+    else:
+        nbr, m_in, m_out, K = None, uniq.shape[0], uniq.shape[0], 1
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(m_in, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) / np.sqrt(cin * max(1, K // 3))
+    want = me.conv_forward(x.double(), w.double() if K > 1 else w[0].double(), nbr)
+    scale = shift = res = None
+    if epilogue:
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        res = torch.randn(m_out, cout, generator=g)
+        want = torch.relu(want * scale.double() + shift.double() + res.double())
+    d = lambda t: None if t is None else t.to(device)
+    nbr_d = None if nbr is None else dev_i32(nbr, device)
+    kw = dict(scale=d(scale), shift=d(shift), residual=d(res), relu=epilogue)
+    xa, xb = (d(x), None) if not split else (d(x[:, :split].contiguous()), d(x[:, split:].contiguous()))
+    got = ops.spconv_fwd_bf16(xa, d(w), nbr_d, m_out, in_b=xb, planes=planes, **kw)
+    f32 = ops.spconv_fwd(xa, d(w), nbr_d, m_out, in_b=xb, **kw)
+    torch.cuda.synchronize()
+    err = (got.cpu().double() - want).abs().max().item()
+    err32 = (f32.cpu().double() - want).abs().max().item()
+    assert torch.allclose(got.cpu().double(), want, rtol=RTOL, atol=ATOL), f"{kind} {cin}->{cout}: max err {err}"
+    assert err <= (max(20.0 * err32, 5e-5) if planes == 2 else 1.5 * err32 + 1e-6), (err, err32)
+    # the switch of the inference path takes this kernel for the dense 128-column layers only
+    with ops.split_planes(planes):
+        routed = ops.spconv_fwd(xa, d(w), nbr_d, m_out, in_b=xb, **kw)
+    assert torch.equal(routed, got if cout % 128 == 0 else f32)
+
+
 @pytest.mark.parametrize("kind,ks,stride,cin,cout", [("conv", 3, 1, 32, 64), ("conv", 2, 2, 64, 64), ("tconv", 2, 2, 64, 32),
                                                     ("conv", 1, 1, 96, 32), ("conv", 3, 1, 256, 256), ("conv", 3, 1, 32, 48)])
 def test_spconv_bf16_training_backward_vs_oracle_autograd(device, kind, ks, stride, cin, cout):

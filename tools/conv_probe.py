@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--lpt", action="store_true", help="128-row tiles in descending pair-count order (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
     ap.add_argument("--kernel", default="tile", choices=["tile", "dense", "dense1", "bf16"], help="kernel of the dense 128-column layers")
+    ap.add_argument("--planes", type=int, default=1, help="--kernel bf16: bf16 pieces per operand (1 = rounded, 2 / 3 = split)")
     ap.add_argument("--centre-tail", action="store_true", help="k3 layers as centre pass + tail rows (ops.spconv_centre_tail)")
     ap.add_argument("--timeline", action="store_true",
                     help="diagnostic build: per-workgroup cycle counters (prologue / main loop / epilogue / barrier / flush)")
@@ -105,7 +106,7 @@ def main():
             tmap = ops.TailMap(nbr)
             conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out)
         elif args.kernel == "bf16" and ops.bf16_conv_applies(cin, 0, cout):
-            conv = lambda: ops.spconv_fwd_bf16(x, w, nbr, m_out)
+            conv = lambda: ops.spconv_fwd_bf16(x, w, nbr, m_out, planes=args.planes)
         else:
             conv = lambda: ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
         for _ in range(3):

@@ -200,6 +200,15 @@ def _run_up(up, x, skip):
     return up[1](ME.cat(y, skip))
 
 
+def _run_mlp(mlp, x):
+    """A conditioning / head MLP on feature rows.  Under ops.train_operands("bf16") (BASELINE configs[4]) its Linears run as
+    bf16 GEMMs with fp32 accumulation, forward and backward (torch.autocast), and hand fp32 rows back."""
+    if ops.TRAIN_OPERANDS == "bf16" and torch.is_grad_enabled() and x.is_cuda:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return mlp(x).float()
+    return mlp(x)
+
+
 def _mlp(cin, hidden, cout, tail=None):
     layers = [nn.Linear(cin, hidden), nn.LeakyReLU(0.1, inplace=True), nn.Linear(hidden, cout)]
     if tail is not None:
@@ -408,9 +417,9 @@ class MinkUNetDiff(_Base):
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"
-        p = latent(self.match_part_to_full(x, part))
+        p = _run_mlp(latent, self.match_part_to_full(x, part))
         t = self._per_batch_rows(temp(temp_emb), x)
-        return x * latemp(torch.cat((t, p) if t_first else (p, t), -1))
+        return x * _run_mlp(latemp, torch.cat((t, p) if t_first else (p, t), -1))
 
     # -- minkunet.py:420-497 --------------------------------------------------------------
     def forward(self, x, x_sparse, part_feats, t):
@@ -436,7 +445,7 @@ class MinkUNetDiff(_Base):
                 inv = torch.cat([inv + r * m0 for r in range(y.replicas)])
             out = ops.gather_rows(self.last(y.F), inv)
             return tuple(out.chunk(y.replicas, dim=0)) if multi else out
-        return self.last(y.slice(x).F)
+        return _run_mlp(self.last, y.slice(x).F)
 
 
 class MinkUNet(_Base):
@@ -462,4 +471,4 @@ class MinkUNet(_Base):
             y = _run_up(getattr(self, f"up{j + 1}"), y, feats[3 - j])
         if _fusable(self):
             return ops.gather_rows(self.last(y.F), x.inverse_mapping)
-        return self.last(y.slice(x).F)
+        return _run_mlp(self.last, y.slice(x).F)

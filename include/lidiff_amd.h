@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 13
+#define LIDIFF_ABI_VERSION 14
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -249,6 +249,12 @@ int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m,
 int64_t lidiff_fps_workspace_bytes(int64_t n_points);
 int lidiff_fps(const double* points, int64_t n_points, int64_t n_samples, int64_t* selected, void* workspace,
                void* stream);
+/* The same selection as ONE persistent cooperative launch (device-wide barrier per selection instead of a launch per
+ * selection; 134 ms against 198 ms for 18 000 of 119 035 points).  *status (device int32, zeroed by the call) turns non-zero if the barrier
+ * timed out -- the selection is then incomplete: run lidiff_fps.  Returns non-zero, nothing enqueued, when the device
+ * cannot hold the grid co-resident (no cooperative launch, or more than 8192 points per CU). */
+int lidiff_fps_coop(const double* points, int64_t n_points, int64_t n_samples, int64_t* selected, void* workspace,
+                    int32_t* status, void* stream);
 
 /* Nearest neighbour of every point of a [n,3] in b [m,3] (both float when elem_bytes = 4, both double when 8):
  * d2[i] = min_j |a_i - b_j|^2 (element type of the inputs), idx[i] = the lowest such j.  Replaces open3d

@@ -50,12 +50,13 @@ SIGNATURES = {
     "lidiff_argmin_rows_f32": (_i32, [_p, _i64, _p, _i64, _p, _p]),
     "lidiff_fps_workspace_bytes": (_i64, [_i64]),
     "lidiff_fps": (_i32, [_p, _i64, _i64, _p, _p, _p]),
+    "lidiff_fps_coop": (_i32, [_p, _i64, _i64, _p, _p, _p, _p]),
     "lidiff_nn_match_grid": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p]),
     "lidiff_nn_dist_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 

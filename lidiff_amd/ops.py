@@ -528,10 +528,12 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
     return dst
 
 
+FPS_COOPERATIVE = os.environ.get("LIDIFF_FPS_COOPERATIVE", "1") != "0"
+
+
 def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
     """open3d farthest_point_down_sample stand-in of preprocess_scan (pipeline:97-99): indices of n_samples
-    points, greedy from index 0, float64 squared distances, first maximum wins.  One kernel per selection, queued
-    without host synchronisation."""
+    points, greedy from index 0, float64 squared distances, first maximum wins."""
     require_device(points)
     pts = points.contiguous().double()
     n = pts.shape[0]
@@ -539,6 +541,17 @@ def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
         return torch.arange(n, device=pts.device)
     sel = torch.empty(n_samples, dtype=torch.int64, device=pts.device)
     ws = torch.empty(_lib.load().lidiff_fps_workspace_bytes(n), dtype=torch.uint8, device=pts.device)
+    if FPS_COOPERATIVE:
+        # one persistent cooperative launch (device-wide barrier per selection).  Its status word is read back -- the caller
+        # indexes with the result on the host side of the step anyway -- and a barrier time-out, or a device that cannot
+        # hold the grid co-resident, falls back to the launch-per-selection kernel below (same indices).
+        status = torch.empty(1, dtype=torch.int32, device=pts.device)
+        try:
+            call("lidiff_fps_coop", ptr(pts), n, int(n_samples), ptr(sel), ptr(ws), ptr(status), stream_ptr())
+            if int(status.item()) == 0:
+                return sel
+        except RuntimeError:
+            pass
     call("lidiff_fps", ptr(pts), n, int(n_samples), ptr(sel), ptr(ws), stream_ptr())
     return sel
 

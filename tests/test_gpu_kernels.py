@@ -429,9 +429,22 @@ def test_fps_reproduces_the_committed_scan_from_the_range_filtered_input(device,
     from lidiff_amd import ops
     from oracle.fps_cpu import farthest_point_sample as fps_oracle
     pts = np.load(os.path.join(GOLDEN, "scan_000123_range_filtered.npy")).astype(np.float64)
-    sel = ops.farthest_point_sample(torch.from_numpy(pts).to(device), 18000).cpu().numpy()
-    assert np.array_equal(pts[sel].astype(np.float32), fps_scan)
-    assert np.array_equal(sel[:300], fps_oracle(pts, 300))
+    import time
+    pts_d = torch.from_numpy(pts).to(device)
+    took = {}
+    for coop in (True, False):            # the persistent cooperative kernel and the launch-per-selection kernel
+        ops.FPS_COOPERATIVE = coop
+        try:
+            ops.farthest_point_sample(pts_d, 64)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sel = ops.farthest_point_sample(pts_d, 18000).cpu().numpy()
+            took[coop] = time.perf_counter() - t0
+        finally:
+            ops.FPS_COOPERATIVE = True
+        assert np.array_equal(pts[sel].astype(np.float32), fps_scan), f"cooperative={coop}"
+        assert np.array_equal(sel[:300], fps_oracle(pts, 300))
+    print(f"FPS 119 035 -> 18 000: cooperative launch {1e3 * took[True]:.1f} ms, one launch per selection {1e3 * took[False]:.1f} ms")
 
 
 def test_sparse_quantize_vs_oracle(device):

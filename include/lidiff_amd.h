@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 14
+#define LIDIFF_ABI_VERSION 15
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -200,6 +200,13 @@ int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const float* in_b, in
                         const float* grad_out, const int32_t* pairs_in, const int32_t* pairs_out,
                         const int32_t* offset_ptr, int64_t n_pairs, int32_t k_vol,
                         int64_t m_in, int64_t m_out, int32_t c_out, float* dw, float* workspace, void* stream);
+/* lidiff_spconv_bwd_w with bf16 operands (bf16 training, planes = 1 of lidiff_spconv_fwd_bf16): the gathered rows of `in`
+ * and `grad_out` are rounded to bf16 (nearest even) on their way into v_mfma_f32_16x16x32_bf16, sums in fp32.  Same
+ * arguments, tiles, pair slices and workspace (lidiff_spconv_bwd_w_workspace_floats) as lidiff_spconv_bwd_w. */
+int lidiff_spconv_bwd_w_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b, const float* grad_out,
+                             const int32_t* pairs_in, const int32_t* pairs_out, const int32_t* offset_ptr, int64_t n_pairs,
+                             int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* dw, float* workspace,
+                             void* stream);
 
 /* Row gather / scatter-add -- SparseTensor.slice(field).F minkunet.py:497,619 and the
  * x_part.F[idx] of match_part_to_full minkunet.py:418; scatter-add is their backward. */

@@ -200,7 +200,7 @@ class _SparseConv(torch.autograd.Function):
             wt = (w3.flip(0) if ctx.flip else w3).transpose(1, 2).contiguous()
             gx = ops.spconv_fwd(g, wt, nbr_swapped, x.shape[0])
         if ctx.needs_input_grad[1]:
-            gw = ops.spconv_bwd_w(x, g, nbr, w3.shape[0]).reshape(kernel.shape)
+            gw = ops.spconv_bwd_w(x, g, nbr, w3.shape[0], bf16=ctx.bf16).reshape(kernel.shape)
         return gx, gw, None, None, None, None, None
 
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "lidiff_spconv_fwd_bf16": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p]),
     "lidiff_spconv_bwd_w_workspace_floats": (_i64, [_i32, _i32, _i32, _i64]),
     "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p]),
+    "lidiff_spconv_bwd_w_bf16": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p]),
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
@@ -56,7 +57,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 

@@ -47,6 +47,11 @@ struct ConvParams {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
+// weight gradient (spconv.hip, spconv_bf16.hip): pairs per chunk, pair slices per offset, the slice-ordered reduction
+constexpr int kDwPairs = 64;
+int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot);
+__global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n, int slices, float* __restrict__ dw);
+
 // spconv_dense.hip: can this convolution take the dense kernel / launch it.
 bool dense_kernel_applies(const ConvParams& p);
 int launch_fwd_dense(const ConvParams& p, hipStream_t st);

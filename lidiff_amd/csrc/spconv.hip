@@ -762,7 +762,6 @@ namespace lidiff {
 // a conflict-free 4-byte read, and nothing is transposed.  The next chunk's rows are prefetched into registers
 // while the current one is multiplied.  Slices are summed with fp32 atomics (as ME does), so dW is deterministic
 // only up to the order of those adds.
-constexpr int kDwPairs = 64;                              // pairs per chunk (K of the product: 16 MFMA steps)
 
 template <int NBI, int CB, bool IDENT>
 __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restrict__ in_a, int c_in_a,
@@ -899,7 +898,7 @@ __global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n, int 
     dw[e] = v;
 }
 
-static int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot) {
+int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot) {
     const int tiles = (int)(ceil_div(c_in, cit) * ceil_div(c_out, cot));
     // pair slices: a few workgroups per CU, but at least 4 chunks each (pairs spread evenly over the offsets)
     int64_t slices = ceil_div((int64_t)1024, (int64_t)tiles * k_vol);

@@ -355,9 +355,221 @@ static int dispatch_bf16(const ConvParams& p, bool ks64, hipStream_t st) {
 #undef LIDIFF_BF16
 }
 
+// =======================================================================================
+// Weight gradient with bf16 operands (bf16 training): dW[k] = in[pairs_k]^T g[pairs_k] as in spconv.hip's
+// spconv_bwd_w_kernel -- same tiles ([16 NBI ci] x [128 CB co] of dW[k] in MFMA accumulators, wave w the co blocks
+// w CB .., pair slices, workspace reduction) -- but the gathered rows of a 64-pair chunk are rounded to bf16 and stored
+// TRANSPOSED in LDS, a_t[ci][pair] / g_t[co][pair] (row pitch 144 B: conflict-free 16-byte reads), so the operand of
+// v_mfma_f32_16x16x32_bf16 -- 8 consecutive pairs of one channel -- is one ds_read_b128 and a chunk is 2 MFMA steps per
+// block instead of 16.  Each thread gathers one (channel quad, pair octet): 8 float4 loads, 4 ds_write_b128.
+template <int NBI, int CB, bool IDENT>
+__global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __restrict__ in_a, int c_in_a,
+                                                                const float* __restrict__ in_b, int c_in_b,
+                                                                const float* __restrict__ g, const int32_t* __restrict__ pairs_in,
+                                                                const int32_t* __restrict__ pairs_out,
+                                                                const int32_t* __restrict__ offset_ptr, int64_t m_out,
+                                                                int c_out, int slices, float* __restrict__ dw,
+                                                                float* __restrict__ part, int k_vol) {
+    constexpr int CIT = 16 * NBI, COT = 128 * CB;
+    constexpr int PB = 2 * kDwPairs + 16;                    // LDS row pitch in bytes
+    constexpr int UA = (CIT / 4) * 8, UG = (COT / 4) * 8;    // (channel quad, pair octet) units per chunk
+    constexpr int NA = (UA + 511) / 512, NG = (UG + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_t = smem;                                        // [ci][pair] bf16
+    char* g_t = smem + CIT * PB;                             // [co][pair] bf16
+    const int c_in = c_in_a + c_in_b;
+    const int k = blockIdx.x;
+    const int co_tiles = (c_out + COT - 1) / COT;
+    const int ci0 = (blockIdx.y / co_tiles) * CIT, co0 = (blockIdx.y % co_tiles) * COT;
+    const int64_t p_lo = IDENT ? 0 : offset_ptr[k], p_hi = IDENT ? m_out : offset_ptr[k + 1];
+    const int64_t per = (((p_hi - p_lo + slices - 1) / slices + kDwPairs - 1) / kDwPairs) * kDwPairs;
+    const int64_t s_lo = p_lo + (int64_t)blockIdx.z * per, s_hi = min(p_hi, s_lo + per);
+    if (s_lo >= s_hi) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+
+    float4 pa[NA][8], pg[NG][8];                             // the next chunk's rows, in flight
+    unsigned keep_a[NA], keep_g[NG];                         // bit i: pair i of the unit is real
+    auto fetch = [&](int64_t base) {
+        int ra[NA][8], rg[NG][8];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int oct = min(tid + 512 * t, UA - 1) / (CIT / 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t pp = min(base + 8 * oct + i, s_hi - 1);
+                ra[t][i] = IDENT ? (int)pp : pairs_in[pp];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int oct = min(tid + 512 * t, UG - 1) / (COT / 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t pp = min(base + 8 * oct + i, s_hi - 1);
+                rg[t][i] = IDENT ? (int)pp : pairs_out[pp];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int u = tid + 512 * t, uc = min(u, UA - 1), oct = uc / (CIT / 4), ci = ci0 + (uc % (CIT / 4)) * 4;
+            const int cic = min(ci, c_in - 4);
+            keep_a[t] = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float* src = cic < c_in_a ? in_a + (unsigned)(ra[t][i] * c_in_a + cic)
+                                                : in_b + (unsigned)(ra[t][i] * c_in_b + (cic - c_in_a));
+                pa[t][i] = *reinterpret_cast<const float4*>(src);
+                keep_a[t] |= (u < UA && base + 8 * oct + i < s_hi && ci < c_in) ? 1u << i : 0u;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int u = tid + 512 * t, uc = min(u, UG - 1), oct = uc / (COT / 4), co = co0 + (uc % (COT / 4)) * 4;
+            keep_g[t] = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pg[t][i] = *reinterpret_cast<const float4*>(g + (unsigned)(rg[t][i] * c_out + min(co, c_out - 4)));
+                keep_g[t] |= (u < UG && base + 8 * oct + i < s_hi && co < c_out) ? 1u << i : 0u;
+            }
+        }
+    };
+    // the unit's 8 pairs x 4 channels -> four rows of 8 bf16 (round to nearest even), zero where the pair is not real
+    auto put = [&](char* dst, const float4 (&v)[8], unsigned keep, int quad, int oct) {
+        float m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = (keep >> i) & 1u ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x8 r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = (j == 0 ? v[i].x : j == 1 ? v[i].y : j == 2 ? v[i].z : v[i].w) * m[i];
+            *reinterpret_cast<bf16x8*>(dst + (4 * quad + j) * PB + 16 * oct) = __builtin_convertvector(r, bf16x8);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int u = tid + 512 * t;
+            if (u < UA) put(a_t, pa[t], keep_a[t], u % (CIT / 4), u / (CIT / 4));
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int u = tid + 512 * t;
+            if (u < UG) put(g_t, pg[t], keep_g[t], u % (COT / 4), u / (COT / 4));
+        }
+    };
+
+    f32x4 acc[NBI][CB];
+#pragma unroll
+    for (int b = 0; b < NBI; ++b)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(s_lo);
+    for (int64_t base = s_lo; base < s_hi; base += kDwPairs) {
+        __syncthreads();                                  // the previous chunk has been multiplied
+        stash();
+        __syncthreads();
+        if (base + kDwPairs < s_hi) fetch(base + kDwPairs);
+#pragma unroll
+        for (int s = 0; s < kDwPairs / 32; ++s) {         // MFMA step: pairs 32 s + 8 (lane >> 4) .. + 7
+            const char* ar = a_t + li * PB + 64 * s + 16 * lq;
+            const char* gr = g_t + (16 * CB * wave + li) * PB + 64 * s + 16 * lq;
+            bf16x8 bf[CB];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) bf[c] = *reinterpret_cast<const bf16x8*>(gr + 16 * c * PB);
+#pragma unroll
+            for (int b = 0; b < NBI; ++b) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ar + 16 * b * PB);
+#pragma unroll
+                for (int c = 0; c < CB; ++c) acc[b][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[c], acc[b][c], 0, 0, 0);
+            }
+        }
+    }
+    float* dwk = part ? part + ((int64_t)blockIdx.z * k_vol + k) * c_in * c_out : dw + (int64_t)k * c_in * c_out;
+#pragma unroll
+    for (int b = 0; b < NBI; ++b)
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + 16 * b + 4 * lq + r, co = co0 + 16 * (CB * wave + c) + li;
+                if (ci < c_in && co < c_out) {
+                    if (part) dwk[(int64_t)ci * c_out + co] = acc[b][c][r];
+                    else if (acc[b][c][r] != 0.f) atomicAdd(dwk + (int64_t)ci * c_out + co, acc[b][c][r]);
+                }
+            }
+}
+
+template <int NBI, int CB, bool IDENT>
+static int launch_bwd_w_bf16(const float* in_a, int c_in_a, const float* in_b, int c_in_b, const float* g,
+                             const int32_t* pin, const int32_t* pout, const int32_t* off, int k_vol, int64_t m_out,
+                             int64_t n_pairs, int c_out, float* dw, float* workspace, hipStream_t st) {
+    constexpr int CIT = 16 * NBI, COT = 128 * CB;
+    const size_t lds = (size_t)(CIT + COT) * (2 * kDwPairs + 16);
+    auto kern = spconv_bwd_w_bf16_kernel<NBI, CB, IDENT>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int c_in = c_in_a + c_in_b;
+    const int tiles = (int)(ceil_div(c_in, CIT) * ceil_div(c_out, COT));
+    const int64_t slices = dw_slices(c_in, c_out, k_vol, n_pairs, CIT, COT);
+    const int64_t n = (int64_t)k_vol * c_in * c_out;
+    float* part = (workspace != nullptr && slices > 1) ? workspace : nullptr;
+    if (part) LIDIFF_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)slices * n * sizeof(float), st));
+    hipLaunchKernelGGL(kern, dim3((unsigned)k_vol, (unsigned)tiles, (unsigned)slices), dim3(512), lds, st, in_a, c_in_a,
+                       in_b, c_in_b, g, pin, pout, off, m_out, c_out, (int)slices, dw, part, k_vol);
+    if (part) dw_reduce_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(part, n, (int)slices, dw);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace lidiff
 
 using namespace lidiff;
+
+extern "C" int lidiff_spconv_bwd_w_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
+                                        const float* grad_out, const int32_t* pairs_in, const int32_t* pairs_out,
+                                        const int32_t* offset_ptr, int64_t n_pairs, int32_t k_vol, int64_t m_in,
+                                        int64_t m_out, int32_t c_out, float* dw, float* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && grad_out != nullptr && dw != nullptr, "null pointer");
+    LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
+    const bool identity = pairs_in == nullptr && pairs_out == nullptr && offset_ptr == nullptr;
+    LIDIFF_CHECK_ARG(identity ? (k_vol == 1 && m_in == m_out) : (pairs_in && pairs_out && offset_ptr),
+                     "rulebook pointers must be all set, or all null for the identity map (K=1, m_in==m_out)");
+    LIDIFF_CHECK_ARG(c_in_a % 4 == 0 && c_in_b % 4 == 0 && c_out % 4 == 0, "channel counts must be multiples of 4");
+    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+    LIDIFF_CHECK_ARG(al16(in_a) && al16(in_b) && al16(grad_out), "feature pointers must be 16-byte aligned");
+    LIDIFF_CHECK_ARG(m_in * (int64_t)(c_in_a > c_in_b ? c_in_a : c_in_b) < (1ll << 31) && m_out * (int64_t)c_out < (1ll << 31),
+                     "a feature matrix exceeds 2^31 elements (32-bit row offsets)");
+    if (identity) n_pairs = m_out;
+    if (m_out == 0 || n_pairs <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int c_in = c_in_a + c_in_b;
+    const int nbi = c_in > 128 ? 16 : c_in > 64 ? 8 : c_in > 32 ? 4 : 2;      // as lidiff_spconv_bwd_w (same workspace size)
+#define LIDIFF_DW(NBI, CB)                                                                                               \
+    return identity ? launch_bwd_w_bf16<NBI, CB, true>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr,  \
+                                                       k_vol, m_out, n_pairs, c_out, dw, workspace, st)                     \
+                    : launch_bwd_w_bf16<NBI, CB, false>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr, \
+                                                        k_vol, m_out, n_pairs, c_out, dw, workspace, st)
+    if (c_out > 128) {
+        if (nbi == 16) LIDIFF_DW(16, 2);
+        if (nbi == 8) LIDIFF_DW(8, 2);
+        if (nbi == 4) LIDIFF_DW(4, 2);
+        LIDIFF_DW(2, 2);
+    }
+    if (nbi == 16) LIDIFF_DW(16, 1);
+    if (nbi == 8) LIDIFF_DW(8, 1);
+    if (nbi == 4) LIDIFF_DW(4, 1);
+    LIDIFF_DW(2, 1);
+#undef LIDIFF_DW
+}
+
 
 extern "C" int64_t lidiff_spconv_packed_weight_bf16_elems(int32_t k_vol, int32_t c_in, int32_t c_out, int32_t planes) {
     return (int64_t)k_vol * ((c_in + 31) / 32) * 32 * c_out * planes;

@@ -444,10 +444,11 @@ def rulebook_of(nbr: torch.Tensor):
     return rb
 
 
-def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None) -> torch.Tensor:
+def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None, bf16: bool = False) -> torch.Tensor:
     """Weight gradient of spconv_fwd (training path, models.py:180-217): dW[k] = gather(in)[pairs_k]^T @
     grad_out[pairs_k] by the MFMA kernel lidiff_spconv_bwd_w over the map's rulebook; channel counts that are not
-    multiples of 4 (the 3-channel stem) go through row gathers + one library GEMM per offset."""
+    multiples of 4 (the 3-channel stem) go through row gathers + one library GEMM per offset.
+    bf16: operands rounded to bf16, fp32 sums (lidiff_spconv_bwd_w_bf16) -- the bf16 training configuration."""
     require_device(in_a, grad_out, nbr, in_b)
     in_a = in_a.contiguous()
     grad_out = grad_out.contiguous()
@@ -463,7 +464,8 @@ def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None) -> torch.Tensor:
             ws = torch.empty(nws, dtype=torch.float32, device=in_a.device) if nws else None
         alloc = torch.empty if ws is not None else torch.zeros
         dw = alloc((k, c_a + c_b, c_out), dtype=torch.float32, device=in_a.device)
-        call("lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out), ptr(pin), ptr(pout), ptr(off),
+        call("lidiff_spconv_bwd_w_bf16" if bf16 else "lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out),
+             ptr(pin), ptr(pout), ptr(off),
              n_pairs, k, in_a.shape[0], m_out, c_out, ptr(dw), ptr(ws), stream_ptr())
         return dw
     x = in_a if in_b is None else torch.cat([in_a, in_b], dim=1)

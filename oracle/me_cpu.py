@@ -206,7 +206,7 @@ _BF16_OPERANDS = False
 class bf16_operands:
     """``with bf16_operands():`` -- restates the product's mixed-precision TRAINING convolution (BASELINE configs[4],
     include/lidiff_amd.h lidiff_spconv_fwd_bf16) on the CPU: for every convolution whose channel counts are multiples of
-    32, forward = conv(bf16(x), bf16(W)), dX = conv^T(bf16(g), bf16(W)), dW = x^T g unrounded; sums in the tensors' own
+    32, forward = conv(bf16(x), bf16(W)), dX = conv^T(bf16(g), bf16(W)), dW = bf16(x)^T bf16(g); sums in the tensors' own
     dtype.  The reference has no such mode of its own (ME has no bf16 kernels): this is the checker of OUR bf16 path."""
 
     def __enter__(self):
@@ -236,7 +236,7 @@ class _Bf16Conv(torch.autograd.Function):
             xr = _bf16_round(feats.detach()).requires_grad_(True)
             gx, = torch.autograd.grad(_conv_plain(xr, _bf16_round(kernel.detach()), ctx.nbr), xr, _bf16_round(g))
             w = kernel.detach().requires_grad_(True)
-            gw, = torch.autograd.grad(_conv_plain(feats.detach(), w, ctx.nbr), w, g)
+            gw, = torch.autograd.grad(_conv_plain(_bf16_round(feats.detach()), w, ctx.nbr), w, _bf16_round(g))
         return gx, gw, None
 
 

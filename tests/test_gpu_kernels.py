@@ -695,9 +695,10 @@ def test_spconv_from_bf16_pieces_is_fp32_accurate(device, planes, kind, cin, cou
                                                     ("conv", 1, 1, 96, 32), ("conv", 3, 1, 256, 256), ("conv", 3, 1, 32, 48)])
 def test_spconv_bf16_training_backward_vs_oracle_autograd(device, kind, ks, stride, cin, cout):
     """The ME-shim convolution under ops.train_operands("bf16"): forward and dX through lidiff_spconv_fwd_bf16 (dX over the
-    swapped map with the transposed, flipped kernel), dW by the fp32 kernel.  Inputs and the output gradient are chosen
-    bf16-representable, so the float64 oracle under me.bf16_operands() (weights rounded there) is the exact reference of all three.  A layer whose
-    channel counts are not multiples of 32 (32 -> 48 here) keeps the fp32 kernels under the same switch."""
+    swapped map with the transposed, flipped kernel), dW through lidiff_spconv_bwd_w_bf16.  The float64 oracle under
+    me.bf16_operands() rounds the same operands to bf16 -- forward conv(bf16 x, bf16 W), dX conv^T(bf16 g, bf16 W),
+    dW bf16(x)^T bf16(g) -- so it is the exact reference of all three up to fp32 summation order.  A layer whose channel
+    counts are not multiples of 32 (32 -> 48 here) keeps the fp32 kernels under the same switch."""
     import lidiff_amd.MinkowskiEngine as ME
     from lidiff_amd import ops
     coords = random_cloud(1500, 5, 31, batch=2)
@@ -711,7 +712,7 @@ def test_spconv_bf16_training_backward_vs_oracle_autograd(device, kind, ks, stri
         mgr.stride(1, 2)
         ts_in = 2
     m_in = mgr.maps[ts_in].coords.shape[0]
-    xf = _bf16r(torch.randn(m_in, cin, generator=g))
+    xf = torch.randn(m_in, cin, generator=g)
     x = ME.SparseTensor(xf.to(device).requires_grad_(True), tensor_stride=ts_in, coordinate_manager=mgr)
     mod = (ME.MinkowskiConvolutionTranspose if kind == "tconv" else ME.MinkowskiConvolution)(
         cin, cout, kernel_size=ks, stride=stride, dimension=3).to(device)
@@ -722,7 +723,7 @@ def test_spconv_bf16_training_backward_vs_oracle_autograd(device, kind, ks, stri
     try:
         with ops.train_operands("bf16"):
             y = mod(x)
-            r = _bf16r(torch.randn(y.F.shape, generator=g))
+            r = torch.randn(y.F.shape, generator=g)
             (y.F * r.to(device)).sum().backward()
     finally:
         ops.PROFILER = None

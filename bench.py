@@ -120,7 +120,7 @@ def cpu_baseline(scan_np, seed=42, threads=0):
     x = scan + o.sigma_t[t] * rng.standard_normal(scan.shape)
     z = rng.standard_normal(scan.shape)
     if threads:
-        me_cpp.set_threads(threads)
+        me_cpp.set_threads(min(threads, os.cpu_count() or threads))
     cores = me_cpp.threads()
     model = "unknown CPU"
     try:
@@ -253,7 +253,10 @@ def main():
     ap.add_argument("--all-variants", action="store_true",
                     help="time every sparse-conv launch, not only the dominant (BN=128) variant: more events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all the box has)")
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="threads of the CPU baseline (0 = all the box has).  Default 32: on the 128-thread EPYC 9575F of the "
+                         "GPU box the leg takes 23.6 s with 32 threads, 37.8 s with 64, 81.7 s with 128 "
+                         "(profiles/r02_cpu_baseline_threads.txt) -- the fastest configuration is the one reported")
     ap.add_argument("--no-coords-roofline", action="store_true", help="skip the coordinate-pipeline (HBM-bound) roofline leg")
     ap.add_argument("--cached-condition", action="store_true",
                     help="also time the same steps with the step-invariant conditions encoded once (reported beside the metric)")

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for pass in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/$pass -o p -- \
-    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/$pass.log 2>&1
+    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline > $OUT/$pass.log 2>&1
 done
 cd $R
 python - <<PY

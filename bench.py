@@ -313,6 +313,15 @@ def main():
             run_steps(pipe, x_init, xs, tvals, 0, args.steps, cache_condition=True)
             torch.cuda.synchronize()
             elapsed_cached = time.perf_counter() - t0
+        # a second, untimed-for-the-metric pass of the same K steps with EVERY conv launch carrying events: the narrow
+        # variants (the low-density stride-1/2 layers) get their own roofline entry, bound by HBM (SURVEY.md 8d bytes)
+        vprof = None
+        if world == 1 and not args.no_kernel_events and not args.all_variants:
+            vprof = ops.ConvProfiler(None)
+            ops.PROFILER = vprof
+            run_steps(pipe, x_init, xs, tvals, 0, args.steps)
+            torch.cuda.synchronize()
+            ops.PROFILER = None
         # beside the metric, never `value`: the same K steps with the dense 128-column layers computed from two bf16 pieces
         # per operand (3 bf16 MFMAs per block, fp32 accumulation; ops.split_planes, lidiff_spconv_fwd_bf16 planes = 2)
         alt = None
@@ -377,6 +386,21 @@ def main():
                              "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                              "alg_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in summ.items() if v["timed"]},
         }
+    if vprof is not None or (prof is not None and args.all_variants):
+        vs = (vprof or prof).summary()
+        narrow = {k: v for k, v in vs.items() if k in ("bn96", "bn64", "bn32", "bn16") and v["timed"]}
+        if narrow:
+            nb, nms = sum(v["bytes"] for v in narrow.values()), sum(v["ms"] for v in narrow.values())
+            out["roofline_narrow"] = {
+                "kernel": "spconv_fwd_kernel, output-channel tiles below 128 (bn96 / bn64 / bn32: the stride-1/2 layers, "
+                          "centre + tail passes included)", "bound": "hbm", "achieved": nb / (nms * 1e-3) / 1e9,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nb / (nms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                "ms_per_step": nms / args.steps, "launches_per_step": sum(v["launches"] for v in narrow.values()) / args.steps,
+                "note": "algorithmic bytes 4 (M_in C_in + M_out C_out) + 4 K C_in C_out + 8 P per launch / HIP-event time, "
+                        "from a second pass of the same steps with every conv launch timed (not the pass behind `value`)",
+                "variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                 "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                 "alg_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in vs.items() if v["timed"]}}
     if alt is not None:
         a_elapsed, aprof = alt
         out["alt"] = {

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 15
+#define LIDIFF_ABI_VERSION 16
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -87,6 +87,13 @@ int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out,
 int lidiff_kernel_map(const int32_t* out_coords, int64_t m_out,
                       const uint64_t* hkeys_in, const int32_t* hvals_in, int64_t cap_in,
                       int32_t ks, int32_t step, int32_t* nbr, void* stream);
+
+/* lidiff_kernel_map for kernel_size 3 of a coordinate map onto ITSELF (out_coords = the rows of the table's map, the
+ * stride-1 convolutions of minkunet.py:53-66,94,97): the same table bit for bit, from half the lookups -- only the 13
+ * offsets below the centre are probed, every hit also fills its mirror entry nbr[26 - k][hit] = row, the centre is the
+ * identity.  Fills nbr [27, m] itself (no pre-initialisation needed). */
+int lidiff_kernel_map_self(const int32_t* coords, int64_t m, const uint64_t* hkeys, const int32_t* hvals, int64_t cap,
+                           int32_t step, int32_t* nbr, void* stream);
 
 /* Kernel map of MinkowskiConvolutionTranspose(ks=2,stride=2) -- minkunet.py:32-46 (ME:
  * swapped fine->coarse map): nbr_up[k*m_fine + j] = parent[j] if k == kernel index of

@@ -87,7 +87,8 @@ class CoordinateManager:
                                        "onto a map created by the matching strided convolution")
                 nbr = ops.kernel_map_up(self.maps[ts_out].coords, self.parents[ts_in], ts_out)
             else:
-                nbr = ops.kernel_map(self.maps[ts_out].coords, self.maps[ts_in].table, ks, ts_in)
+                nbr = ops.kernel_map(self.maps[ts_out].coords, self.maps[ts_in].table, ks, ts_in,
+                                     self_map=(ts_in == ts_out and ks == 3))
             self.kmaps[key] = nbr
         return nbr
 

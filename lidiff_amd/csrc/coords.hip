@@ -280,6 +280,65 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 3))) 
     }
 }
 
+// kernel_size-3 map of a coordinate map ONTO ITSELF: row o is the neighbour of row i under offset k exactly when i is the
+// neighbour of o under the mirrored offset 26 - k, and the centre offset is the identity.  So only the 13 offsets below the
+// centre are looked up; every hit also writes its mirror entry (each table slot is written by at most one row: no race, the
+// table equals kernel_map_kernel<3>'s bit for bit).  nbr must be pre-filled with -1.  Half the scattered requests of the
+// plain kernel on low-density maps -- and the number of requests is what bounds it.
+__global__ __launch_bounds__(kBlock) void kernel_map_self_kernel(const int32_t* __restrict__ coords, int64_t m,
+                                                                const uint64_t* __restrict__ hkeys,
+                                                                const int32_t* __restrict__ hvals, uint32_t mask, int step,
+                                                                int32_t* __restrict__ nbr) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= m) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[o];
+    auto key_of = [&](int k, bool& ok) {
+        const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+        return pack_key(c.x, c.y + dx * step, c.z + dy * step, c.w + dz * step, ok);
+    };
+    uint64_t got[13];
+    uint32_t slot[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        bool ok;
+        slot[k] = hash_key(key_of(k, ok)) & mask;
+        got[k] = hkeys[slot[k]];
+    }
+    uint32_t hit = 0, walk = 0;
+    int val[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        bool ok;
+        const uint64_t key = key_of(k, ok);
+        const bool h = ok && got[k] == key;
+        hit |= h ? 1u << k : 0u;
+        walk |= (ok && !h && got[k] != kEmptyKey) ? 1u << k : 0u;
+        val[k] = hvals[slot[k] & (0u - (uint32_t)h)];
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) asm volatile("" ::"v"(val[k]));
+    nbr[(int64_t)13 * m + o] = (int)o;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        int res = (hit >> k) & 1u ? val[k] : -1;
+        if ((walk >> k) & 1u) {
+            bool ok;
+            const uint64_t key = key_of(k, ok);
+            uint32_t sl = (slot[k] + 1) & mask;
+            for (uint32_t probe = 1; probe <= mask; ++probe) {
+                const uint64_t q = hkeys[sl];
+                if (q == key) { res = hvals[sl]; break; }
+                if (q == kEmptyKey) break;
+                sl = (sl + 1) & mask;
+            }
+        }
+        if (res >= 0) {
+            nbr[(int64_t)k * m + o] = res;
+            nbr[(int64_t)(26 - k) * m + res] = (int)o;
+        }
+    }
+}
+
 __global__ void kernel_map_up_kernel(const int32_t* __restrict__ fine, const int32_t* __restrict__ parent,
                                      int64_t m, int ts, int32_t* __restrict__ nbr_up) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1023,6 +1082,19 @@ int lidiff_kernel_map(const int32_t* out_coords, int64_t m_out, const uint64_t* 
     if (ks == 3) kernel_map_kernel<3><<<blocks, kBlock, 0, st>>>(out_coords, m_out, hkeys_in, hvals_in, mask, step, nbr);
     else if (ks == 2) kernel_map_kernel<2><<<blocks, kBlock, 0, st>>>(out_coords, m_out, hkeys_in, hvals_in, mask, step, nbr);
     else kernel_map_kernel<1><<<blocks, kBlock, 0, st>>>(out_coords, m_out, hkeys_in, hvals_in, mask, step, nbr);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_kernel_map_self(const int32_t* coords, int64_t m, const uint64_t* hkeys, const int32_t* hvals, int64_t cap,
+                           int32_t step, int32_t* nbr, void* stream) {
+    LIDIFF_CHECK_ARG(cap > 0 && (cap & (cap - 1)) == 0, "cap must be a power of two");
+    LIDIFF_CHECK_ARG(step >= 1, "step must be >= 1");
+    if (m == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    LIDIFF_CHECK_HIP(hipMemsetAsync(nbr, 0xff, (size_t)27 * m * sizeof(int32_t), st));
+    kernel_map_self_kernel<<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>(coords, m, hkeys, hvals, (uint32_t)(cap - 1),
+                                                                             step, nbr);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

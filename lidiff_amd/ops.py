@@ -95,12 +95,17 @@ def vox_mean_bwd(grad_out, inverse, counts):
     return g
 
 
-def kernel_map(out_coords: torch.Tensor, in_table: HashTable, ks: int, step: int) -> torch.Tensor:
-    """Neighbour table nbr[K, M_out] (minkunet.py:53-66 ks=3; 13-29 ks=2/stride 2)."""
+def kernel_map(out_coords: torch.Tensor, in_table: HashTable, ks: int, step: int, self_map: bool = False) -> torch.Tensor:
+    """Neighbour table nbr[K, M_out] (minkunet.py:53-66 ks=3; 13-29 ks=2/stride 2).  self_map: out_coords are the rows of
+    in_table's own map and ks == 3 -- the mirrored offsets come for free (lidiff_kernel_map_self, same table)."""
     require_device(out_coords)
     out_coords = out_coords.contiguous()
     m = out_coords.shape[0]
     nbr = torch.empty((ks ** 3, m), dtype=torch.int32, device=out_coords.device)
+    if self_map and ks == 3:
+        call("lidiff_kernel_map_self", ptr(out_coords), m, ptr(in_table.keys), ptr(in_table.vals), in_table.cap, int(step),
+             ptr(nbr), stream_ptr())
+        return nbr
     call("lidiff_kernel_map", ptr(out_coords), m, ptr(in_table.keys), ptr(in_table.vals), in_table.cap,
          int(ks), int(step), ptr(nbr), stream_ptr())
     return nbr

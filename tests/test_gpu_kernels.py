@@ -37,6 +37,7 @@ def check_maps(coords_np, device):
     assert np.array_equal(first.cpu().numpy(), o_first)
     nbr3 = ops.kernel_map(uniq, table, 3, 1)
     assert np.array_equal(nbr3.cpu().numpy(), me.kernel_map(o_uniq, o_uniq, 3, 1))
+    assert torch.equal(ops.kernel_map(uniq, table, 3, 1, self_map=True), nbr3)      # 13 lookups + mirror entries: same table
     cur, cur_t, o_cur, ts = uniq, table, o_uniq, 1
     for _ in range(4):
         coarse, parent, ctable = ops.map_stride(cur, ts * 2, st)
@@ -50,6 +51,7 @@ def check_maps(coords_np, device):
         assert np.array_equal(up.cpu().numpy(), me.transpose_kernel_map(o_down, o_cur.shape[0]))
         k3 = ops.kernel_map(coarse, ctable, 3, ts * 2)
         assert np.array_equal(k3.cpu().numpy(), me.kernel_map(o_coarse, o_coarse, 3, ts * 2))
+        assert torch.equal(ops.kernel_map(coarse, ctable, 3, ts * 2, self_map=True), k3)
         cur, cur_t, o_cur, ts = coarse, ctable, o_coarse, ts * 2
     assert int(st.item()) == 0
     return nbr3

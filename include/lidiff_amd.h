@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 16
+#define LIDIFF_ABI_VERSION 17
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -94,6 +94,12 @@ int lidiff_kernel_map(const int32_t* out_coords, int64_t m_out,
  * identity.  Fills nbr [27, m] itself (no pre-initialisation needed). */
 int lidiff_kernel_map_self(const int32_t* coords, int64_t m, const uint64_t* hkeys, const int32_t* hvals, int64_t cap,
                            int32_t step, int32_t* nbr, void* stream);
+
+/* The kernel_size-2 / stride-2 map of a strided convolution (fine map -> its coarse map, minkunet.py:13-29) from the
+ * parent array lidiff_map_stride returned: nbr_down [8, m_coarse] -- the table lidiff_kernel_map(coarse coords, fine
+ * table, ks 2, step ts_fine) builds, bit for bit, from one pass over the fine rows instead of 8 lookups per coarse row. */
+int lidiff_kernel_map_down(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine, int32_t ts_fine,
+                           int64_t m_coarse, int32_t* nbr_down, void* stream);
 
 /* Kernel map of MinkowskiConvolutionTranspose(ks=2,stride=2) -- minkunet.py:32-46 (ME:
  * swapped fine->coarse map): nbr_up[k*m_fine + j] = parent[j] if k == kernel index of

@@ -86,6 +86,10 @@ class CoordinateManager:
                     raise RuntimeError("transposed convolution supported for kernel_size=2, stride=2 "
                                        "onto a map created by the matching strided convolution")
                 nbr = ops.kernel_map_up(self.maps[ts_out].coords, self.parents[ts_in], ts_out)
+            elif ks == 2 and ts_out == 2 * ts_in and ts_out in self.parents:
+                # the strided convolution's map straight from the parent array of the stride map (no lookups)
+                nbr = ops.kernel_map_down(self.maps[ts_in].coords, self.parents[ts_out], ts_in,
+                                          self.maps[ts_out].coords.shape[0])
             else:
                 nbr = ops.kernel_map(self.maps[ts_out].coords, self.maps[ts_in].table, ks, ts_in,
                                      self_map=(ts_in == ts_out and ks == 3))

@@ -28,6 +28,7 @@ SIGNATURES = {
     "lidiff_map_stride": (_i32, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "lidiff_kernel_map": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
     "lidiff_kernel_map_self": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p, _p]),
+    "lidiff_kernel_map_down": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p]),
     "lidiff_kernel_map_up": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_rulebook_compact": (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _p]),
     "lidiff_rulebook_workspace_bytes": (_i64, [_i32, _i64]),
@@ -58,7 +59,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 
 

@@ -111,6 +111,18 @@ def kernel_map(out_coords: torch.Tensor, in_table: HashTable, ks: int, step: int
     return nbr
 
 
+def kernel_map_down(fine_coords: torch.Tensor, parent: torch.Tensor, ts_fine: int, m_coarse: int) -> torch.Tensor:
+    """The ks=2 / stride-2 table nbr[8, M_coarse] of a strided convolution (minkunet.py:13-29) from the parent array of
+    map_stride -- the table kernel_map(coarse, fine table, 2, ts_fine) builds, without a lookup."""
+    require_device(fine_coords, parent)
+    fine_coords, parent = fine_coords.contiguous(), parent.contiguous()
+    assert parent.dtype == torch.int32 and parent.shape[0] == fine_coords.shape[0]
+    nbr = torch.empty((8, m_coarse), dtype=torch.int32, device=fine_coords.device)
+    call("lidiff_kernel_map_down", ptr(fine_coords), ptr(parent), fine_coords.shape[0], int(ts_fine), int(m_coarse),
+         ptr(nbr), stream_ptr())
+    return nbr
+
+
 def kernel_map_up(fine_coords: torch.Tensor, parent: torch.Tensor, ts_fine: int) -> torch.Tensor:
     """Neighbour table of the transposed ks=2/stride-2 conv (minkunet.py:32-46)."""
     require_device(fine_coords, parent)

@@ -47,6 +47,7 @@ def check_maps(coords_np, device):
         down = ops.kernel_map(coarse, cur_t, 2, ts)
         o_down = me.kernel_map(o_cur, o_coarse, 2, ts)
         assert np.array_equal(down.cpu().numpy(), o_down)
+        assert torch.equal(ops.kernel_map_down(cur, parent, ts, coarse.shape[0]), down)   # from the parent array: same table
         up = ops.kernel_map_up(cur, parent, ts)
         assert np.array_equal(up.cpu().numpy(), me.transpose_kernel_map(o_down, o_cur.shape[0]))
         k3 = ops.kernel_map(coarse, ctable, 3, ts * 2)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-2 closing session C (final build): full GPU suite, smoke, default bench, rocprofv3 kernel stats of the bench command.
+# Closing GPU session of a round: full GPU suite, smoke, default bench, rocprofv3 kernel stats of the bench command.
 set -u
 cd "$(dirname "$0")/.."
-R=$(pwd); OUT=$R/gpurun_out/r2fc; mkdir -p $OUT
+R=$(pwd); OUT=$R/gpurun_out/closing; mkdir -p $OUT
 export PYTHONUNBUFFERED=1
 timeout 1800 python -m pytest tests -q -m gpu --durations=8 -rs 2>&1 | tail -30 > $OUT/pytest_gpu.txt; tail -4 $OUT/pytest_gpu.txt
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $OUT/smoke.txt

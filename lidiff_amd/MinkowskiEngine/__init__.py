@@ -141,6 +141,43 @@ class CoordinateManager:
         coarse = m(2 * ts_in)                         # measured on the 180k-point scan: pays for r >= ~0.85
         return coarse > 0 and coarse >= 0.85 * m(ts_in)   # (<= ~2 neighbours per voxel), not at r = 0.69 (4.3)
 
+    def prebuild(self, max_stride: int = 16, tail_maps: bool = True):
+        """Every map the networks will ask for, built now (MinkGlobalEnc / MinkUNetDiff / MinkUNet: four stride-2 levels, a
+        kernel_size-3 map per level, the kernel_size-2 maps down and back up, the tail maps of the low-density levels).
+        The builders read map sizes back to the host; doing all of it in one place lets DiffCompletion run it on a side
+        stream, under the convolutions of another tensor, instead of level by level in the middle of a network."""
+        ts = 1
+        while True:
+            self.kernel_map(ts, ts, 3)
+            if ts == max_stride:
+                break
+            nxt = self.stride(ts, 2)
+            self.kernel_map(ts, nxt, 2)
+            self.kernel_map(nxt, ts, 2, True)
+            ts = nxt
+        for ts in list(self.maps):                      # the sparse-map hint of a level needs the next level's size
+            if tail_maps and self.maps[ts].coords.shape[0] >= 1024 and self.is_sparse_map(ts, ts, 3):
+                self.tail_map(ts)
+
+    def tensors(self):
+        """Every device tensor this manager holds (for record_stream when it was built on another stream)."""
+        out = [self.status]
+        for m in self.maps.values():
+            out += [m.coords, m.table.keys, m.table.vals]
+        out += list(self.parents.values())
+        out += [t for t in self.kmaps.values() if isinstance(t, torch.Tensor)]
+        for v in self.aux.values():
+            for t in (v if isinstance(v, (tuple, list)) else [v]):
+                if isinstance(t, torch.Tensor):
+                    out.append(t)
+                elif isinstance(t, ops.TailMap):
+                    out += [q for q in (t.ptr, t.nbr, t.idx) if q is not None]
+        return out
+
+    def record_stream(self, stream):
+        for t in self.tensors():
+            t.record_stream(stream)
+
     def check(self):
         """Raise if a kernel flagged a coordinate outside the hash-key range (host sync)."""
         s = int(self.status.item())
@@ -233,7 +270,9 @@ class TensorField:
         self.quantization_mode = quantization_mode
         self.coordinate_manager = coordinate_manager or CoordinateManager(features.device)
         self.inverse_mapping = None
-        self._sparse = None
+        self._sparse = None          # the voxelised tensor, once built without autograd (DiffCompletion.prepare)
+        self.prepared = None         # event: maps and voxel features ready (built on a side stream)
+        self.ready = None            # event: features / coordinates written (recorded by whoever wants to hand the field over)
 
     @property
     def F(self):
@@ -252,9 +291,14 @@ class TensorField:
         if self.inverse_mapping is None:
             ci = self._C if self._C.dtype == torch.int32 else ops.coords_floor(self._C)
             self.inverse_mapping, _ = mgr.insert(ci)
+        if self._sparse is not None:
+            return self._sparse
         m = mgr.maps[1].coords.shape[0]
-        return SparseTensor(_VoxelMean.apply(self._F.float(), self.inverse_mapping, m),
-                            tensor_stride=1, coordinate_manager=mgr)
+        sp = SparseTensor(_VoxelMean.apply(self._F.float(), self.inverse_mapping, m),
+                          tensor_stride=1, coordinate_manager=mgr)
+        if not (torch.is_grad_enabled() and self._F.requires_grad):
+            self._sparse = sp        # same features for every caller of this field (no graph attached)
+        return sp
 
 
 class SparseTensor:
@@ -319,6 +363,7 @@ class SparseTensor:
         out.quantization_mode = field.quantization_mode
         out.coordinate_manager = field.coordinate_manager
         out.inverse_mapping = field.inverse_mapping
+        out._sparse = out.prepared = out.ready = None
         return out
 
 

@@ -99,7 +99,7 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
         nbr, order = mgr.kernel_map_ordered(x.tensor_stride, ts_out, conv.kernel_size, conv.transposed)
     scale, shift = _bn_affine(bn)
     hint = conv.sparse_hint(x, ts_out)
-    if _CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None:
+    if _CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and m_out >= 1024:
         f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
                                    residual=residual, relu=relu, replicas=x.replicas)
     else:

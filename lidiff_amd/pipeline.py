@@ -76,14 +76,85 @@ class DiffCompletion(nn.Module):
     def points_to_tensor(self, points):
         x_feats = ME.utils.batched_coordinates(list(points[:]), dtype=torch.float32, device=self.device)
         x_coord = torch.round(x_feats / self.hparams["data"]["resolution"])
-        return ME.TensorField(features=x_feats[:, 1:], coordinates=x_coord,
-                              quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
-                              minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
+        field = ME.TensorField(features=x_feats[:, 1:], coordinates=x_coord,
+                               quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                               minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
+        if self.overlap_maps and field.F.device.type == "cuda":
+            field.ready = torch.cuda.Event()         # its points exist once the current stream gets here
+            field.ready.record(torch.cuda.current_stream(self.device))
+        return field
+
+    # -- overlap of the coordinate pipeline with the convolutions ---------------------------------------------------
+    # Voxelising a field and building its maps is a chain of small, latency-bound kernels with a host read of every map
+    # size; on the stream of the convolutions each read drains the queue.  With overlap_maps the chain of a field runs
+    # on a side stream while the main stream is busy with another tensor's convolutions: the conditions of step i + 1
+    # under the UNet of step i, the maps of x_t under the condition encoders.  Every step still builds everything anew.
+    overlap_maps = os.environ.get("LIDIFF_OVERLAP_MAPS", "1") not in ("0", "lazy")
+    eager_maps = os.environ.get("LIDIFF_OVERLAP_MAPS", "1") != "lazy"      # False: maps are built when a layer first asks
+
+    def _streams(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return torch.cuda.current_stream(self.device), self._side
+
+    def prepare(self, field, tail_maps=True):
+        """Voxelise `field` and build ALL its maps now -- on the side stream with overlap_maps, else on the current one
+        (no-op if already done).  Building eagerly also gives every level its sparse-map hint: asked lazily, a level's hint
+        needs the next coarser map, which the encoder half of a network has not built yet."""
+        if (not self.eager_maps or field.prepared is not None or field.F.device.type != "cuda"
+                or getattr(field, "_keep", None) is not None):
+            return field
+        if not self.overlap_maps:                    # same work, same maps (and the same kernel choices), on this stream
+            with torch.no_grad():
+                field._keep = field.sparse()
+                field.coordinate_manager.prebuild(tail_maps=tail_maps)
+            return field
+        main, side = self._streams()
+        if field.ready is None:                      # produced on the main stream just now
+            field.ready = torch.cuda.Event()
+            field.ready.record(main)
+        side.wait_event(field.ready)
+        with torch.cuda.stream(side), torch.no_grad():
+            sp = field.sparse()
+            field.coordinate_manager.prebuild(tail_maps=tail_maps)
+            field.prepared = torch.cuda.Event()
+            field.prepared.record(side)
+        field._keep = sp
+        return field
+
+    def _adopt(self, field):
+        """Make a prepared field's tensors safe to use on the current stream."""
+        if field.prepared is not None:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(field.prepared)
+            field.coordinate_manager.record_stream(main)
+            for t in (field._keep.F, field.inverse_mapping):
+                t.record_stream(main)
+            field.prepared = None
+            field.ready = torch.cuda.Event()         # consumed: a later prepare() of the same field is a no-op anyway
+        return field
 
     # pipeline:86-90
     def reset_partial_pcd(self, x_part, x_uncond):
-        x_part = self.points_to_tensor(x_part.F.reshape(1, -1, 3).detach())
-        x_uncond = self.points_to_tensor(torch.zeros_like(x_part.F.reshape(1, -1, 3)))
+        if not self.overlap_maps or x_part.F.device.type != "cuda":
+            x_part = self.points_to_tensor(x_part.F.reshape(1, -1, 3).detach())
+            x_uncond = self.points_to_tensor(torch.zeros_like(x_part.F.reshape(1, -1, 3)))
+            return self.prepare(x_part), self.prepare(x_uncond, tail_maps=False)
+        # The next step's conditions are rebuilt from the same points (pipeline:86-90), which were there before this step's
+        # network was queued: the whole rebuild -- batched coordinates, rounding, voxelisation, maps -- runs on the side
+        # stream, ordered after the START of this step (not after its UNet), i.e. under the UNet.
+        main, side = self._streams()
+        start = getattr(self, "_step_start", None)
+        if start is None:
+            start = torch.cuda.Event()
+            start.record(main)
+        side.wait_event(start)
+        with torch.cuda.stream(side):
+            pts = x_part.F.reshape(1, -1, 3).detach()
+            x_part = self.points_to_tensor(pts)
+            x_uncond = self.points_to_tensor(torch.zeros_like(pts))
+            self.prepare(x_part)
+            self.prepare(x_uncond, tail_maps=False)       # one voxel: nothing to gain from tail maps
         return x_part, x_uncond
 
     # pipeline:92-105
@@ -134,19 +205,26 @@ class DiffCompletion(nn.Module):
     # pipeline:148-153
     def encode_conditions(self, x_cond, x_uncond):
         with torch.no_grad():
-            return self.partial_enc(x_cond), self.partial_enc(x_uncond)
+            self.prepare(x_cond)                     # no-ops for fields reset_partial_pcd has prepared already
+            self.prepare(x_uncond, tail_maps=False)
+            return self.partial_enc(self._adopt(x_cond)), self.partial_enc(self._adopt(x_uncond))
 
     def classfree_forward(self, x_t, x_cond, x_uncond, t, parts=None):
+        if self.overlap_maps and x_t.F.device.type == "cuda":
+            self._step_start = torch.cuda.Event()
+            self._step_start.record(torch.cuda.current_stream(self.device))
         with torch.no_grad():
-            x_t_sparse = x_t.sparse()
             if self.pair_cfg:
                 # same arithmetic as the two forwards below, but the conditional / unconditional pair shares one
                 # pass over x_t's maps: every sparse conv is ONE launch with two stacked feature matrices
                 if parts is None:
-                    parts = self.encode_conditions(x_cond, x_uncond)
+                    parts = self.encode_conditions(x_cond, x_uncond)      # queued on the main stream ...
+                self.prepare(x_t)                                         # ... x_t's maps meanwhile, on the side stream
+                x_t_sparse = self._adopt(x_t).sparse()
                 e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t)
                 e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
                 return e_uncond + self.w_uncond * (e_cond - e_uncond)
+        x_t_sparse = x_t.sparse()
         e_cond = self.forward(x_t, x_t_sparse, x_cond, t)
         e_uncond = self.forward(x_t, x_t_sparse, x_uncond, t)
         return e_uncond + self.w_uncond * (e_cond - e_uncond)

@@ -97,7 +97,7 @@ class DiffCompletion(nn.Module):
             self._side = torch.cuda.Stream(device=self.device)
         return torch.cuda.current_stream(self.device), self._side
 
-    def prepare(self, field, tail_maps=True):
+    def prepare(self, field, tail_maps=True, also=None):
         """Voxelise `field` and build ALL its maps now -- on the side stream with overlap_maps, else on the current one
         (no-op if already done).  Building eagerly also gives every level its sparse-map hint: asked lazily, a level's hint
         needs the next coarser map, which the encoder half of a network has not built yet."""
@@ -108,6 +108,8 @@ class DiffCompletion(nn.Module):
             with torch.no_grad():
                 field._keep = field.sparse()
                 field.coordinate_manager.prebuild(tail_maps=tail_maps)
+                if also is not None:
+                    also(field)
             return field
         main, side = self._streams()
         if field.ready is None:                      # produced on the main stream just now
@@ -117,10 +119,20 @@ class DiffCompletion(nn.Module):
         with torch.cuda.stream(side), torch.no_grad():
             sp = field.sparse()
             field.coordinate_manager.prebuild(tail_maps=tail_maps)
+            if also is not None:
+                also(field)
             field.prepared = torch.cuda.Event()
             field.prepared.record(side)
         field._keep = sp
         return field
+
+    def _match_levels(self, field, parts):
+        mgr = field.coordinate_manager
+        empty = torch.empty((0, 0), device=self.device)
+        for part in parts:
+            if part.C.shape[0] > 1:                  # a one-voxel part (the unconditional branch) needs no match
+                for ts in sorted(mgr.maps):
+                    self.model.match_index(ME.SparseTensor(empty, tensor_stride=ts, coordinate_manager=mgr), part)
 
     def _adopt(self, field):
         """Make a prepared field's tensors safe to use on the current stream."""
@@ -219,7 +231,9 @@ class DiffCompletion(nn.Module):
                 # pass over x_t's maps: every sparse conv is ONE launch with two stacked feature matrices
                 if parts is None:
                     parts = self.encode_conditions(x_cond, x_uncond)      # queued on the main stream ...
-                self.prepare(x_t)                                         # ... x_t's maps meanwhile, on the side stream
+                # ... x_t's maps meanwhile, on the side stream -- and the part -> full matches of every level, which need
+                # only coordinates (the condition's coarsest map and x_t's maps), not the encoders' features
+                self.prepare(x_t, also=lambda f: self._match_levels(f, parts))
                 x_t_sparse = self._adopt(x_t).sparse()
                 e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t)
                 e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)

@@ -55,7 +55,7 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int k_vol,
 // was measured and takes the SAME time as BM = 128 on every layer (profiles/r02_bf16_kernel_probe.txt): the kernel is bound
 // by per-CU throughput, not by the phases of one workgroup; only BM = 128 is instantiated.)
 template <int BM, int WC, int WR, int KS, int P>
-__global__ __launch_bounds__(64 * WC * WR) void spconv_fwd_bf16_kernel(const ConvParams p_launch) {
+__global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf16_kernel(const ConvParams p_launch) {
     constexpr int BN = 32 * WC, NW = WC * WR, NT = 64 * NW, RB = BM / 16 / WR;
     constexpr int AF = BM * KS;                  // floats per A image
     constexpr int NCHK = KS / 4, RPI = 64 / NCHK, NINST = BM / RPI, T = (NINST + NW - 1) / NW;
@@ -345,9 +345,13 @@ static int launch_bf16(const ConvParams& p, hipStream_t st) {
 
 template <int P>
 static int dispatch_bf16(const ConvParams& p, bool ks64, hipStream_t st) {
+    static const int tile_rows = [] { const char* e = getenv("LIDIFF_BF16_TILE"); return e ? atoi(e) : 128; }();
+    static const int tile_ks = [] { const char* e = getenv("LIDIFF_BF16_KS"); return e ? atoi(e) : 64; }();
     // three planes: 32-channel stages only (the W registers of a 64-channel stage would not fit beside the accumulators)
 #define LIDIFF_BF16(BM, WC, WR) \
     return ks64 && P < 3 ? launch_bf16<BM, WC, WR, (P < 3 ? 64 : 32), P>(p, st) : launch_bf16<BM, WC, WR, 32, P>(p, st)
+    if (P == 1 && tile_rows == 64 && p.c_out % 128 == 0)
+        return ks64 && tile_ks == 64 ? launch_bf16<64, 4, 2, 64, 1>(p, st) : launch_bf16<64, 4, 2, 32, 1>(p, st);
     if (p.c_out % 128 == 0) LIDIFF_BF16(128, 4, 2);
     if (p.c_out % 96 == 0) LIDIFF_BF16(128, 3, 2);
     if (p.c_out % 64 == 0) LIDIFF_BF16(128, 2, 4);

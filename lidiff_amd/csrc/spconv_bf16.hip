@@ -623,7 +623,12 @@ extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const f
     // measurement aid (tools/conv_probe.py --kernel bf16): LIDIFF_BF16_PROBE bits switch parts of the kernel off -- 1 no
     // gather traffic (zero-filled rows), 2 one hot W slab, 4 no fragment reads / MFMAs, 8 no flush, 16 no gather requests,
     // 32 no stage barrier.  Results are wrong with any bit set.
-    static const int probe = [] { const char* e = getenv("LIDIFF_BF16_PROBE"); return e ? atoi(e) : 0; }();
+    static const int probe = [] {
+        const char* e = getenv("LIDIFF_BF16_PROBE");
+        const int v = e ? atoi(e) : 0;
+        if (v) fprintf(stderr, "lidiff_amd: LIDIFF_BF16_PROBE=%d -- parts of lidiff_spconv_fwd_bf16 are switched OFF, its results are WRONG (measurement only)\n", v);
+        return v;
+    }();
     p.probe = probe;
     hipStream_t st = (hipStream_t)stream;
     const bool ks64 = c_in_a % 64 == 0 && c_in_b % 64 == 0;

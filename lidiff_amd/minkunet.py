@@ -23,6 +23,9 @@ through the ME-API shim.
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import math
 
 import numpy as np
@@ -198,6 +201,10 @@ def _run_up(up, x, skip):
     if _fusable(up):
         return up[1][1](up[1][0](y, extra=skip.F))
     return up[1](ME.cat(y, skip))
+
+
+# training path: the conditioning MLPs' row-wise Linears in front of the gather (see MinkUNetDiff._condition)
+_COMMUTE_TRAIN = os.environ.get("LIDIFF_COMMUTE_TRAIN", "1") != "0"
 
 
 def _run_mlp(mlp, x):
@@ -414,6 +421,20 @@ class MinkUNetDiff(_Base):
                 self._condition_hidden(name, x, q, temp_emb, out=hidden[r * m:(r + 1) * m])
             torch.mul(x.F, lin2(hidden), out=out)
             return x._like(out)
+        if _COMMUTE_TRAIN and torch.is_grad_enabled():
+            # Training path (models.py:180-217), same arithmetic with the row-wise Linears moved in front of the gather they
+            # commute with: latent(part.F[idx]) = latent(part.F)[idx], and lin1(cat(p, t)) = p W_p^T + (t W_t^T + b).  Of
+            # the four Linears per level that the reference order runs over the M_l rows of x (360 000 at B = 2) only the last
+            # one still does; the others see the few thousand part rows / the B time rows.  Autograd: the gather scatters
+            # its gradient back onto the part rows, the per-batch broadcast sums its segments.
+            lin2 = getattr(self, f"latemp_{name}")[2]
+            amp = (torch.autocast("cuda", dtype=torch.bfloat16) if ops.TRAIN_OPERANDS == "bf16" and x.F.is_cuda
+                   else contextlib.nullcontext())
+            with amp:
+                h_p, h_t = self._condition_terms(name, part.F, temp_emb)
+            hidden = TF.leaky_relu(ME._GatherRows.apply(h_p.float(), self.match_index(x, part))
+                                   + self._per_batch_rows(h_t.float(), x), 0.1)
+            return x * _run_mlp(lin2, hidden)
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))
         t_first = name == "up1"

@@ -226,6 +226,8 @@ class _SparseConv(torch.autograd.Function):
         ctx.flip = flip
         w3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
         ctx.bf16 = ops.TRAIN_OPERANDS == "bf16" and ops.bf16_conv_applies(w3.shape[1], 0, w3.shape[2], sparse_map)
+        # the weight-gradient kernel does not care about the map's density: bf16 operands on every eligible layer
+        ctx.bf16_dw = ops.TRAIN_OPERANDS == "bf16" and w3.shape[1] % 32 == 0 and w3.shape[2] % 32 == 0
         if ctx.bf16:
             return ops.spconv_fwd_bf16(x, kernel, nbr, m_out)
         return ops.spconv_fwd(x, kernel, nbr, m_out)
@@ -242,7 +244,7 @@ class _SparseConv(torch.autograd.Function):
             wt = (w3.flip(0) if ctx.flip else w3).transpose(1, 2).contiguous()
             gx = ops.spconv_fwd(g, wt, nbr_swapped, x.shape[0])
         if ctx.needs_input_grad[1]:
-            gw = ops.spconv_bwd_w(x, g, nbr, w3.shape[0], bf16=ctx.bf16).reshape(kernel.shape)
+            gw = ops.spconv_bwd_w(x, g, nbr, w3.shape[0], bf16=ctx.bf16_dw).reshape(kernel.shape)
         return gx, gw, None, None, None, None, None
 
 

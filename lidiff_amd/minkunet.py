@@ -26,7 +26,6 @@ from __future__ import annotations
 import contextlib
 import os
 
-import math
 
 import numpy as np
 import torch

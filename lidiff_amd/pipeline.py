@@ -14,7 +14,6 @@ fresh scheduler state per scan (App. D.4).
 from __future__ import annotations
 
 import os
-import struct
 
 import numpy as np
 import torch

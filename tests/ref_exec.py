@@ -174,6 +174,85 @@ def reference_pipeline(backend: str, device="cpu"):
                  device), minknet
 
 
+def reference_models(backend: str, device="cpu"):
+    """The reference's models/models.py as a module object (class DiffusionPoints: the Lightning training module,
+    models.py:18-217), importing the reference's own lidiff.models.minkunet and lidiff.utils.{scheduling, collations,
+    metrics} -- all read from /root/reference -- over the stand-ins."""
+    minknet, mods = reference_minkunet(backend, device)
+
+    class _Lightning(_LightningModule):
+        def log(self, *a, **k):
+            pass
+
+    pl_top = types.ModuleType("pytorch_lightning")
+    pl_core = types.ModuleType("pytorch_lightning.core")
+    pl_light = types.ModuleType("pytorch_lightning.core.lightning")
+    pl_light.LightningModule = _Lightning
+    pl_top.core, pl_core.lightning = pl_core, pl_light
+    pl_top.LightningModule = _Lightning
+    pl_top.LightningDataModule = type("LightningDataModule", (), {})
+    o3d = _open3d_stub()
+    o3d.geometry.Geometry = type("Geometry", (), {})
+    mods = dict(mods)
+    mods.update({"open3d": o3d, "pytorch_lightning": pl_top, "pytorch_lightning.core": pl_core,
+                 "pytorch_lightning.core.lightning": pl_light})
+    utils = {}
+    for name in ("scheduling", "collations", "metrics"):
+        utils[name] = _load(os.path.join(REF_PKG, "utils", name + ".py"), f"_ref_utils_{name}_{backend}", mods, device)
+    lidiff_pkg, lidiff_models, lidiff_utils = (types.ModuleType("lidiff"), types.ModuleType("lidiff.models"),
+                                               types.ModuleType("lidiff.utils"))
+    lidiff_pkg.models, lidiff_pkg.utils, lidiff_models.minkunet = lidiff_models, lidiff_utils, minknet
+    mods.update({"lidiff": lidiff_pkg, "lidiff.models": lidiff_models, "lidiff.models.minkunet": minknet,
+                 "lidiff.utils": lidiff_utils})
+    for name, mod in utils.items():
+        setattr(lidiff_utils, name, mod)
+        mods["lidiff.utils." + name] = mod
+    return _load(os.path.join(REF_PKG, "models", "models.py"), f"_ref_models_{backend}", mods, device), minknet
+
+
+def _chamfer_distance_stub(x, y):
+    """pytorch3d.loss.chamfer_distance with its defaults (pytorch3d is not installable here): for [B,N,3] vs [B,M,3] the
+    squared distance of every point to its nearest neighbour in the other cloud, mean over points, both directions
+    added, batch mean.  Brute force in torch (differentiable through the distances, as pytorch3d's knn_gather is)."""
+    d = ((x[:, :, None, :] - y[:, None, :, :]) ** 2).sum(-1)                 # [B, N, M]
+    return (d.min(dim=2).values.mean(dim=1) + d.min(dim=1).values.mean(dim=1)).mean(), None
+
+
+def reference_models_refine(backend: str, device="cpu"):
+    """The reference's models/models_refine.py (class RefineDiffusion, models_refine.py:18-76) over the stand-ins."""
+    minknet, mods = reference_minkunet(backend, device)
+    pl_light = types.ModuleType("pytorch_lightning.core.lightning")
+
+    class _Lightning(_LightningModule):
+        def log(self, *a, **k):
+            pass
+
+    pl_top, pl_core = types.ModuleType("pytorch_lightning"), types.ModuleType("pytorch_lightning.core")
+    pl_light.LightningModule = _Lightning
+    pl_top.core, pl_core.lightning = pl_core, pl_light
+    pl_top.LightningModule = _Lightning
+    pl_top.LightningDataModule = type("LightningDataModule", (), {})
+    o3d = _open3d_stub()
+    o3d.geometry.Geometry = type("Geometry", (), {})
+    p3d, p3d_loss = types.ModuleType("pytorch3d"), types.ModuleType("pytorch3d.loss")
+    p3d_loss.chamfer_distance = _chamfer_distance_stub
+    p3d.loss = p3d_loss
+    mods = dict(mods)
+    mods.update({"open3d": o3d, "pytorch_lightning": pl_top, "pytorch_lightning.core": pl_core,
+                 "pytorch_lightning.core.lightning": pl_light, "pytorch3d": p3d, "pytorch3d.loss": p3d_loss})
+    utils = {name: _load(os.path.join(REF_PKG, "utils", name + ".py"), f"_ref_utils2_{name}_{backend}", mods, device)
+             for name in ("scheduling", "collations", "metrics")}
+    lidiff_pkg, lidiff_models, lidiff_utils = (types.ModuleType("lidiff"), types.ModuleType("lidiff.models"),
+                                               types.ModuleType("lidiff.utils"))
+    lidiff_pkg.models, lidiff_pkg.utils, lidiff_models.minkunet = lidiff_models, lidiff_utils, minknet
+    mods.update({"lidiff": lidiff_pkg, "lidiff.models": lidiff_models, "lidiff.models.minkunet": minknet,
+                 "lidiff.utils": lidiff_utils})
+    for name, mod in utils.items():
+        setattr(lidiff_utils, name, mod)
+        mods["lidiff.utils." + name] = mod
+    return _load(os.path.join(REF_PKG, "models", "models_refine.py"), f"_ref_models_refine_{backend}", mods, device), minknet
+
+
 @contextlib.contextmanager
 def cuda_calls_as(device):
     """The reference writes ``.cuda()`` (pipeline:23-24,34,59-66,100); inside this context those calls move to

@@ -156,6 +156,96 @@ def test_reference_pipeline_loop_over_oracle_shim(tmp_path, monkeypatch):
 
 
 @needs_reference
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_reference_training_step_over_oracle_shim_equals_functional_oracle(seed):
+    """models.py:180-217 executed: the reference's own DiffusionPoints.training_step (q_sample, points_to_tensor, the
+    condition drop, forward through ITS minkunet.py in training mode, the three loss terms) over the oracle's ME stand-in,
+    with torch autograd, against oracle.minkunet_cpu.training_loss -- the functional restatement every GPU training-parity
+    test uses as truth -- on the same weights, batch and random draws (the draws are replayed from the same seed in the
+    order the reference makes them: randn noise, randint t, rand for the drop).  Seeds cover both branches of the drop."""
+    from lidiff_amd.pipeline import DEFAULT_HPARAMS
+    from oracle import minkunet_cpu as net
+    enc, unet, _ = build_seeded_models(42)
+    ref, _ = ref_exec.reference_models("oracle")
+    with ref_exec.cuda_calls_as("cpu"):
+        mod = ref.DiffusionPoints(DEFAULT_HPARAMS)
+        mod.partial_enc.load_state_dict(enc.state_dict(), strict=True)
+        mod.model.load_state_dict(unet.state_dict(), strict=True)
+        mod.train()
+        scan, _ = small_scene(seed=seed, n=400)
+        full = torch.from_numpy(np.stack([scan, scan[::-1].copy() + np.float32(0.37)]))
+        part = full[:, :60].contiguous()
+        batch = {"pcd_full": full, "pcd_part": part, "mean": torch.zeros(2, 3), "std": torch.ones(2, 3)}
+        torch.manual_seed(seed)
+        loss_ref = mod.training_step(batch, 0)
+        params = dict(mod.named_parameters())
+        names = [k for k in params if k.startswith(("partial_enc.", "model."))]
+        grads_ref = torch.autograd.grad(loss_ref, [params[k] for k in names], allow_unused=True)
+    # the same draws, in the reference's order (models.py:183,186,195)
+    torch.manual_seed(seed)
+    noise = torch.randn(full.shape)
+    t = torch.randint(0, DEFAULT_HPARAMS["diff"]["t_steps"], size=(2,))
+    drop = not bool(torch.rand(1) > DEFAULT_HPARAMS["train"]["uncond_prob"])
+    sd = {k: v.detach().clone() for k, v in diffusion_state_dict(enc, unet).items()}
+    for k, v in sd.items():
+        v.requires_grad_(v.is_floating_point() and "running" not in k)
+    loss_o, _ = net.training_loss(sd, full, part, noise, t, drop_condition=drop)
+    grads_o = torch.autograd.grad(loss_o, [sd[k] for k in names], allow_unused=True)
+    assert abs(float(loss_ref) - float(loss_o)) <= 1e-5 * abs(float(loss_o)), (float(loss_ref), float(loss_o), drop)
+    compared = 0
+    for k, a, b in zip(names, grads_ref, grads_o):
+        if a is None or b is None:
+            assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0), k
+            continue
+        if drop and k.startswith("partial_enc."):
+            continue                     # inf - inf on both sides (zero-variance BatchNorm of the zeroed condition)
+        if float(b.norm()) <= 1e-7:
+            continue
+        compared += 1
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos >= 0.999, (k, cos, drop)
+    assert compared >= 100, compared
+
+
+@needs_reference
+def test_reference_refine_training_step_over_oracle_shim_equals_functional_oracle():
+    """models_refine.py:53-76 executed: the reference's RefineDiffusion.training_step (voxelisation with the batch column
+    divided too, its MinkUNet in training mode, 6 offsets per point, Chamfer loss) over the oracle's ME stand-in and a
+    brute-force stand-in of pytorch3d's chamfer_distance, against oracle.minkunet_cpu.refine_training_loss (KD-tree
+    nearest neighbours) -- the truth of the GPU refine-step parity test."""
+    from lidiff_amd.diffusion import REFINE_HPARAMS
+    from oracle import minkunet_cpu as net
+    _, _, refine = build_seeded_models(42)
+    ref, _ = ref_exec.reference_models_refine("oracle")
+    scan, noisy = small_scene(seed=5, n=300)
+    pcd_noise = torch.from_numpy(np.stack([noisy, noisy[::-1].copy()]))
+    rng = np.random.default_rng(3)
+    pcd_full = torch.from_numpy(np.stack([scan, scan[::-1].copy()]).astype(np.float32)
+                                + 0.02 * rng.standard_normal((2,) + scan.shape).astype(np.float32))
+    with ref_exec.cuda_calls_as("cpu"):
+        mod = ref.RefineDiffusion(REFINE_HPARAMS)
+        mod.model_refine.load_state_dict(refine.state_dict(), strict=True)
+        mod.train()
+        loss_ref = mod.training_step({"pcd_noise": pcd_noise, "pcd_full": pcd_full}, 0)
+        params = dict(mod.model_refine.named_parameters())
+        grads_ref = torch.autograd.grad(loss_ref, list(params.values()), allow_unused=True)
+    sd = {k: v.detach().clone() for k, v in refine.state_dict().items()}
+    for k, v in sd.items():
+        v.requires_grad_(v.is_floating_point() and "running" not in k)
+    loss_o = net.refine_training_loss(sd, pcd_noise, pcd_full, up_factor=REFINE_HPARAMS["train"]["up_factor"])
+    grads_o = torch.autograd.grad(loss_o, [sd[k] for k in params], allow_unused=True)
+    assert abs(float(loss_ref.detach()) - float(loss_o.detach())) <= 1e-5 * abs(float(loss_o.detach()))
+    compared = 0
+    for k, a, b in zip(params, grads_ref, grads_o):
+        if a is None or b is None or float(b.norm()) <= 1e-9:
+            continue
+        compared += 1
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos >= 0.999, (k, cos)
+    assert compared >= 100, compared
+
+
+@needs_reference
 def test_reference_preprocess_scan_equals_product_and_fixture(tmp_path, monkeypatch, fps_scan):
     """preprocess_scan (pipeline:92-105) executed on the bundled scan with the FPS oracle behind the open3d stand-in
     reproduces the committed 18 000-point fixture (x10), i.e. the input every bench / parity run starts from."""

@@ -145,6 +145,14 @@ def _open3d_stub():
         def estimate_normals(self):
             pass
 
+        def compute_point_cloud_distance(self, other):
+            """open3d: per point of self the Euclidean distance to its nearest point of `other` (brute force, float64)."""
+            a, b = np.asarray(self.points, np.float64), np.asarray(other.points, np.float64)
+            out = np.empty(a.shape[0])
+            for lo in range(0, a.shape[0], 512):
+                out[lo:lo + 512] = np.sqrt(((a[lo:lo + 512, None, :] - b[None, :, :]) ** 2).sum(-1).min(axis=1))
+            return out
+
     o3d.geometry = types.SimpleNamespace(PointCloud=PointCloud)
     o3d.utility = types.SimpleNamespace(Vector3dVector=Vector3dVector)
     o3d.io = types.SimpleNamespace(read_point_cloud=None, write_point_cloud=None)
@@ -251,6 +259,13 @@ def reference_models_refine(backend: str, device="cpu"):
         setattr(lidiff_utils, name, mod)
         mods["lidiff.utils." + name] = mod
     return _load(os.path.join(REF_PKG, "models", "models_refine.py"), f"_ref_models_refine_{backend}", mods, device), minknet
+
+
+def reference_metrics():
+    """The reference's utils/metrics.py (RMSE, ChamferDistance, CompletionIoU, PrecisionRecall) over the open3d stand-in."""
+    o3d = _open3d_stub()
+    o3d.geometry.Geometry = type("Geometry", (), {})
+    return _load(os.path.join(REF_PKG, "utils", "metrics.py"), "_ref_metrics", {"open3d": o3d}, "cpu"), o3d
 
 
 @contextlib.contextmanager

@@ -246,6 +246,43 @@ def test_reference_refine_training_step_over_oracle_shim_equals_functional_oracl
 
 
 @needs_reference
+def test_reference_metrics_equal_the_metrics_oracle():
+    """utils/metrics.py executed (RMSE, ChamferDistance, PrecisionRecall incl. its AUC, CompletionIoU) over an open3d
+    stand-in whose compute_point_cloud_distance is a brute-force search: the same numbers as oracle/metrics_cpu.py (KD-tree
+    search, set-based occupancy), which is the truth of tests/test_gpu_evaluation.py."""
+    from oracle import metrics_cpu as om
+    ref, o3d = ref_exec.reference_metrics()
+    rng = np.random.default_rng(8)
+
+    def cloud(a):
+        c = o3d.geometry.PointCloud()
+        c.points = o3d.utility.Vector3dVector(a)
+        return c
+    pairs = []
+    for _ in range(3):
+        gt = rng.uniform(-48, 48, (1500, 3)) * np.array([1.0, 1.0, 0.1])
+        pt = np.concatenate([gt[::2] + rng.normal(0, 0.05, (750, 3)), rng.uniform(-48, 48, (100, 3))])
+        pairs.append((gt, pt))
+    rmse, cd, iou = ref.RMSE(), ref.ChamferDistance(), ref.CompletionIoU(voxel_sizes=[2.0, 1.0])
+    pr = ref.PrecisionRecall(0.05, 0.1, 20)
+    for gt, pt in pairs:
+        rmse.update(cloud(gt), cloud(pt))
+        cd.update(cloud(gt), cloud(pt))
+        pr.update(cloud(gt), cloud(pt))
+        iou.update(cloud(gt), cloud(pt))
+    np.testing.assert_allclose(rmse.dists, [om.rmse_update(g, p) for g, p in pairs], rtol=1e-12)
+    np.testing.assert_allclose(cd.dists, [om.chamfer_update(g, p) for g, p in pairs], rtol=1e-12)
+    want = [om.precision_recall_update(g, p, pr.thresholds) for g, p in pairs]
+    for j, t in enumerate(pr.thresholds):
+        np.testing.assert_allclose(pr.pr_dict[t], [w[j][0] for w in want], rtol=1e-12)
+        np.testing.assert_allclose(pr.re_dict[t], [w[j][1] for w in want], rtol=1e-12)
+        np.testing.assert_allclose(pr.f1_dict[t], [w[j][2] for w in want], rtol=1e-12)
+    counts = sum(om.completion_iou_counts(g, p, voxel_sizes=(2.0, 1.0)).astype(np.int64) for g, p in pairs)
+    assert np.array_equal(iou.conf_matrix.astype(np.int64), counts)
+    assert all(np.isfinite(v) for v in pr.compute_auc())
+
+
+@needs_reference
 def test_reference_preprocess_scan_equals_product_and_fixture(tmp_path, monkeypatch, fps_scan):
     """preprocess_scan (pipeline:92-105) executed on the bundled scan with the FPS oracle behind the open3d stand-in
     reproduces the committed 18 000-point fixture (x10), i.e. the input every bench / parity run starts from."""

@@ -218,6 +218,20 @@ class DiffCompletion(nn.Module):
         with torch.no_grad():
             self.prepare(x_cond)                     # no-ops for fields reset_partial_pcd has prepared already
             self.prepare(x_uncond, tail_maps=False)
+            if self.overlap_maps and getattr(self, "_warm", False) and x_uncond.prepared is not None:
+                # the unconditional branch encodes ONE voxel: ~70 launches that cannot fill the chip.  They run on the side
+                # stream (where the field's maps were built) while the main stream encodes the condition.  Only once the
+                # weights have been packed and the BatchNorm folded by a first pass on the main stream.
+                main, side = self._streams()
+                with torch.cuda.stream(side):
+                    e_un = self.partial_enc(x_uncond)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                e_c = self.partial_enc(self._adopt(x_cond))
+                main.wait_event(done)
+                self._adopt(x_uncond)
+                e_un.F.record_stream(main)
+                return e_c, e_un
             return self.partial_enc(self._adopt(x_cond)), self.partial_enc(self._adopt(x_uncond))
 
     def classfree_forward(self, x_t, x_cond, x_uncond, t, parts=None):
@@ -235,6 +249,7 @@ class DiffCompletion(nn.Module):
                 self.prepare(x_t, also=lambda f: self._match_levels(f, parts))
                 x_t_sparse = self._adopt(x_t).sparse()
                 e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t)
+                self._warm = True
                 e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
                 return e_uncond + self.w_uncond * (e_cond - e_uncond)
         x_t_sparse = x_t.sparse()

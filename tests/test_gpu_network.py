@@ -227,7 +227,7 @@ def test_completion_loop_vs_oracle(device, models):
     assert np.quantile(dd, 0.99) <= 1e-5, (np.quantile(dd, 0.99), dd.max())
 
 
-def test_overlapped_coordinate_pipeline_is_bit_identical(device, models, fps_scan):
+def test_overlapped_coordinate_pipeline_equals_the_serial_one(device, models, fps_scan):
     """DiffCompletion.overlap_maps: the coordinate pipeline of a field on a side stream, under another tensor's convolutions
     (the next step's conditions under the UNet, x_t's maps under the condition encoders).  Scheduling only: four closed-loop
     steps on the 180k-point scan give the same points with and without it, to the last bits (see below) -- twice, to give a

@@ -204,6 +204,68 @@ def coords_roofline(scan_np, device, iters=5):
             "traffic": None, "ms": ms, "algorithmic_mbytes": nbytes / 1e6, "voxels_per_level": m}
 
 
+def train_leg(scan_np, device, steps=3, warmup=1):
+    """Beside the metric, never `value`: BASELINE configs[4]'s per-GPU shape -- DiffusionPoints.training_step (models.py:180-217)
+    forward + loss + backward + Adam on B = 2 scans of 180 000 points with 18 000-point partial scans, random-init weights,
+    fp32 and bf16 (bf16 conv / MLP GEMM operands, fp32 accumulation and state) -- timed with HIP events on the launch stream.
+    Per precision: ms per step and per phase, and the time inside the sparse-conv kernels by role (forward + input-gradient
+    launches, weight-gradient launches; events around every launch: a few % of overhead, stated)."""
+    from lidiff_amd import ops
+    from lidiff_amd.diffusion import DiffusionPoints
+    rng = np.random.default_rng(0)
+    scan = scan_np.astype(np.float32)
+    batches = []
+    for _ in range(2):
+        part = np.stack([scan + 0.01 * rng.standard_normal(scan.shape).astype(np.float32) for _ in range(2)])
+        full = np.tile(part, (1, 10, 1)) + 0.05 * rng.standard_normal((2, 10 * scan.shape[0], 3)).astype(np.float32)
+        batches.append({"pcd_full": torch.from_numpy(full), "pcd_part": torch.from_numpy(part)})
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    out = {"workload": "configs[4] per-GPU shape: B = 2 x 180000 points, 18000-point partial scans, forward + loss + backward "
+                       "+ Adam, random-init weights (tools/train_probe.py is the same step)", "steps": steps, "warmup": warmup}
+    for precision in ("32", "bf16"):
+        torch.manual_seed(0)
+        module = DiffusionPoints(device=device, precision=precision)
+        module.train()
+        opt, _ = module.configure_optimizers()
+        gen = torch.Generator(device=device).manual_seed(1)
+        tot = {"forward_loss_ms": 0.0, "backward_ms": 0.0, "optimizer_ms": 0.0}
+        torch.cuda.reset_peak_memory_stats()
+        conv_ms = dw_ms = 0.0
+        for step in range(warmup + steps):
+            timed = step >= warmup
+            prof = ops.ConvProfiler(None) if timed else None
+            ops.PROFILER = prof
+            e = [ev() for _ in range(4)]
+            e[0].record()
+            loss = module.training_step(batches[step % 2], step, generator=gen)
+            e[1].record()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            e[2].record()
+            opt.step()
+            e[3].record()
+            torch.cuda.synchronize()
+            ops.PROFILER = None
+            if timed:
+                tot["forward_loss_ms"] += e[0].elapsed_time(e[1])
+                tot["backward_ms"] += e[1].elapsed_time(e[2])
+                tot["optimizer_ms"] += e[2].elapsed_time(e[3])
+                conv_ms += sum(a.elapsed_time(b) for _, a, b, *_ in prof.launches if a is not None)
+                dw_ms += prof.dw_ms()
+        ms = {k: v / steps for k, v in tot.items()}
+        total = sum(ms.values())
+        out["f32" if precision == "32" else "bf16"] = {
+            "ms_per_step": total, "steps_per_s": 1e3 / total, "scans_per_s": 2e3 / total, **ms,
+            "conv_fwd_dx_kernels_ms": conv_ms / steps, "conv_dw_kernels_ms": dw_ms / steps,
+            "other_ms": total - (conv_ms + dw_ms) / steps,
+            "peak_memory_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "final_loss": float(loss.detach())}
+        del module, opt, loss
+        torch.cuda.empty_cache()
+    out["note"] = ("other_ms = BatchNorm (torch), conditioning / head MLP GEMMs (hipBLASLt), coordinate maps, loss, Adam and "
+                   "launch gaps; data-parallel training adds one bucketed gradient all-reduce per step (lidiff_amd/dist.py)")
+    return out
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` outside a torchrun environment: re-execute under torch.distributed.run with one
     rank per GPU on 127.0.0.1 (the form the driver uses itself) and hand its exit code back.  A box with fewer
@@ -260,6 +322,8 @@ def main():
     ap.add_argument("--no-coords-roofline", action="store_true", help="skip the coordinate-pipeline (HBM-bound) roofline leg")
     ap.add_argument("--cached-condition", action="store_true",
                     help="also time the same steps with the step-invariant conditions encoded once (reported beside the metric)")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the 'train' leg (configs[4]'s per-GPU training step, fp32 and bf16: 4 steps each)")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the 'alt' leg (the same steps with the dense layers from two bf16 pieces per operand)")
     ap.add_argument("--dry-run", action="store_true",
@@ -422,6 +486,10 @@ def main():
     if world == 1 and not args.no_coords_roofline:
         with torch.no_grad():
             out["roofline_hbm"] = coords_roofline(scan_np, device)
+    if world == 1 and not args.no_train:
+        del pipe
+        torch.cuda.empty_cache()
+        out["train"] = train_leg(scan_np, device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scan_np, threads=args.cpu_threads)
     print(json.dumps(out))

@@ -28,13 +28,14 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 17
+#define LIDIFF_ABI_VERSION 18
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
 #define LIDIFF_CONV_DENSE_KERNEL 2  /* lidiff_spconv_fwd flags: software-pipelined kernel for the dense 128-column layers */
 #define LIDIFF_CONV_DENSE_ONE_WAVE 4 /* ... in its four-wave form (one wave per SIMD, 32 columns per wave) */
+#define LIDIFF_CONV_SKEW 8          /* tile kernel, dense 128-column layers: the wave halves of a SIMD run load / multiply phases in opposite order */
 
 int lidiff_abi_version(void);
 const char* lidiff_last_error(void);
@@ -63,9 +64,12 @@ int lidiff_vox_unique(const int32_t* coords, int64_t n_rows,
 
 /* UNWEIGHTED_AVERAGE quantisation -- pipeline:77, models.py:171 (ME:
  * MinkowskiSPMMAverageFunction): out[v] = mean of feats[i] over inverse[i]==v.
- * counts[m] (float) is an output too (kept for the backward). */
+ * counts[m] (float) is an output too (kept for the backward).  Deterministic: the members of a voxel are summed in
+ * 64-bit fixed point with integer atomics (order-free; scale from max |x| and n_rows so that nothing overflows) and the
+ * exact sum is rounded to fp32 once.  workspace: lidiff_vox_mean_workspace_bytes(m, c) bytes, 16-byte aligned. */
+int64_t lidiff_vox_mean_workspace_bytes(int64_t m, int32_t c);
 int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, int32_t c,
-                    int64_t m, float* out, float* counts, void* stream);
+                    int64_t m, float* out, float* counts, void* workspace, void* stream);
 /* backward of the above: grad_feats[i] = grad_out[inverse[i]] / counts[inverse[i]] */
 int lidiff_vox_mean_bwd(const float* grad_out, const int64_t* inverse, const float* counts,
                         int64_t n_rows, int32_t c, float* grad_feats, void* stream);
@@ -272,7 +276,9 @@ int lidiff_fps(const double* points, int64_t n_points, int64_t n_samples, int64_
 /* The same selection as ONE persistent cooperative launch (device-wide barrier per selection instead of a launch per
  * selection; 134 ms against 198 ms for 18 000 of 119 035 points).  *status (device int32, zeroed by the call) turns non-zero if the barrier
  * timed out -- the selection is then incomplete: run lidiff_fps.  Returns non-zero, nothing enqueued, when the device
- * cannot hold the grid co-resident (no cooperative launch, or more than 8192 points per CU). */
+ * cannot hold the grid co-resident (no cooperative launch, or more than 8192 points per CU) -- which
+ * lidiff_fps_coop_supported(n_points) answers beforehand (1 / 0), so that a caller never has to interpret an error. */
+int32_t lidiff_fps_coop_supported(int64_t n_points);
 int lidiff_fps_coop(const double* points, int64_t n_points, int64_t n_samples, int64_t* selected, void* workspace,
                     int32_t* status, void* stream);
 

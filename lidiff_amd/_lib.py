@@ -23,7 +23,8 @@ SIGNATURES = {
     "lidiff_unique_workspace_bytes": (_i64, [_i64]),
     "lidiff_coords_floor": (_i32, [_p, _i64, _p, _p]),
     "lidiff_vox_unique": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
-    "lidiff_vox_mean": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p]),
+    "lidiff_vox_mean_workspace_bytes": (_i64, [_i64, _i32]),
+    "lidiff_vox_mean": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p]),
     "lidiff_vox_mean_bwd": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     "lidiff_map_stride": (_i32, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "lidiff_kernel_map": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
@@ -53,13 +54,14 @@ SIGNATURES = {
     "lidiff_argmin_rows_f32": (_i32, [_p, _i64, _p, _i64, _p, _p]),
     "lidiff_fps_workspace_bytes": (_i64, [_i64]),
     "lidiff_fps": (_i32, [_p, _i64, _i64, _p, _p, _p]),
+    "lidiff_fps_coop_supported": (_i32, [_i64]),
     "lidiff_fps_coop": (_i32, [_p, _i64, _i64, _p, _p, _p, _p]),
     "lidiff_nn_match_grid": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p]),
     "lidiff_nn_dist_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 _lib = None
 
 

@@ -180,35 +180,64 @@ static int run_unique(const int32_t* coords, int64_t n, int s, uint64_t* hkeys, 
 }
 
 // ---------------------------------------------------------------------------------------
-// voxel mean
+// voxel mean -- deterministic.  The points of a voxel are summed in 64-bit FIXED POINT with integer atomics: integer
+// addition is associative, so the sum does not depend on the order in which the atomics land (fp32 atomics, as ME's GPU path
+// uses, made two runs of the same step differ in the last bits).  The scale is 2^shift with shift chosen per call from
+// max |x| and the point count so that the sum of all N values cannot overflow 62 bits; with LiDiff's features (metres,
+// |x| < 2^7, N < 2^18) shift = 37: every fp32 value above 2^-14 m is represented exactly, the sum is exact, and it is rounded
+// to fp32 ONCE -- for one or two points per voxel (x_t: ~1.0 per voxel) that is bit for bit the sequential fp32 sum.
+__global__ void mean_absmax_kernel(const float* __restrict__ feats, int64_t total, uint32_t* __restrict__ amax) {
+    uint32_t m = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(feats[e]) & 0x7fffffffu);          // |x| as bits: monotonic for finite values
+    for (int off = kWave / 2; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off));
+    if (lane_id() == 0 && m) atomicMax(amax, m);
+}
+
+// 2^shift: the largest power of two for which n_bits-many values below 2^(exponent of amax + 1) sum to less than 2^62
+__device__ __forceinline__ int mean_shift(uint32_t amax_bits, int n_bits) {
+    if (amax_bits == 0) return 0;
+    const int e = (int)(amax_bits >> 23) - 126;                       // max |x| < 2^e
+    return 62 - e - n_bits;
+}
+
 __global__ void mean_accum_kernel(const float* __restrict__ feats, const int64_t* __restrict__ inverse,
-                                  int64_t n, int c, float* __restrict__ out, float* __restrict__ counts) {
+                                  int64_t n, int c, int n_bits, const uint32_t* __restrict__ amax,
+                                  unsigned long long* __restrict__ acc, int32_t* __restrict__ cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     const int row = valid ? (int)inverse[i] : -1;
+    const double scale = ldexp(1.0, mean_shift(*amax, n_bits));
     // all valid lanes of the wave fall in one voxel (x_uncond, heavy duplicates): reduce in the
     // wave and issue ONE atomic per channel instead of 64 serialised same-address atomics.
-    const int r0 = __shfl(row, __ffsll((long long)__ballot(valid)) - 1);
     const unsigned long long vm = __ballot(valid);
     if (vm == 0) return;
+    const int r0 = __shfl(row, __ffsll((long long)vm) - 1);
     if (__all(!valid || row == r0)) {
         for (int j = 0; j < c; ++j) {
-            float v = valid ? feats[i * c + j] : 0.f;
+            long long v = valid ? __double2ll_rn((double)feats[i * c + j] * scale) : 0ll;
             for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane_id() == 0) atomicAdd(&out[(int64_t)r0 * c + j], v);
+            if (lane_id() == 0) atomicAdd(&acc[(int64_t)r0 * c + j], (unsigned long long)v);
         }
-        if (lane_id() == 0) atomicAdd(&counts[r0], (float)__popcll(vm));
+        if (lane_id() == 0) atomicAdd(&cnt[r0], (int32_t)__popcll(vm));
         return;
     }
     if (!valid) return;
-    for (int j = 0; j < c; ++j) atomicAdd(&out[(int64_t)row * c + j], feats[i * c + j]);
-    atomicAdd(&counts[row], 1.0f);
+    for (int j = 0; j < c; ++j)
+        atomicAdd(&acc[(int64_t)row * c + j], (unsigned long long)__double2ll_rn((double)feats[i * c + j] * scale));
+    atomicAdd(&cnt[row], 1);
 }
 
-__global__ void mean_div_kernel(float* __restrict__ out, const float* __restrict__ counts,
-                                int64_t total, int c) {
+__global__ void mean_div_kernel(const unsigned long long* __restrict__ acc, const int32_t* __restrict__ cnt,
+                                int64_t total, int c, int n_bits, const uint32_t* __restrict__ amax,
+                                float* __restrict__ out, float* __restrict__ counts) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < total) out[e] = out[e] / counts[e / c];
+    if (e >= total) return;
+    const double inv_scale = ldexp(1.0, -mean_shift(*amax, n_bits));
+    const float n = (float)cnt[e / c];
+    const float sum = (float)((double)(long long)acc[e] * inv_scale);  // the exact sum, rounded to fp32 once
+    out[e] = sum / n;
+    if (e % c == 0) counts[e / c] = n;
 }
 
 __global__ void mean_bwd_kernel(const float* __restrict__ grad_out, const int64_t* __restrict__ inverse,
@@ -1061,16 +1090,29 @@ int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out, uint
                       d_status, workspace, (hipStream_t)stream);
 }
 
+int64_t lidiff_vox_mean_workspace_bytes(int64_t m, int32_t c) {
+    return (m < 0 || c <= 0) ? 0 : 16 + m * (int64_t)c * 8 + ((m * 4 + 15) / 16) * 16;
+}
+
 int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, int32_t c, int64_t m,
-                    float* out, float* counts, void* stream) {
+                    float* out, float* counts, void* workspace, void* stream) {
     LIDIFF_CHECK_ARG(c > 0 && m >= 0 && n_rows >= 0, "bad shape");
     hipStream_t st = (hipStream_t)stream;
     if (m == 0) return 0;
-    LIDIFF_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)m * c * sizeof(float), st));
-    LIDIFF_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)m * sizeof(float), st));
-    if (n_rows > 0)
-        mean_accum_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(feats, inverse, n_rows, c, out, counts);
-    mean_div_kernel<<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(out, counts, m * c, c);
+    LIDIFF_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "workspace must be 16-byte aligned");
+    // workspace: [max |x| bits (16 B)] [fixed-point sums m x c int64] [point counts m int32]
+    uint32_t* amax = (uint32_t*)workspace;
+    unsigned long long* acc = (unsigned long long*)((char*)workspace + 16);
+    int32_t* cnt = (int32_t*)(acc + m * c);
+    LIDIFF_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)lidiff_vox_mean_workspace_bytes(m, c), st));
+    int n_bits = 1;
+    while ((1ll << n_bits) <= n_rows) ++n_bits;                       // n_rows < 2^n_bits
+    if (n_rows > 0) {
+        const int64_t total = n_rows * c;
+        mean_absmax_kernel<<<(unsigned)(ceil_div(total, kBlock) < 1024 ? ceil_div(total, kBlock) : 1024), kBlock, 0, st>>>(feats, total, amax);
+        mean_accum_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(feats, inverse, n_rows, c, n_bits, amax, acc, cnt);
+    }
+    mean_div_kernel<<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(acc, cnt, m * c, c, n_bits, amax, out, counts);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -1302,22 +1344,36 @@ int lidiff_fps(const double* points, int64_t n_points, int64_t n_samples, int64_
 // one cooperative launch (fps_coop_kernel); workspace: lidiff_fps_workspace_bytes.  *status (device int, zeroed here) becomes
 // non-zero if the device-wide barrier timed out -- the selection is then incomplete and lidiff_fps must be used instead.
 // Returns non-zero (nothing enqueued) if the device cannot hold the grid co-resident or n_points exceeds grid x 8192.
+// grid / points-per-thread of the cooperative kernel for n_points, or false when this device cannot run it that way
+static bool fps_coop_plan(int64_t n_points, int* grid_out, int* pt_out) {
+    int dev = 0, cus = 0, coop = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return false;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_kernel, kFpsBlock, 0) != hipSuccess || per_cu < 1)
+        return false;
+    const int64_t blocks = ceil_div(n_points, kFpsBlock);
+    const int grid = (int)(blocks < cus ? blocks : cus);
+    const int64_t pt = ceil_div(n_points, (int64_t)grid * kFpsBlock);
+    if (pt > kFpsCoopPt) return false;
+    *grid_out = grid;
+    *pt_out = (int)pt;
+    return true;
+}
+
+int32_t lidiff_fps_coop_supported(int64_t n_points) {
+    int grid = 0, pt = 0;
+    return n_points >= 1 && fps_coop_plan(n_points, &grid, &pt) ? 1 : 0;
+}
+
 int lidiff_fps_coop(const double* points, int64_t n_points, int64_t n_samples, int64_t* selected, void* workspace,
                     int32_t* status, void* stream) {
     LIDIFF_CHECK_ARG(n_points >= 1 && n_samples >= 1 && n_samples <= n_points, "need 1 <= n_samples <= n_points");
     LIDIFF_CHECK_ARG(status != nullptr && workspace != nullptr, "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    int dev = 0, cus = 0, coop = 0, per_cu = 0;
-    LIDIFF_CHECK_HIP(hipGetDevice(&dev));
-    LIDIFF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    LIDIFF_CHECK_HIP(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev));
-    LIDIFF_CHECK_ARG(coop != 0, "device does not support cooperative launches");
-    LIDIFF_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_kernel, kFpsBlock, 0));
-    LIDIFF_CHECK_ARG(per_cu >= 1, "fps_coop_kernel does not fit on a CU");
-    const int64_t blocks = ceil_div(n_points, kFpsBlock);
-    const int grid = (int)(blocks < cus ? blocks : cus);
-    int pt = (int)ceil_div(n_points, (int64_t)grid * kFpsBlock);
-    LIDIFF_CHECK_ARG(pt <= kFpsCoopPt, "too many points for the cooperative kernel");
+    int grid = 0, pt = 0;
+    LIDIFF_CHECK_ARG(fps_coop_plan(n_points, &grid, &pt),
+                     "no cooperative launch for this device / point count (ask lidiff_fps_coop_supported first)");
     double* part_val = (double*)workspace;
     int64_t* part_idx = (int64_t*)(part_val + 2 * grid);
     unsigned int* counter = (unsigned int*)(part_idx + 2 * grid);

@@ -67,7 +67,13 @@ struct ConvCfg {
     }
 };
 
-template <int BM, int WN, int WM, int KS, bool VEC>
+// SKEW: the two waves that share a SIMD (waves w and w + NW/2) take the stage's two phases in opposite order.  Left alone
+// they run in lockstep -- both issue the next stage's loads (8 vector-memory instructions, ~100 cycles each while MFMAs are
+// queued) and only then start multiplying, so the SIMD's matrix pipe idles for the whole issue phase of every stage
+// (profiles/r02_dense_kernel_probe.txt: issue 879 + mma 1828 | issue 2228 + mma 2708 of a 6115-cycle stage).  With SKEW
+// the second-dispatched half multiplies first and issues its loads behind its first SKEW_AT 16-channel MFMA groups, i.e.
+// while its partner -- done with its own loads by then -- feeds the pipe.
+template <int BM, int WN, int WM, int KS, bool VEC, bool SKEW = false>
 __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p_launch) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
     ConvParams p = p_launch;                     // per-replica view (pointers moved below)
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #pragma unroll
     for (int j = 0; j < NJ; ++j) foff[j] = li * KS + 4 * ((4 * j + lq) ^ swz(li));
 
+    const bool late = SKEW && wave >= NW / 2;             // wave-uniform: this wave multiplies first, loads second
     constexpr int IMG = AF * 4;                           // bytes per A image
     int img = 0;                                          // byte offset of the image being multiplied
     f32x4 wc[NJ], wnx[NJ];                                // W fragments: current stage / next stage
@@ -320,29 +327,31 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         f32x4 acc[NB > 0 ? NB : 1];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto mma = [&]() {
-            if constexpr (NB > 0) {
+        // MFMA groups [J0, J1) of the stage (a group = 16 channels = 4 MFMA steps per row block), fragments read from the image
+        auto mma_part = [&](auto j0_tag, auto j1_tag) {
+            constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
+            if constexpr (NB > 0 && J1 > J0) {
                 const float* As = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a_buf) + img);
-                f32x4 a[NB][NJ];
+                f32x4 a[NB > 0 ? NB : 1][J1 > J0 ? J1 - J0 : 1];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
+                for (int j = J0; j < J1; ++j)
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
-                        a[b][j] = *reinterpret_cast<const f32x4*>(As + (wm + WM * b) * (16 * KS) + foff[j]);
+                        a[b][j - J0] = *reinterpret_cast<const f32x4*>(As + (wm + WM * b) * (16 * KS) + foff[j]);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
+                for (int j = J0; j < J1; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
-                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][j][e], wc[j][e], acc[b], 0, 0, 0);
+                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][j - J0][e], wc[j][e], acc[b], 0, 0, 0);
                 // Fragment reads run one 16-channel group ahead of the MFMAs: left to itself the scheduler issues
                 // the reads of group j+1 only after the last MFMA of group j, and the MFMA pipe then idles for an LDS
                 // round trip four times per stage (both waves of a SIMD leave the barrier in lockstep, so neither
                 // fills the other's gap).
                 __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
 #pragma unroll
-                for (int j = 0; j + 1 < NJ; ++j)
+                for (int j = J0; j + 1 < J1; ++j)
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -351,6 +360,8 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB, 0);
             }
         };
+        auto mma = [&]() { mma_part(ic<0>{}, ic<NJ>{}); };
+        constexpr int SKEW_AT = NJ / 2;                   // MFMA groups the late half runs before it issues its loads
         auto stage_end = [&]() {
 #ifdef LIDIFF_CONV_PROBE
             STAMP(tb0);
@@ -370,22 +381,43 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #define PHASE(acc, from)
 #endif
         for (int s = 0; s + 1 < nslab; ++s) {             // not the last slab: the next stage is the same item
-            issue(img ^ IMG, item.k, s + 1, item.n, wnx);
-            PHASE(t_issue, tp);
-            mma();
-            PHASE(t_mma, tp);
+            if (!late) {
+                issue(img ^ IMG, item.k, s + 1, item.n, wnx);
+                PHASE(t_issue, tp);
+                mma();
+                PHASE(t_mma, tp);
+            } else {
+                mma_part(ic<0>{}, ic<SKEW_AT>{});
+                PHASE(t_mma, tp);
+                issue(img ^ IMG, item.k, s + 1, item.n, wnx);
+                PHASE(t_issue, tp);
+                mma_part(ic<SKEW_AT>{}, ic<NJ>{});
+                PHASE(t_mma, tp);
+            }
             stage_end();
 #ifdef LIDIFF_CONV_PROBE
             tp = __builtin_readcyclecounter();
 #endif
         }
-        if (has_next) {                                   // last slab: the next stage opens the next item
-            load_rows(next);
-            issue(img ^ IMG, next.k, 0, next.n, wnx);
+        if (!late) {
+            if (has_next) {                               // last slab: the next stage opens the next item
+                load_rows(next);
+                issue(img ^ IMG, next.k, 0, next.n, wnx);
+            }
+            PHASE(t_issue, tp);
+            mma();
+            PHASE(t_mma, tp);
+        } else {
+            mma_part(ic<0>{}, ic<SKEW_AT>{});
+            PHASE(t_mma, tp);
+            if (has_next) {
+                load_rows(next);
+                issue(img ^ IMG, next.k, 0, next.n, wnx);
+            }
+            PHASE(t_issue, tp);
+            mma_part(ic<SKEW_AT>{}, ic<NJ>{});
+            PHASE(t_mma, tp);
         }
-        PHASE(t_issue, tp);
-        mma();
-        PHASE(t_mma, tp);
         STAMP(tf0);
         if constexpr (NB > 0) {
             if (!PROBE(16)) {
@@ -642,12 +674,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int k_vol, int 
     wp[idx] = kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f;
 }
 
-template <int BM, int WN, int WM, int KS, bool VEC>
+template <int BM, int WN, int WM, int KS, bool VEC, bool SKEW = false>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
     const size_t lds = Cfg::lds_bytes(p.k_vol);
     LIDIFF_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded");
-    auto kern = spconv_fwd_kernel<BM, WN, WM, KS, VEC>;
+    auto kern = spconv_fwd_kernel<BM, WN, WM, KS, VEC, SKEW>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -668,8 +700,11 @@ static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
     if (!vec) return launch_fwd<BM, WN, WM, 32, false>(p, st);
     // 64-channel stages halve the per-stage costs of dense maps; low-density maps (hint from the caller)
     // take the 32-channel kernel, whose tiles can pack several offsets into one stage
-    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0 && !(p.flags & LIDIFF_CONV_SPARSE_MAP))
+    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0 && !(p.flags & LIDIFF_CONV_SPARSE_MAP)) {
+        if constexpr (WM == 1 && WN == 8)               // the dense 128-column layers: skewed wave halves on request
+            if (p.flags & LIDIFF_CONV_SKEW) return launch_fwd<BM, WN, WM, 64, true, true>(p, st);
         return launch_fwd<BM, WN, WM, 64, true>(p, st);
+    }
     return launch_fwd<BM, WN, WM, 32, true>(p, st);
 }
 

@@ -22,6 +22,17 @@ REFINE_HPARAMS = {"data": {"resolution": 0.05, "num_points": 180000, "scan_windo
                   "train": {"lr": 1e-4, "batch_size": 8, "up_factor": 6, "max_epoch": 5}}
 
 
+def prebuild_maps(field):
+    """Voxelise `field` and build every coordinate / kernel map its network will ask for BEFORE the first layer runs.  The
+    sparse-map hint of a level (fp32 packed-stage kernel vs bf16 kernel in bf16 training) looks at the next coarser map;
+    built lazily, the encoder half of a network would not have it yet and the same level would run different kernels on
+    the way down and on the way up.  Built up front, the choice depends on the maps only."""
+    with torch.no_grad():
+        field.sparse()
+        field.coordinate_manager.prebuild(tail_maps=False)
+    return field
+
+
 def linear_beta_schedule(timesteps, beta_start, beta_end):
     """lidiff/utils/scheduling.py:15-16."""
     return torch.linspace(beta_start, beta_end, timesteps)
@@ -101,6 +112,8 @@ class DiffusionPoints(nn.Module):
             x_part = self.points_to_tensor(pcd_part)
         else:
             x_part = self.points_to_tensor(torch.zeros_like(pcd_part))
+        prebuild_maps(x_full)
+        prebuild_maps(x_part)
         with ops.train_operands("bf16" if self.precision == "bf16" else "f32"):
             denoise_t = self.forward(x_full, x_full.sparse(), x_part, t)
         loss_mse = self.p_losses(denoise_t, noise)
@@ -152,7 +165,7 @@ class RefineDiffusion(nn.Module):
         x_t = ME.TensorField(features=x_feats, coordinates=x_coord,
                              quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
                              minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
-        offset = self.forward_refine(x_t).reshape(-1, up, 3)
+        offset = self.forward_refine(prebuild_maps(x_t)).reshape(-1, up, 3)
         pred = (x_feats[:, None, :] + offset).reshape(batch["pcd_full"].shape[0], -1, 3)
         return chamfer_distance(pred, batch["pcd_full"].to(self.device).float())
 

@@ -77,13 +77,14 @@ def map_stride(coords: torch.Tensor, s_out: int, status: torch.Tensor):
 
 
 def vox_mean(feats: torch.Tensor, inverse: torch.Tensor, m: int):
-    """UNWEIGHTED_AVERAGE features (pipeline:77).  Returns (out[M,C], counts[M])."""
+    """UNWEIGHTED_AVERAGE features (pipeline:77).  Returns (out[M,C], counts[M]).  Deterministic (fixed-point sums)."""
     require_device(feats, inverse)
     feats = feats.contiguous().float()
     n, c = feats.shape
     out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
     counts = torch.empty(m, dtype=torch.float32, device=feats.device)
-    call("lidiff_vox_mean", ptr(feats), ptr(inverse), n, c, m, ptr(out), ptr(counts), stream_ptr())
+    ws = torch.empty(_lib.load().lidiff_vox_mean_workspace_bytes(int(m), int(c)), dtype=torch.uint8, device=feats.device)
+    call("lidiff_vox_mean", ptr(feats), ptr(inverse), n, c, m, ptr(out), ptr(counts), ptr(ws), stream_ptr())
     return out, counts
 
 
@@ -171,6 +172,11 @@ class ConvProfiler:
     def __init__(self, variants=None):
         self.variants = None if variants is None else set(variants)
         self.launches = []          # (variant, start|None, end|None, m_in, m_out, c_in, c_out, k, nbr|None, replicas)
+        self.dw = []                # (start, end) of the weight-gradient launches (variant "dw"; bench.py's train leg)
+
+    def dw_ms(self) -> float:
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.dw)
 
     def wants(self, variant: str) -> bool:
         return self.variants is None or variant in self.variants
@@ -207,6 +213,8 @@ DETERMINISTIC_DW = True
 # Kernel choice for the dense 128-column layers: "tile" (spconv.hip, default), "dense" (spconv_dense.hip, eight waves),
 # "dense1" (its four-wave form).  Results are bit-identical; DESIGN.md section 4.2 has the measurements.
 DENSE_KERNEL = os.environ.get("LIDIFF_CONV_KERNEL", "tile")
+# extra lidiff_spconv_fwd flag bits (include/lidiff_amd.h LIDIFF_CONV_*), e.g. 8 = LIDIFF_CONV_SKEW
+CONV_FLAGS = int(os.environ.get("LIDIFF_CONV_FLAGS", "0"))
 
 
 def conv_variant(c_out: int) -> str:
@@ -319,7 +327,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
          c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas),
-         int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6}[kernel or DENSE_KERNEL],
+         int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6}[kernel or DENSE_KERNEL] | CONV_FLAGS,
          ptr(t_rows), ptr(t_ptr), ptr(t_idx), n_tail, stream_ptr())
     if timed:
         end.record()
@@ -481,9 +489,17 @@ def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None, bf16: bool = False) -> 
             ws = torch.empty(nws, dtype=torch.float32, device=in_a.device) if nws else None
         alloc = torch.empty if ws is not None else torch.zeros
         dw = alloc((k, c_a + c_b, c_out), dtype=torch.float32, device=in_a.device)
+        prof = PROFILER
+        timed = prof is not None and prof.wants("dw")
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         call("lidiff_spconv_bwd_w_bf16" if bf16 else "lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out),
              ptr(pin), ptr(pout), ptr(off),
              n_pairs, k, in_a.shape[0], m_out, c_out, ptr(dw), ptr(ws), stream_ptr())
+        if timed:
+            ev[1].record()
+            prof.dw.append(ev)
         return dw
     x = in_a if in_b is None else torch.cat([in_a, in_b], dim=1)
     if nbr is None:                                   # kernel_size 1: identity map
@@ -560,17 +576,16 @@ def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
         return torch.arange(n, device=pts.device)
     sel = torch.empty(n_samples, dtype=torch.int64, device=pts.device)
     ws = torch.empty(_lib.load().lidiff_fps_workspace_bytes(n), dtype=torch.uint8, device=pts.device)
-    if FPS_COOPERATIVE:
+    if FPS_COOPERATIVE and _lib.load().lidiff_fps_coop_supported(n):
         # one persistent cooperative launch (device-wide barrier per selection).  Its status word is read back -- the caller
-        # indexes with the result on the host side of the step anyway -- and a barrier time-out, or a device that cannot
-        # hold the grid co-resident, falls back to the launch-per-selection kernel below (same indices).
+        # indexes with the result on the host side of the step anyway.  Only a barrier time-out (reported, not silent)
+        # falls back to the launch-per-selection kernel below (same indices); every other failure raises.
         status = torch.empty(1, dtype=torch.int32, device=pts.device)
-        try:
-            call("lidiff_fps_coop", ptr(pts), n, int(n_samples), ptr(sel), ptr(ws), ptr(status), stream_ptr())
-            if int(status.item()) == 0:
-                return sel
-        except RuntimeError:
-            pass
+        call("lidiff_fps_coop", ptr(pts), n, int(n_samples), ptr(sel), ptr(ws), ptr(status), stream_ptr())
+        if int(status.item()) == 0:
+            return sel
+        import warnings
+        warnings.warn("lidiff_fps_coop: device-wide barrier timed out; re-running the selection with lidiff_fps")
     call("lidiff_fps", ptr(pts), n, int(n_samples), ptr(sel), ptr(ws), stream_ptr())
     return sel
 

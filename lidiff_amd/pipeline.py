@@ -160,6 +160,9 @@ class DiffCompletion(nn.Module):
             start = torch.cuda.Event()
             start.record(main)
         side.wait_event(start)
+        # the old field's points were allocated on the main stream and are dropped when this step returns: tell the caching
+        # allocator that the side stream reads them, or the block could be handed out again while the side stream still reads
+        x_part.F.record_stream(side)
         with torch.cuda.stream(side):
             pts = x_part.F.reshape(1, -1, 3).detach()
             x_part = self.points_to_tensor(pts)
@@ -209,19 +212,34 @@ class DiffCompletion(nn.Module):
     # pipeline:140-146
     def forward(self, x_full, x_full_sparse, x_part, t):
         with torch.no_grad():
-            part_feat = self.partial_enc(x_part)
+            # a field that reset_partial_pcd / prepare built on the side stream: join before the encoder reads its maps
+            part_feat = self.partial_enc(self._adopt(x_part))
             out = self.model(x_full, x_full_sparse, part_feat, t)
         return out.reshape(t.shape[0], -1, 3)
 
     # pipeline:148-153
+    def _encoder_state(self):
+        """Identity of partial_enc's tensors as the packed-weight / folded-BatchNorm caches key them (storage + version):
+        changes with load_state_dict, an optimizer step, .to(), copy_ -- anything after which the next encoder pass
+        re-packs weights and re-folds BatchNorm."""
+        ver = ptrs = 0
+        for t in list(self.partial_enc.parameters()) + list(self.partial_enc.buffers()):
+            ver += t._version
+            ptrs ^= t.data_ptr()
+        return ver, ptrs, self.partial_enc.training
+
     def encode_conditions(self, x_cond, x_uncond):
         with torch.no_grad():
             self.prepare(x_cond)                     # no-ops for fields reset_partial_pcd has prepared already
             self.prepare(x_uncond, tail_maps=False)
-            if self.overlap_maps and getattr(self, "_warm", False) and x_uncond.prepared is not None:
+            state = self._encoder_state()
+            if (self.overlap_maps and getattr(self, "_warm_state", None) == state and not state[2]
+                    and x_uncond.prepared is not None):
                 # the unconditional branch encodes ONE voxel: ~70 launches that cannot fill the chip.  They run on the side
-                # stream (where the field's maps were built) while the main stream encodes the condition.  Only once the
-                # weights have been packed and the BatchNorm folded by a first pass on the main stream.
+                # stream (where the field's maps were built) while the main stream encodes the condition.  Only while the
+                # encoder's tensors are the ones a pass on the MAIN stream has already packed / folded (_warm_state): after
+                # any change of the weights the next pass runs on the main stream alone, so that the caches are (re)built
+                # in stream order and never first touched from the side stream.
                 main, side = self._streams()
                 with torch.cuda.stream(side):
                     e_un = self.partial_enc(x_uncond)
@@ -232,7 +250,9 @@ class DiffCompletion(nn.Module):
                 self._adopt(x_uncond)
                 e_un.F.record_stream(main)
                 return e_c, e_un
-            return self.partial_enc(self._adopt(x_cond)), self.partial_enc(self._adopt(x_uncond))
+            out = self.partial_enc(self._adopt(x_cond)), self.partial_enc(self._adopt(x_uncond))
+            self._warm_state = state                 # packed weights / folded BatchNorm now exist, queued on the main stream
+            return out
 
     def classfree_forward(self, x_t, x_cond, x_uncond, t, parts=None):
         if self.overlap_maps and x_t.F.device.type == "cuda":
@@ -249,10 +269,10 @@ class DiffCompletion(nn.Module):
                 self.prepare(x_t, also=lambda f: self._match_levels(f, parts))
                 x_t_sparse = self._adopt(x_t).sparse()
                 e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t)
-                self._warm = True
                 e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
                 return e_uncond + self.w_uncond * (e_cond - e_uncond)
-        x_t_sparse = x_t.sparse()
+        # two forwards, as the reference runs them (pair_cfg = False); forward() joins the side stream for the conditions
+        x_t_sparse = self._adopt(x_t).sparse()
         e_cond = self.forward(x_t, x_t_sparse, x_cond, t)
         e_uncond = self.forward(x_t, x_t_sparse, x_uncond, t)
         return e_uncond + self.w_uncond * (e_cond - e_uncond)

@@ -122,3 +122,18 @@ def state_dict_arrays(sd):
     """A few weight tensors as cache-key material (seeded models: the seed decides all of them)."""
     keys = sorted(sd.keys())
     return [sd[k].detach().cpu().numpy() for k in (keys[0], keys[len(keys) // 2], keys[-1])]
+
+
+def record_parity(name: str, **values):
+    """Append the ACHIEVED error of a parity test as one JSON line to $LIDIFF_PARITY_LOG (default
+    gpurun_out/parity_errors.jsonl, which gpurun merges back): the source of profiles/rNN_parity_errors.txt and of the
+    tolerances the tests assert (<= 10x the measured values).  Never fails a test."""
+    import json
+    path = os.environ.get("LIDIFF_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_errors.jsonl"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps({"test": name, **{k: (float(v) if isinstance(v, (int, float, np.floating)) else v)
+                                                 for k, v in values.items()}}) + "\n")
+    except OSError:
+        pass

@@ -15,6 +15,7 @@ They pin the oracle against regressions and give the GPU parity tests fixed inpu
   dpm_trajectory.npz       : DPM-Solver++ (sde, 2nd order) trajectory with injected noise
   unet_small.npz           : MinkGlobalEnc + MinkUNetDiff CFG output and MinkUNet output on a
                              2 000-point cloud, weights from torch.manual_seed(42)
+  c1_t*.npz, t50_small.npz : (--heavy) the whole-network oracle results of the BASELINE-configuration tests, see make_heavy()
 """
 import os
 import sys
@@ -166,7 +167,29 @@ def make_unet():
     print("unet eps", eps.shape, float(np.abs(eps).mean()), "refine", off.shape, "from", source)
 
 
+def make_heavy():
+    """python tests/golden/make_golden.py --heavy: the slow whole-network oracle legs of tests/test_gpu_baseline.py
+    (tests/heavy_oracle.py) as tracked fixtures -- one CFG step on the 180 000-point bench scan at four trajectory positions
+    (c1_t999 / c1_t300 / c1_t100 / c1_t20 .npz, ~45 s of CPU each) and the 50-step closed loop on 2 000 points (t50_small.npz)."""
+    import time
+    import heavy_oracle as heavy
+    fps = np.load(os.path.join(HERE, "scan_000123_fps18000.npy"))
+    sd = heavy.seeded_state_dict()
+    for t in heavy.C1_TIMESTEPS:
+        t0 = time.time()
+        out = heavy.c1_compute(fps, t, sd)
+        heavy.save_golden(f"c1_t{t}", heavy.c1_key(fps, t, sd), {"eps": out["eps"].astype(np.float32), "t": np.array(t)})
+        print(f"c1_t{t}: max |eps| {np.abs(out['eps']).max():.4f}, {time.time() - t0:.0f} s", flush=True)
+    t0 = time.time()
+    traj = heavy.t50_compute(sd)
+    heavy.save_golden("t50_small", heavy.t50_key(sd), {"eps": traj["eps"].astype(np.float32), "x": traj["x"]})
+    print(f"t50_small: {time.time() - t0:.0f} s", flush=True)
+
+
 if __name__ == "__main__":
+    if "--heavy" in sys.argv:
+        make_heavy()
+        sys.exit(0)
     if os.path.exists("/root/reference/lidiff/Datasets/test/000123.ply") and "--no-scan" not in sys.argv:
         make_scan()
     cm = make_coords()

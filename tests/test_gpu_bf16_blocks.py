@@ -1,0 +1,165 @@
+"""Block-level pins of the bf16 TRAINING path (BASELINE configs[4]): every stage of the encoder and
+decoder of MinkUNetDiff (minkunet.py:183-263, 283-368: BasicConvolutionBlock / BasicDeconvolutionBlock + two ResidualBlocks,
+train-mode BatchNorm) on the HIP bf16 kernels -- forward, input gradient and every parameter gradient -- against the oracle's
+emulation of the same arithmetic (oracle/me_cpu.py: bf16_operands(): operands rounded to bf16, sums in float64), FROM
+IDENTICAL INPUTS per block, so the comparison is one block deep instead of 49 convolutions deep.
+
+Why not bit-tight, and what the bars mean.  Inside a block the second convolution rounds the first one's output to bf16.
+The two sides agree on that output to fp32 summation noise (~1e-6 relative), so an element that sits within 1e-6 of a bf16
+rounding boundary (probability ~1e-6 / 2^-8 = 3e-4 per element) rounds the other way on the two sides and enters the next sum
+with a 2^-8 relative difference.  A row of the next convolution sums 27 x C inputs, so a fair share of the output rows sees
+ONE such term: an error of ~2^-8 |x w| = 2^-8 / sqrt(27 C) of the row's scale -- 1e-4 .. 2e-4.  These tests therefore hold
+  * the FIRST convolution of every block (no rounding upstream) to the fp32 kernel's bar, 1e-4, on every element
+    (test_gpu_kernels.py pins each kernel alone the same way);
+  * the block output, dX and every dW to: >= 99 % of the elements within 1e-4 (rtol = atol), NO element beyond 4e-3 of the
+    tensor's scale (one flipped term), cosine >= 0.99999 (measured values: gpurun_out/parity_errors.jsonl ->
+    profiles/r03_parity_errors.txt).
+The same code path run twice on the CPU in float32 and float64 (tools/bf16_block_calibration.py) shows the same two regimes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import record_parity
+from oracle import me_cpu as me
+from oracle import minkunet_cpu as net
+
+pytestmark = pytest.mark.gpu
+
+# name, kind, level of the block's INPUT (stride 2^level), c_in, c_out, c_skip
+BLOCKS = [("stage1", "stage", 0, 32, 32, 0), ("stage2", "stage", 1, 32, 64, 0), ("stage3", "stage", 2, 64, 128, 0),
+          ("stage4", "stage", 3, 128, 256, 0), ("up1", "up", 4, 256, 256, 128), ("up2", "up", 3, 256, 128, 64),
+          ("up3", "up", 2, 128, 96, 32), ("up4", "up", 1, 96, 96, 32)]
+
+
+def scene_points(fps_scan):
+    """36 000 points: the bundled scan twice with 0.3 m of noise -- thousands of voxels at every level down to stride 16."""
+    rng = np.random.default_rng(17)
+    base = np.tile(fps_scan.astype(np.float32), (2, 1))
+    return (base + 0.3 * rng.standard_normal(base.shape).astype(np.float32)).astype(np.float32)
+
+
+def block_inputs(name, m_in, m_skip, m_out, cin, cout, cskip):
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = torch.randn(m_in, cin, generator=g)
+    skip = torch.randn(m_skip, cskip, generator=g) if cskip else None
+    cot = torch.randn(m_out, cout, generator=g)                       # cotangent: loss = sum(out * cot)
+    return x, skip, cot
+
+
+def oracle_block(sd, kind, x_cpu, skip_cpu, x, skip, cot, dtype=torch.float64):
+    """(out, dX, {param: grad}) of the oracle's block under bf16_operands() + train_mode(), sums in `dtype`."""
+    sdd = {k: v.detach().to(dtype).requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k)
+           for k, v in sd.items()}
+    xin = x.to(dtype).requires_grad_(True)
+    xs = x_cpu.replace(xin)
+    with me.bf16_operands(), net.train_mode():
+        if kind == "stage":
+            y = net._stage(sdd, "b", xs)
+        else:
+            y = net._up(sdd, "b", xs, skip_cpu.replace(skip.to(dtype)))
+    names = [k for k, v in sdd.items() if v.requires_grad]
+    grads = torch.autograd.grad((y.F * cot.to(dtype)).sum(), [xin] + [sdd[k] for k in names], allow_unused=True)
+    return y.F.detach(), grads[0], dict(zip(names, grads[1:]))
+
+
+def first_conv(sd, kind, x_cpu, x, dtype=torch.float64):
+    """The block's first convolution alone (strided conv of a stage / transposed conv of an up block), bf16 operands."""
+    with me.bf16_operands(), torch.no_grad():
+        fn = me.conv if kind == "stage" else me.conv_transpose
+        return fn(x_cpu.replace(x.to(dtype)), sd["b.0.net.0.kernel"].to(dtype), 2, 2).F
+
+
+def compare(tag, got, want):
+    """-> dict(frac_within_1e-4, worst / scale, cosine)"""
+    got, want = got.double().reshape(-1), want.double().reshape(-1)
+    d = (got - want).abs()
+    scale = want.abs().max().item() + 1e-30
+    within = (d <= 1e-4 + 1e-4 * want.abs()).double().mean().item()
+    cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-300))
+    return {"what": tag, "within_1e-4": within, "worst_over_scale": d.max().item() / scale, "cosine": cos}
+
+
+def check(stats, block):
+    record_parity("bf16_block", block=block, **stats)
+    assert stats["within_1e-4"] >= 0.99 and stats["worst_over_scale"] <= 4e-3 and stats["cosine"] >= 0.99999, (block, stats)
+
+
+@pytest.fixture(scope="module")
+def maps(device, fps_scan):
+    import lidiff_amd.MinkowskiEngine as ME
+    from test_gpu_network import to_field
+    pts = scene_points(fps_scan)
+    f_dev = to_field(pts, device)
+    f_dev.sparse()
+    mgr = f_dev.coordinate_manager
+    mgr.prebuild(tail_maps=False)
+    f_cpu = net.points_to_field(torch.from_numpy(pts)[None])
+    x0 = f_cpu.sparse()
+    ts = 1
+    for _ in range(4):
+        ts = x0.mgr.stride(ts, 2)
+    for t in (1, 2, 4, 8, 16):
+        assert np.array_equal(mgr.maps[t].coords.cpu().numpy(), x0.mgr.maps[t])
+    return ME, mgr, x0.mgr
+
+
+@pytest.mark.parametrize("name,kind,level,cin,cout,cskip", BLOCKS)
+def test_bf16_training_block_vs_oracle_emulation(device, maps, name, kind, level, cin, cout, cskip):
+    from lidiff_amd import minkunet as product
+    from lidiff_amd import ops
+    ME, mgr, cmgr = maps
+    ts_in = 1 << level
+    ts_out = ts_in * 2 if kind == "stage" else ts_in // 2
+    m = lambda t: cmgr.maps[t].shape[0]
+    torch.manual_seed(1000 + level)
+    block = product._stage(cin, cout, 3) if kind == "stage" else product._up(cin, cout, cskip, 3)
+    for mod in block.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data.uniform_(0.8, 1.2)
+            mod.bias.data.normal_(0, 0.1)
+    sd = {"b." + k: v.detach().clone() for k, v in block.state_dict().items()}
+    x, skip, cot = block_inputs(name, m(ts_in), m(ts_out) if cskip else 0, m(ts_out), cin, cout, cskip)
+    x_cpu = me.CpuSparseTensor(x, ts_in, cmgr)
+    skip_cpu = me.CpuSparseTensor(skip, ts_out, cmgr) if cskip else None
+
+    block = block.to(device).train()
+    xd = x.to(device).requires_grad_(True)
+    prev = ops.BF16_SPARSE_MAPS
+    ops.BF16_SPARSE_MAPS = True                                     # the oracle emulates EVERY eligible layer in bf16
+    try:
+        with ops.train_operands("bf16"):
+            xin = ME.SparseTensor(xd, tensor_stride=ts_in, coordinate_manager=mgr)
+            if kind == "stage":
+                y = block(xin)
+            else:
+                y = product._run_up(block, xin, ME.SparseTensor(skip.to(device), tensor_stride=ts_out, coordinate_manager=mgr))
+            assert y.tensor_stride == ts_out
+            (y.F * cot.to(device)).sum().backward()
+            with torch.no_grad():
+                conv = block[0].net[0]                              # strided conv of a stage / transposed conv of an up block
+                nbr, _, ts_first, _ = conv.maps(xin)
+                first = ops.spconv_fwd_bf16(xd.detach(), conv.kernel, nbr, m(ts_first))
+    finally:
+        ops.BF16_SPARSE_MAPS = prev
+    want_first = first_conv(sd, kind, x_cpu, x)
+    s = compare("first conv", first.cpu(), want_first)
+    record_parity("bf16_block", block=name, **s)
+    assert torch.allclose(first.cpu().double(), want_first, rtol=1e-4, atol=1e-4), (name, s)   # no rounding upstream: fp32 bar
+    out_o, gx_o, gp_o = oracle_block(sd, kind, x_cpu, skip_cpu, x, skip, cot)
+    check(compare("block output", y.F.detach().cpu(), out_o), name)
+    check(compare("dX", xd.grad.cpu(), gx_o), name)
+    worst = None
+    n_params = 0
+    for k, p in block.named_parameters():
+        go = gp_o["b." + k]
+        assert go is not None and p.grad is not None, k
+        st = compare("dW " + k, p.grad.cpu(), go)
+        n_params += 1
+        if worst is None or st["cosine"] < worst["cosine"]:
+            worst = st
+        # parameter gradients are sums over all rows: flipped terms average out -- cosine and norm are the bar
+        nrel = abs(float(p.grad.norm()) - float(go.norm())) / (float(go.norm()) + 1e-30)
+        assert st["cosine"] >= 0.99999 and nrel <= 1e-3, (name, k, st, nrel)
+    record_parity("bf16_block", block=name, n_params=n_params, **worst)
+    print(f"bf16 block {name}: {n_params} parameter gradients, worst {worst}")

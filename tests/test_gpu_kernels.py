@@ -116,6 +116,49 @@ def test_floor_and_mean(device, fps_scan):
     assert np.array_equal(counts.cpu().numpy(), np.bincount(inv.cpu().numpy(), minlength=uniq.shape[0]))
 
 
+def test_voxel_mean_is_deterministic_and_correctly_rounded(device, fps_scan):
+    """lidiff_vox_mean sums a voxel's members in 64-bit fixed point with integer atomics: the result does not depend on the
+    order the atomics land in (bit-identical across runs, also with other kernels in flight), it is the EXACT sum rounded to
+    fp32 once -- hence bit for bit the sequential fp32 sum (ME's CPU order, oracle/me_cpu.py:voxel_mean) wherever a voxel
+    holds one or two points -- and within one rounding of the float64 mean everywhere else (heavy duplicates, the
+    all-in-one-voxel x_uncond field of pipeline:89, large and tiny magnitudes in one call)."""
+    from lidiff_amd import ops
+    pts = noisy_scan_points(fps_scan, 0.05, 0, n_rep=10)                      # 180 000 points, ~1.1 per voxel
+    feats = torch.from_numpy(pts)
+    ci = torch.cat([torch.zeros(pts.shape[0], 1), torch.round(feats / 0.05)], 1).to(torch.int32).to(device)
+    uniq, inv, _, _ = ops.vox_unique(ci, status(device))
+    m = uniq.shape[0]
+    fd = feats.to(device)
+    out, counts = ops.vox_mean(fd, inv, m)
+    side = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(side):                                             # noise on the chip while the second run sums
+        junk = torch.randn(4096, 4096, device=device)
+        for _ in range(3):
+            junk = junk @ junk * 1e-3
+    out2, _ = ops.vox_mean(fd, inv, m)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    inv_np = inv.cpu().numpy()
+    cnt = np.bincount(inv_np, minlength=m)
+    want = me.voxel_mean(feats, inv_np, m)                                    # sequential fp32 sums in point order
+    few = torch.from_numpy(cnt <= 2)
+    assert few.float().mean() > 0.8 and torch.equal(out.cpu()[few], want[few])
+    exact = torch.zeros(m, 3, dtype=torch.float64).index_add_(0, torch.from_numpy(inv_np), feats.double())
+    exact = (exact.float() / torch.from_numpy(cnt).float()[:, None])          # exact sum -> fp32 once -> fp32 division
+    assert torch.equal(out.cpu(), exact)
+    # every point in ONE voxel (x_uncond), mixed magnitudes, three runs
+    n = 70001
+    g = torch.Generator().manual_seed(4)
+    vals = torch.randn(n, 3, generator=g) * torch.tensor([50.0, 1e-3, 1.0])
+    one = torch.zeros(n, dtype=torch.int64, device=device)
+    runs = [ops.vox_mean(vals.to(device), one, 1)[0].cpu() for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    ref = vals.double().mean(0)
+    assert torch.allclose(runs[0][0].double(), ref, rtol=1e-6, atol=1e-7), (runs[0], ref)
+    zeros = ops.vox_mean(torch.zeros(n, 3, device=device), one, 1)[0]
+    assert torch.equal(zeros.cpu(), torch.zeros(1, 3))
+
+
 def conv_case(device, coords_np, cin, cout, kind, seed, epilogue=False, split=0):
     """kind: 'k3' | 'down' | 'up' | 'k1'."""
     from lidiff_amd import ops
@@ -511,6 +554,43 @@ def test_spconv_dense_kernel_is_bit_identical_to_the_tile_kernel(device, kernel)
             want = me.conv_forward(x[:m].double(), (w if k > 1 else w[0]).double(), nbr_np)
             want = torch.relu(want * sc.double() + sh.double() + res[:m].double())
             assert torch.allclose(got[:m].cpu().double(), want, rtol=RTOL, atol=ATOL), (kind, cin, split, cout)
+
+
+@pytest.mark.parametrize("cin,cout,split,replicas", [(256, 256, 0, 1), (384, 256, 256, 2), (128, 128, 0, 2), (64, 128, 0, 1)])
+def test_spconv_skewed_wave_halves_are_bit_identical(device, fps_scan, cin, cout, split, replicas):
+    """LIDIFF_CONV_SKEW (the two waves of a SIMD take a stage's load / multiply phases in opposite order): scheduling only --
+    every accumulator sees the same products in the same order, so the output equals the plain tile kernel's bit for bit, on
+    a dense map of the bench scan (stride 8), with epilogue, split input and replicas."""
+    from lidiff_amd import ops
+    import lidiff_amd.MinkowskiEngine as ME
+    pts = noisy_scan_points(fps_scan, 0.5, 1, n_rep=4)
+    feats = torch.from_numpy(pts).to(device)
+    coord = torch.cat([torch.zeros(pts.shape[0], 1, device=device), torch.round(feats / 0.05)], 1)
+    field = ME.TensorField(features=feats, coordinates=coord, device=device)
+    field.sparse()
+    mgr = field.coordinate_manager
+    ts = 1
+    for _ in range(3):
+        ts = mgr.stride(ts, 2)
+    nbr = mgr.kernel_map(8, 8, 3)
+    m = nbr.shape[1]
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(replicas * m, cin, generator=g).to(device)
+    w = (torch.randn(27, cin, cout, generator=g) / np.sqrt(9 * cin)).to(device)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(device), torch.randn(cout, generator=g).to(device)
+    res = torch.randn(replicas * m, cout, generator=g).to(device)
+    kw = dict(in_b=x[:, split:].contiguous() if split else None, scale=scale, shift=shift, residual=res, relu=True,
+              replicas=replicas)
+    xa = x[:, :split].contiguous() if split else x
+    prev = ops.CONV_FLAGS
+    try:
+        ops.CONV_FLAGS = 0
+        plain = ops.spconv_fwd(xa, w, nbr, m, **kw)
+        ops.CONV_FLAGS = 8
+        skew = ops.spconv_fwd(xa, w, nbr, m, **kw)
+    finally:
+        ops.CONV_FLAGS = prev
+    assert torch.isfinite(plain).all() and torch.equal(plain, skew)
 
 
 @pytest.mark.parametrize("cin,cout,split", [(32, 32, 0), (96, 96, 0), (128, 96, 96), (3, 32, 0), (64, 128, 0)])

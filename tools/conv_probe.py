@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--kernel", default="tile", choices=["tile", "dense", "dense1", "bf16"], help="kernel of the dense 128-column layers")
     ap.add_argument("--planes", type=int, default=1, help="--kernel bf16: bf16 pieces per operand (1 = rounded, 2 / 3 = split)")
     ap.add_argument("--centre-tail", action="store_true", help="k3 layers as centre pass + tail rows (ops.spconv_centre_tail)")
+    ap.add_argument("--replicas", type=int, default=1, help="stacked feature matrices per launch (the bench runs the CFG pair: 2)")
+    ap.add_argument("--flags", type=int, default=0, help="extra lidiff_spconv_fwd flag bits (8 = LIDIFF_CONV_SKEW)")
+    ap.add_argument("--cases", default="", help="several cases in ONE process (maps built once): 'level,cin,cout,kind,hint,flags;...' "
+                                                "(hint -1 = the manager's rule)")
     ap.add_argument("--timeline", action="store_true",
                     help="diagnostic build: per-workgroup cycle counters (prologue / main loop / epilogue / barrier / flush)")
     ap.add_argument("--probe", type=int, default=None,
@@ -54,6 +58,7 @@ def main():
     from lidiff_amd import ops
     import lidiff_amd.MinkowskiEngine as ME
     ops.DENSE_KERNEL = args.kernel if args.kernel != "bf16" else "tile"
+    ops.CONV_FLAGS = args.flags
     dev = torch.device("cuda:0")
     scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_fps18000.npy"))
     rng = np.random.default_rng(0)
@@ -80,7 +85,7 @@ def main():
         m_out = nbr.shape[1] if nbr is not None else m_in
         k = nbr.shape[0] if nbr is not None else 1
         pairs = int((nbr >= 0).sum()) if nbr is not None else m_in
-        x = torch.randn(m_in, cin, device=dev)
+        x = torch.randn(args.replicas * m_in, cin, device=dev)
         w = torch.randn(k, cin, cout, device=dev) * 0.05
         order = None
         if args.ordered and nbr is not None:
@@ -106,9 +111,9 @@ def main():
             tmap = ops.TailMap(nbr)
             conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out)
         elif args.kernel == "bf16" and ops.bf16_conv_applies(cin, 0, cout):
-            conv = lambda: ops.spconv_fwd_bf16(x, w, nbr, m_out, planes=args.planes)
+            conv = lambda: ops.spconv_fwd_bf16(x, w, nbr, m_out, planes=args.planes, replicas=args.replicas)
         else:
-            conv = lambda: ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
+            conv = lambda: ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order, replicas=args.replicas)
         for _ in range(3):
             conv()
         torch.cuda.synchronize()
@@ -119,15 +124,15 @@ def main():
         e.record()
         torch.cuda.synchronize()
         us = 1e3 * s.elapsed_time(e) / args.iters
-        tf = 2.0 * pairs * cin * cout / (us * 1e-6) / 1e12
+        tf = 2.0 * args.replicas * pairs * cin * cout / (us * 1e-6) / 1e12
         print(f"sigma={args.sigma} level={level} kind={kind} {cin}->{cout} m_in={m_in} m_out={m_out} pairs={pairs} "
-              f"nbrs/row={pairs / m_out:.2f} hint={int(hint)} avg_us={us:.1f} TFLOP/s={tf:.2f}", flush=True)
+              f"nbrs/row={pairs / m_out:.2f} hint={int(hint)} reps={args.replicas} flags={args.flags} avg_us={us:.1f} TFLOP/s={tf:.2f}", flush=True)
         if args.timeline:
             import ctypes
             from lidiff_amd import _lib
             tl = torch.zeros(1 << 15, 2, 10, dtype=torch.int64, device=dev)
             _lib.load().lidiff_debug_set_conv_timeline(ctypes.c_void_p(tl.data_ptr()))
-            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order)
+            ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order, replicas=args.replicas)
             torch.cuda.synchronize()
             _lib.load().lidiff_debug_set_conv_timeline(ctypes.c_void_p(0))
             raw = tl.cpu().numpy()
@@ -154,7 +159,13 @@ def main():
                       f"flush {q[:, 4].mean() / stages:.0f} + barrier {q[:, 3].mean() / stages:.0f} + rest "
                       f"{(q[:, 1] - q[:, 8] - q[:, 9] - q[:, 4] - q[:, 3]).mean() / stages:.0f}")
 
-    if args.sweep:
+    if args.cases:
+        for case in args.cases.split(";"):
+            lv, ci, co, kind, hint, flags = case.split(",")
+            args.sparse_hint, args.flags = int(hint), int(flags)
+            ops.CONV_FLAGS = args.flags
+            run(int(lv), int(ci), int(co), kind)
+    elif args.sweep:
         shapes = [(0, 32, 32), (1, 32, 32), (1, 32, 64), (2, 64, 64), (2, 64, 128), (3, 128, 128), (3, 128, 256),
                   (3, 256, 256), (3, 384, 256), (4, 256, 256), (2, 192, 128), (2, 128, 128), (1, 128, 96), (1, 96, 96),
                   (0, 128, 96), (0, 96, 96)]

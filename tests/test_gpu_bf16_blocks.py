@@ -4,17 +4,21 @@ train-mode BatchNorm) on the HIP bf16 kernels -- forward, input gradient and eve
 emulation of the same arithmetic (oracle/me_cpu.py: bf16_operands(): operands rounded to bf16, sums in float64), FROM
 IDENTICAL INPUTS per block, so the comparison is one block deep instead of 49 convolutions deep.
 
-Why not bit-tight, and what the bars mean.  Inside a block the second convolution rounds the first one's output to bf16.
-The two sides agree on that output to fp32 summation noise (~1e-6 relative), so an element that sits within 1e-6 of a bf16
-rounding boundary (probability ~1e-6 / 2^-8 = 3e-4 per element) rounds the other way on the two sides and enters the next sum
-with a 2^-8 relative difference.  A row of the next convolution sums 27 x C inputs, so a fair share of the output rows sees
-ONE such term: an error of ~2^-8 |x w| = 2^-8 / sqrt(27 C) of the row's scale -- 1e-4 .. 2e-4.  These tests therefore hold
-  * the FIRST convolution of every block (no rounding upstream) to the fp32 kernel's bar, 1e-4, on every element
-    (test_gpu_kernels.py pins each kernel alone the same way);
-  * the block output, dX and every dW to: >= 99 % of the elements within 1e-4 (rtol = atol), NO element beyond 4e-3 of the
-    tensor's scale (one flipped term), cosine >= 0.99999 (measured values: gpurun_out/parity_errors.jsonl ->
-    profiles/r03_parity_errors.txt).
-The same code path run twice on the CPU in float32 and float64 (tools/bf16_block_calibration.py) shows the same two regimes.
+Why a block cannot be held to the fp32 bar, and what the bars are.  Inside a block every convolution after the first
+rounds its input to bf16.  The two sides agree on that input to fp32 summation noise (~1e-6 relative), so an element within
+1e-6 of a bf16 rounding boundary (probability ~1e-6 / 2^-8 = 3e-4 per element) rounds the other way on the two sides and
+enters the next sum with a 2^-8 relative difference; a row of the next convolution sums 27 x C inputs (6 912 at C = 256), so
+most rows see one or two such terms: ~2^-8 / sqrt(27 C) of the row's scale, 0.5e-4 .. 2e-4 per layer, more through the
+ReLU masks and the BatchNorm statistics of the backward pass.  tools/bf16_block_calibration.py measures exactly this effect
+WITHOUT any device: the oracle's emulation run twice on the CPU, with float32 and with float64 sums
+(profiles/r03_bf16_block_calibration.txt) -- block output: 56 % (stage4) .. 99.6 % (stage1) of the elements within 1e-4, worst
+0.3e-3 .. 1.7e-3 of the tensor's scale, 1 - cosine <= 3e-7; dX: cosine 0.9997 .. 0.999996; parameter gradients: cosine >=
+0.9996.  These tests therefore hold
+  * the FIRST convolution of every block (no rounding upstream) to the fp32 kernel's bar, 1e-4, on every element;
+  * the block output to: no element beyond 5e-3 of the tensor's scale, 1 - cosine <= 1e-6;
+  * dX and every parameter gradient to cosine >= 0.999 and norm within 1 %
+(3x the CPU-vs-CPU spread; the measured device values go to gpurun_out/parity_errors.jsonl -> profiles/r03_parity_errors.txt).
+This is one block deep; the step-level test (49 convolutions deep) can only "track" the fp32 step for the same reason.
 """
 import numpy as np
 import pytest
@@ -80,9 +84,12 @@ def compare(tag, got, want):
     return {"what": tag, "within_1e-4": within, "worst_over_scale": d.max().item() / scale, "cosine": cos}
 
 
-def check(stats, block):
+def check(stats, block, out=False):
     record_parity("bf16_block", block=block, **stats)
-    assert stats["within_1e-4"] >= 0.99 and stats["worst_over_scale"] <= 4e-3 and stats["cosine"] >= 0.99999, (block, stats)
+    if out:
+        assert stats["worst_over_scale"] <= 5e-3 and stats["cosine"] >= 1.0 - 1e-6, (block, stats)
+    else:
+        assert stats["cosine"] >= 0.999, (block, stats)
 
 
 @pytest.fixture(scope="module")
@@ -147,7 +154,7 @@ def test_bf16_training_block_vs_oracle_emulation(device, maps, name, kind, level
     record_parity("bf16_block", block=name, **s)
     assert torch.allclose(first.cpu().double(), want_first, rtol=1e-4, atol=1e-4), (name, s)   # no rounding upstream: fp32 bar
     out_o, gx_o, gp_o = oracle_block(sd, kind, x_cpu, skip_cpu, x, skip, cot)
-    check(compare("block output", y.F.detach().cpu(), out_o), name)
+    check(compare("block output", y.F.detach().cpu(), out_o), name, out=True)
     check(compare("dX", xd.grad.cpu(), gx_o), name)
     worst = None
     n_params = 0
@@ -158,8 +165,7 @@ def test_bf16_training_block_vs_oracle_emulation(device, maps, name, kind, level
         n_params += 1
         if worst is None or st["cosine"] < worst["cosine"]:
             worst = st
-        # parameter gradients are sums over all rows: flipped terms average out -- cosine and norm are the bar
         nrel = abs(float(p.grad.norm()) - float(go.norm())) / (float(go.norm()) + 1e-30)
-        assert st["cosine"] >= 0.99999 and nrel <= 1e-3, (name, k, st, nrel)
+        assert st["cosine"] >= 0.999 and nrel <= 1e-2, (name, k, st, nrel)
     record_parity("bf16_block", block=name, n_params=n_params, **worst)
     print(f"bf16 block {name}: {n_params} parameter gradients, worst {worst}")

@@ -322,6 +322,8 @@ def main():
     ap.add_argument("--no-coords-roofline", action="store_true", help="skip the coordinate-pipeline (HBM-bound) roofline leg")
     ap.add_argument("--cached-condition", action="store_true",
                     help="also time the same steps with the step-invariant conditions encoded once (reported beside the metric)")
+    ap.add_argument("--layer-table", default="",
+                    help="write the per-layer table of the all-variants pass (ms per step, pairs, TFLOP/s per conv shape) to this file")
     ap.add_argument("--no-train", action="store_true",
                     help="skip the 'train' leg (configs[4]'s per-GPU training step, fp32 and bf16: 4 steps each)")
     ap.add_argument("--no-alt", action="store_true",
@@ -386,6 +388,13 @@ def main():
             run_steps(pipe, x_init, xs, tvals, 0, args.steps)
             torch.cuda.synchronize()
             ops.PROFILER = None
+            if args.layer_table:
+                with open(args.layer_table, "w") as f:
+                    f.write(f"# per conv shape over {args.steps} steps (all launches timed with HIP events): python bench.py --layer-table\n")
+                    for r in ops.layer_table(vprof, args.steps):
+                        f.write(f"{r['variant']:<6} k={r['k']:<2} {r['c_in']:>3}->{r['c_out']:<3} launches/step {r['launches_per_step']:5.1f}  "
+                                f"ms/step {r['ms_per_step']:6.3f}  avg {r['avg_us']:7.1f} us  rows {r['avg_rows']:9.0f}  pairs {r['avg_pairs']:10.0f}  "
+                                f"{r['tflops']:6.1f} TFLOP/s\n")
         # beside the metric, never `value`: the same K steps with the dense 128-column layers computed from two bf16 pieces
         # per operand (3 bf16 MFMAs per block, fp32 accumulation; ops.split_planes, lidiff_spconv_fwd_bf16 planes = 2)
         alt = None

@@ -126,6 +126,25 @@ class CoordinateManager:
             self.kmaps[key] = hit
         return hit, order
 
+    UP_ORDER_MIN_ROWS = 4096
+
+    def up_order(self, ts_in: int, ts_out: int):
+        """(neighbour table with its columns grouped by kernel offset, that row order) of the transposed kernel_size-2 /
+        stride-2 map ts_in -> ts_out, or None for small maps.  Every output row of such a map has exactly ONE pair (its
+        parent voxel, under the offset its position inside the parent cell selects), so in plain row order a 128-row tile
+        holds ~16 pairs of each of the 8 offsets: eight almost empty MFMA stages per channel slab.  Grouped by offset a
+        tile is 128 pairs of ONE offset -- a dense stage.  Results do not depend on the order (lidiff_spconv_fwd row_order)."""
+        key = ("up_order", ts_in, ts_out)
+        if key not in self.aux:
+            nbr = self.kernel_map(ts_in, ts_out, 2, True)
+            if nbr.shape[1] < self.UP_ORDER_MIN_ROWS:
+                self.aux[key] = None
+            else:
+                offset_of_row = (nbr >= 0).to(torch.uint8).argmax(0).to(torch.uint8)
+                order = torch.sort(offset_of_row, stable=True).indices
+                self.aux[key] = (nbr.index_select(1, order).contiguous(), order.to(torch.int32))
+        return self.aux[key]
+
     def is_sparse_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False) -> bool:
         """Performance hint for lidiff_spconv_fwd (LIDIFF_CONV_SPARSE_MAP), from voxel counts the host already
         holds (no device sync): does the kernel map bring only a few pairs per offset and 128-row tile?
@@ -141,7 +160,7 @@ class CoordinateManager:
         coarse = m(2 * ts_in)                         # measured on the 180k-point scan: pays for r >= ~0.85
         return coarse > 0 and coarse >= 0.85 * m(ts_in)   # (<= ~2 neighbours per voxel), not at r = 0.69 (4.3)
 
-    def prebuild(self, max_stride: int = 16, tail_maps: bool = True):
+    def prebuild(self, max_stride: int = 16, tail_maps: bool = True, up_orders: bool = False):
         """Every map the networks will ask for, built now (MinkGlobalEnc / MinkUNetDiff / MinkUNet: four stride-2 levels, a
         kernel_size-3 map per level, the kernel_size-2 maps down and back up, the tail maps of the low-density levels).
         The builders read map sizes back to the host; doing all of it in one place lets DiffCompletion run it on a side
@@ -154,6 +173,8 @@ class CoordinateManager:
             nxt = self.stride(ts, 2)
             self.kernel_map(ts, nxt, 2)
             self.kernel_map(nxt, ts, 2, True)
+            if up_orders:
+                self.up_order(nxt, ts)
             ts = nxt
         for ts in list(self.maps):                      # the sparse-map hint of a level needs the next level's size
             if tail_maps and self.maps[ts].coords.shape[0] >= 1024 and self.is_sparse_map(ts, ts, 3):

@@ -90,6 +90,10 @@ _ORDERED_TILES = False
 # the centre offset of a stride-1 map is the identity, the other offsets bring ~0.1-0.5 pairs per voxel
 _CENTRE_TAIL = True
 
+# transposed (kernel_size 2 / stride 2) convolutions with their output rows grouped by kernel offset (CoordinateManager.up_order):
+# 128 pairs of ONE offset per tile instead of ~16 of each of the eight
+_UP_ORDERED = os.environ.get("LIDIFF_UP_ORDERED", "1") != "0"
+
 
 def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=None) -> ME.SparseTensor:
     """relu?( bn(conv([x | extra])) + residual ) as ONE kernel launch (eval mode only)."""
@@ -101,6 +105,10 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
         nbr, order = mgr.kernel_map_ordered(x.tensor_stride, ts_out, conv.kernel_size, conv.transposed)
     scale, shift = _bn_affine(bn)
     hint = conv.sparse_hint(x, ts_out)
+    if conv.transposed and _UP_ORDERED and order is None:
+        hit = mgr.up_order(x.tensor_stride, ts_out)
+        if hit is not None:
+            (nbr, order), hint = hit, False
     if _CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and m_out >= 1024:
         f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
                                    residual=residual, relu=relu, replicas=x.replicas)

@@ -207,6 +207,36 @@ class ConvProfiler:
         return out
 
 
+def layer_table(prof: "ConvProfiler", steps: int = 1):
+    """Per-layer view of a profile in which every launch carried events: rows keyed by (variant, kernel volume, C_in, C_out,
+    M_out bucket), with launches per step, ms per step, pairs per launch and algorithmic TFLOP/s -- where a step's time goes."""
+    torch.cuda.synchronize()
+    counts, rows = {}, {}
+    for variant, start, end, m_in, m_out, c_in, c_out, k, nbr, reps in prof.launches:
+        if start is None:
+            continue
+        if nbr is None:
+            p = m_out
+        else:
+            key = nbr.data_ptr()
+            if key not in counts:
+                counts[key] = int((nbr >= 0).sum().item())
+            p = counts[key]
+        r = rows.setdefault((variant, k, c_in, c_out), {"launches": 0, "ms": 0.0, "flops": 0.0, "pairs": 0, "m_out": 0})
+        r["launches"] += 1
+        r["ms"] += start.elapsed_time(end)
+        r["flops"] += 2.0 * reps * p * c_in * c_out
+        r["pairs"] += reps * p
+        r["m_out"] += reps * m_out
+    out = []
+    for (variant, k, c_in, c_out), r in rows.items():
+        n = r["launches"]
+        out.append({"variant": variant, "k": k, "c_in": c_in, "c_out": c_out, "launches_per_step": n / steps,
+                    "ms_per_step": r["ms"] / steps, "avg_us": 1e3 * r["ms"] / n, "avg_pairs": r["pairs"] / n,
+                    "avg_rows": r["m_out"] / n, "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0})
+    return sorted(out, key=lambda d: -d["ms_per_step"])
+
+
 PROFILER: ConvProfiler | None = None
 # weight gradients: pair slices summed in slice order through a workspace (bit-reproducible); False = fp32 atomics
 DETERMINISTIC_DW = True

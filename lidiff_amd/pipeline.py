@@ -96,7 +96,7 @@ class DiffCompletion(nn.Module):
             self._side = torch.cuda.Stream(device=self.device)
         return torch.cuda.current_stream(self.device), self._side
 
-    def prepare(self, field, tail_maps=True, also=None):
+    def prepare(self, field, tail_maps=True, also=None, up_orders=False):
         """Voxelise `field` and build ALL its maps now -- on the side stream with overlap_maps, else on the current one
         (no-op if already done).  Building eagerly also gives every level its sparse-map hint: asked lazily, a level's hint
         needs the next coarser map, which the encoder half of a network has not built yet."""
@@ -106,7 +106,7 @@ class DiffCompletion(nn.Module):
         if not self.overlap_maps:                    # same work, same maps (and the same kernel choices), on this stream
             with torch.no_grad():
                 field._keep = field.sparse()
-                field.coordinate_manager.prebuild(tail_maps=tail_maps)
+                field.coordinate_manager.prebuild(tail_maps=tail_maps, up_orders=up_orders)
                 if also is not None:
                     also(field)
             return field
@@ -117,7 +117,7 @@ class DiffCompletion(nn.Module):
         side.wait_event(field.ready)
         with torch.cuda.stream(side), torch.no_grad():
             sp = field.sparse()
-            field.coordinate_manager.prebuild(tail_maps=tail_maps)
+            field.coordinate_manager.prebuild(tail_maps=tail_maps, up_orders=up_orders)
             if also is not None:
                 also(field)
             field.prepared = torch.cuda.Event()
@@ -266,7 +266,7 @@ class DiffCompletion(nn.Module):
                     parts = self.encode_conditions(x_cond, x_uncond)      # queued on the main stream ...
                 # ... x_t's maps meanwhile, on the side stream -- and the part -> full matches of every level, which need
                 # only coordinates (the condition's coarsest map and x_t's maps), not the encoders' features
-                self.prepare(x_t, also=lambda f: self._match_levels(f, parts))
+                self.prepare(x_t, also=lambda f: self._match_levels(f, parts), up_orders=minknet._UP_ORDERED)
                 x_t_sparse = self._adopt(x_t).sparse()
                 e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t)
                 e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)

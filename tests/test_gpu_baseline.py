@@ -6,7 +6,7 @@ only through size-independent properties:
       parents, ks3 / ks2 / transposed neighbour tables and the ME-layout rulebook -- BIT-EXACT;
   (b) one sparse convolution per (level x channel pair) the networks really run on those maps, with the sparse-map
       hint the host really passes (the packed-stage / KS = 64 / 16-bit-list kernel variants that the real sparsity
-      selects), against the oracle in float64 -- rtol / atol 1e-4;
+      selects), against the oracle in float64 -- rtol / atol LAYER_TOL = 2e-5 (5x the worst measured);
   (c) BASELINE configs[0] (C1): ONE classifier-free-guided denoising step (timesteps = [999]) on the 180 000-point
       scan against oracle/minkunet_cpu.py, and the same at three later positions of the T = 50 trajectory (t = 300 / 100 /
       20) -- every point within test_gpu_network.NET_RTOL / NET_ATOL (<= 10x the errors measured on the MI355X,
@@ -30,6 +30,9 @@ from test_gpu_network import NET_ATOL, NET_RTOL, X_ATOL, to_field
 pytestmark = pytest.mark.gpu
 
 RES = 0.05
+# one convolution on the bench maps vs the float64 oracle, rtol = atol: measured worst over the 56 cases 4.7e-6 on outputs of
+# scale 12, i.e. 0.04 of the per-kernel bar 1e-4 that tests/test_gpu_kernels.py uses (profiles/r03_parity_errors.txt)
+LAYER_TOL = 2e-5
 
 
 def scan_coords(fps_scan, sigma, seed=0):
@@ -133,10 +136,10 @@ def _layer_case(device, scene, level, kind, cin, cout, split, replicas=1):
         want = torch.relu(want * scale.double() + shift.double() + res[r * m_out:(r + 1) * m_out].double())
         d = (got[r * m_out:(r + 1) * m_out] - want).abs()
         err = d.max().item()
-        frac = (d / (1e-4 + 1e-4 * want.abs())).max().item()
+        frac = (d / (LAYER_TOL + LAYER_TOL * want.abs())).max().item()
         record_parity("conv_layer_on_bench_maps", sigma=scene.sigma, level=level, kind=kind, c_in=cin, c_out=cout, hint=int(hint),
                       replica=r, max_abs_err=err, max_abs_out=want.abs().max().item(), worst_tolerance_fraction=frac)
-        assert torch.allclose(got[r * m_out:(r + 1) * m_out], want, rtol=1e-4, atol=1e-4), \
+        assert torch.allclose(got[r * m_out:(r + 1) * m_out], want, rtol=LAYER_TOL, atol=LAYER_TOL), \
             f"level {level} {kind} {cin}->{cout} hint={hint} replica {r}: max err {err}"
     return hint
 

@@ -1,8 +1,8 @@
 """GPU parity tests at the ME-API / network / sampling-loop level (pytest -m gpu).
 
-Tolerances: a single conv is within rtol/atol 1e-4 of the oracle; through the 49-conv UNet the
-fp32 sum-order differences compound, so network outputs are compared at rtol 1e-3 / atol 2e-3
-(outputs are O(0.1-1)); fused vs unfused execution of the SAME device kernels at 1e-3.
+Tolerances: a single conv is within rtol/atol 1e-4 of the oracle (measured worst on the bench maps: 4.7e-6 on outputs of
+scale 12); whole-network outputs (49 convs deep, O(0.1-1)) are compared at NET_RTOL / NET_ATOL below, which are <= 10x the
+errors measured on the device; every test records what it achieved (conftest.record_parity).
 """
 import os
 
@@ -10,15 +10,18 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, build_seeded_models, diffusion_state_dict, noisy_scan_points, small_scene
+from conftest import GOLDEN, build_seeded_models, diffusion_state_dict, noisy_scan_points, record_parity, small_scene
 from oracle import me_cpu as me
 from oracle import minkunet_cpu as net
 from oracle.dpm_solver import DpmSolverSdeOracle
 
 pytestmark = pytest.mark.gpu
 
-NET_RTOL, NET_ATOL = 1e-3, 2e-3
-X_ATOL = 5e-3        # metres: points after one teacher-forced DPM-Solver++ update
+# Whole-network tolerances, set from the errors MEASURED on the MI355X (profiles/r03_parity_errors.txt): one CFG step on the
+# 180 000-point scan has max |eps error| 3.4e-7 .. 6.3e-7 at the four trajectory positions (|eps| up to 0.17 .. 0.29) and the
+# teacher-forced T = 50 loop 3.3e-7 in eps / 7.9e-6 m in the points -- the bars are <= 10x those (round 2 ran with 1e-3 / 2e-3).
+NET_RTOL, NET_ATOL = 1e-5, 3e-6
+X_ATOL = 8e-5        # metres: points after one teacher-forced DPM-Solver++ update
 
 
 @pytest.fixture(scope="module")
@@ -114,6 +117,7 @@ def test_golden_unet_cfg(device, models):
     for fused in (False, True):
         got = run_cfg(models, device, g["scan"], g["noisy"], fused).cpu()
         err = (got - want).abs().max().item()
+        record_parity("golden_unet_cfg", fused=int(fused), max_abs_err=err, max_abs=want.abs().max().item())
         assert torch.allclose(got, want, rtol=NET_RTOL, atol=NET_ATOL), f"fused={fused}: max err {err}"
 
 
@@ -125,6 +129,7 @@ def test_golden_refine_unet(device, models):
         with torch.no_grad(), product.fusion(fused):
             got = refine(to_field(g["noisy"], device)).cpu()
         assert got.shape == (2000, 18)
+        record_parity("golden_refine_unet", fused=int(fused), max_abs_err=(got - torch.from_numpy(g["refine"])).abs().max().item())
         assert torch.allclose(got, torch.from_numpy(g["refine"]), rtol=NET_RTOL, atol=NET_ATOL), f"fused={fused}"
 
 
@@ -145,6 +150,7 @@ def test_unet_batch2_vs_oracle(device, models):
             oxf = net.points_to_field(torch.from_numpy(noisy), divide_batch_col=False)
             ocf = net.points_to_field(torch.from_numpy(scan), divide_batch_col=False)
             want = net.denoise_forward(sd, oxf, oxf.sparse(), ocf, t).reshape(-1, 3)
+            record_parity("unet_batch2", fused=int(fused), max_abs_err=(got - want).abs().max().item(), max_abs=want.abs().max().item())
             assert torch.allclose(got, want, rtol=NET_RTOL, atol=NET_ATOL), f"fused={fused}"
 
 
@@ -155,6 +161,7 @@ def test_fused_equals_unfused_realistic_sparsity(device, models, fps_scan):
     scan = np.tile(fps_scan[:3600], (10, 1))
     a = run_cfg(models, device, scan, noisy, fused=True)
     b = run_cfg(models, device, scan, noisy, fused=False)
+    record_parity("fused_vs_unfused_36k", max_abs_diff=(a - b).abs().max().item(), max_abs=b.abs().max().item())
     assert torch.allclose(a, b, rtol=NET_RTOL, atol=NET_ATOL), (a - b).abs().max().item()
 
 
@@ -216,6 +223,8 @@ def test_completion_loop_vs_oracle(device, models):
     # differently on the two sides (and GPU/CPU round(x/0.05) disagree for ~5 ppm of inputs), which
     # legitimately changes that point's trajectory; require 98 % of the points within tolerance.
     err = np.abs(out - want).max(axis=1)
+    record_parity("closed_loop_T3_1500pts", share_above_5mm=float(np.mean(err > 5e-3)), share_above_0p1mm=float(np.mean(err > 1e-4)),
+                  median_err_m=float(np.median(err)), max_err_m=float(err.max()))
     assert np.mean(err > 5e-3) < 0.02 and np.median(err) < 1e-3, (np.mean(err > 5e-3), np.median(err), err.max())
     # encoding the step-invariant conditions once per scan changes nothing, bit for bit
     pipe.cache_condition = True

@@ -318,5 +318,5 @@ def test_reference_networks_over_hip_shim_equal_fused_product(device):
         want = unet(xf, xf.sparse(), enc(cf), t)
         xr, cr = to_field(noisy, device), to_field(scan, device)
         got = r_unet(xr, xr.sparse(), r_enc(cr), t)
-        assert torch.allclose(got, want, rtol=1e-3, atol=2e-3), (got - want).abs().max()
-        assert torch.allclose(r_ref(to_field(noisy, device)), refine(to_field(noisy, device)), rtol=1e-3, atol=2e-3)
+        assert torch.allclose(got, want, rtol=1e-5, atol=3e-6), (got - want).abs().max()
+        assert torch.allclose(r_ref(to_field(noisy, device)), refine(to_field(noisy, device)), rtol=1e-5, atol=3e-6)

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--kernel", default="tile", choices=["tile", "dense", "dense1", "bf16"], help="kernel of the dense 128-column layers")
     ap.add_argument("--planes", type=int, default=1, help="--kernel bf16: bf16 pieces per operand (1 = rounded, 2 / 3 = split)")
     ap.add_argument("--centre-tail", action="store_true", help="k3 layers as centre pass + tail rows (ops.spconv_centre_tail)")
+    ap.add_argument("--up-ordered", action="store_true", help="'up' layers with their output rows grouped by offset (CoordinateManager.up_order)")
     ap.add_argument("--replicas", type=int, default=1, help="stacked feature matrices per launch (the bench runs the CFG pair: 2)")
     ap.add_argument("--flags", type=int, default=0, help="extra lidiff_spconv_fwd flag bits (8 = LIDIFF_CONV_SKEW)")
     ap.add_argument("--cases", default="", help="several cases in ONE process (maps built once): 'level,cin,cout,kind,hint,flags;...' "
@@ -49,10 +50,10 @@ def main():
         csrc = os.path.join(ROOT, "lidiff_amd", "csrc")
         lib = os.path.join(csrc, "liblidiff_amd_probe.so")
         if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(csrc, f)) for f in
-                                                                 ("spconv.hip", "spconv_dense.hip", "spconv.h")):
+                                                                 ("spconv.hip", "spconv_dense.hip", "spconv_bf16.hip", "coords.hip", "spconv.h")):
             subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-DLIDIFF_CONV_PROBE",
                             "-shared", os.path.join(csrc, "spconv.hip"), os.path.join(csrc, "spconv_dense.hip"),
-                            os.path.join(csrc, "coords.hip"), "-o", lib], check=True)
+                            os.path.join(csrc, "spconv_bf16.hip"), os.path.join(csrc, "coords.hip"), "-o", lib], check=True)
         _lib.LIB_PATH = lib
         _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))
     from lidiff_amd import ops
@@ -107,6 +108,8 @@ def main():
                 "up": mgr.is_sparse_map(ts * 2, ts, 2, True), "k1": False}[kind]
         if args.sparse_hint >= 0:
             hint = bool(args.sparse_hint)
+        if args.up_ordered and kind == "up":
+            (nbr, order), hint = mgr.up_order(ts * 2, ts), False
         if args.centre_tail and kind == "k3":
             tmap = ops.TailMap(nbr)
             conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out)

@@ -35,7 +35,6 @@ extern "C" {
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
 #define LIDIFF_CONV_DENSE_KERNEL 2  /* lidiff_spconv_fwd flags: software-pipelined kernel for the dense 128-column layers */
 #define LIDIFF_CONV_DENSE_ONE_WAVE 4 /* ... in its four-wave form (one wave per SIMD, 32 columns per wave) */
-#define LIDIFF_CONV_SKEW 8          /* tile kernel, dense 128-column layers: the wave halves of a SIMD run load / multiply phases in opposite order */
 
 int lidiff_abi_version(void);
 const char* lidiff_last_error(void);

@@ -140,9 +140,10 @@ class CoordinateManager:
             if nbr.shape[1] < self.UP_ORDER_MIN_ROWS:
                 self.aux[key] = None
             else:
-                offset_of_row = (nbr >= 0).to(torch.uint8).argmax(0).to(torch.uint8)
-                order = torch.sort(offset_of_row, stable=True).indices
-                self.aux[key] = (nbr.index_select(1, order).contiguous(), order.to(torch.int32))
+                # the ME-layout rulebook of the map lists its pairs by offset, then by output row: its output-row column IS the
+                # order (one pair per row => a permutation), built by three small kernels without a host read
+                _, order, _ = ops.rulebook_compact(nbr, total=nbr.shape[1])
+                self.aux[key] = (nbr.index_select(1, order.long()).contiguous(), order)
         return self.aux[key]
 
     def is_sparse_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False) -> bool:

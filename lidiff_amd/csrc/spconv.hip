@@ -67,13 +67,7 @@ struct ConvCfg {
     }
 };
 
-// SKEW: the two waves that share a SIMD (waves w and w + NW/2) take the stage's two phases in opposite order.  Left alone
-// they run in lockstep -- both issue the next stage's loads (8 vector-memory instructions, ~100 cycles each while MFMAs are
-// queued) and only then start multiplying, so the SIMD's matrix pipe idles for the whole issue phase of every stage
-// (profiles/r02_dense_kernel_probe.txt: issue 879 + mma 1828 | issue 2228 + mma 2708 of a 6115-cycle stage).  With SKEW
-// the second-dispatched half multiplies first and issues its loads behind its first SKEW_AT 16-channel MFMA groups, i.e.
-// while its partner -- done with its own loads by then -- feeds the pipe.
-template <int BM, int WN, int WM, int KS, bool VEC, bool SKEW = false>
+template <int BM, int WN, int WM, int KS, bool VEC>
 __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p_launch) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
     ConvParams p = p_launch;                     // per-replica view (pointers moved below)
@@ -136,7 +130,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #endif
 
     // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
-    for (int e = tid; e < BM * BN / 4; e += NT)
+    for (int e = tid; e < (BM + 1) * BN / 4; e += NT)     // the tile and the dummy row behind it
         reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = tid; r < rows_here; r += NT) orow[r] = p.row_order ? p.row_order[row0 + r] : (int32_t)(row0 + r);
     if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
@@ -310,7 +304,6 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #pragma unroll
     for (int j = 0; j < NJ; ++j) foff[j] = li * KS + 4 * ((4 * j + lq) ^ swz(li));
 
-    const bool late = SKEW && wave >= NW / 2;             // wave-uniform: this wave multiplies first, loads second
     constexpr int IMG = AF * 4;                           // bytes per A image
     int img = 0;                                          // byte offset of the image being multiplied
     f32x4 wc[NJ], wnx[NJ];                                // W fragments: current stage / next stage
@@ -321,7 +314,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     // dependent MFMAs are NB x 32 cycles apart.  The accumulators live only inside the item: after its
     // last slab they are added into the LDS tile through the pair list's local output row -- batched
     // and branch-free: NB list words, then 4 NB tile reads, then 4 NB writes (3 LDS round trips); rows
-    // beyond n go to a per-lane dummy word.
+    // beyond n go to the dummy row behind the tile.
     auto run_item = [&](auto nb_tag, const Item& item, const Item& next, bool has_next) {
         constexpr int NB = decltype(nb_tag)::value;
         f32x4 acc[NB > 0 ? NB : 1];
@@ -361,7 +354,6 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
             }
         };
         auto mma = [&]() { mma_part(ic<0>{}, ic<NJ>{}); };
-        constexpr int SKEW_AT = NJ / 2;                   // MFMA groups the late half runs before it issues its loads
         auto stage_end = [&]() {
 #ifdef LIDIFF_CONV_PROBE
             STAMP(tb0);
@@ -381,47 +373,30 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #define PHASE(acc, from)
 #endif
         for (int s = 0; s + 1 < nslab; ++s) {             // not the last slab: the next stage is the same item
-            if (!late) {
-                issue(img ^ IMG, item.k, s + 1, item.n, wnx);
-                PHASE(t_issue, tp);
-                mma();
-                PHASE(t_mma, tp);
-            } else {
-                mma_part(ic<0>{}, ic<SKEW_AT>{});
-                PHASE(t_mma, tp);
-                issue(img ^ IMG, item.k, s + 1, item.n, wnx);
-                PHASE(t_issue, tp);
-                mma_part(ic<SKEW_AT>{}, ic<NJ>{});
-                PHASE(t_mma, tp);
-            }
+            issue(img ^ IMG, item.k, s + 1, item.n, wnx);
+            PHASE(t_issue, tp);
+            mma();
+            PHASE(t_mma, tp);
             stage_end();
 #ifdef LIDIFF_CONV_PROBE
             tp = __builtin_readcyclecounter();
 #endif
         }
-        if (!late) {
-            if (has_next) {                               // last slab: the next stage opens the next item
-                load_rows(next);
-                issue(img ^ IMG, next.k, 0, next.n, wnx);
-            }
-            PHASE(t_issue, tp);
-            mma();
-            PHASE(t_mma, tp);
-        } else {
-            mma_part(ic<0>{}, ic<SKEW_AT>{});
-            PHASE(t_mma, tp);
-            if (has_next) {
-                load_rows(next);
-                issue(img ^ IMG, next.k, 0, next.n, wnx);
-            }
-            PHASE(t_issue, tp);
-            mma_part(ic<SKEW_AT>{}, ic<NJ>{});
-            PHASE(t_mma, tp);
+        if (has_next) {                                   // last slab: the next stage opens the next item
+            load_rows(next);
+            issue(img ^ IMG, next.k, 0, next.n, wnx);
         }
+        PHASE(t_issue, tp);
+        mma();
+        PHASE(t_mma, tp);
         STAMP(tf0);
         if constexpr (NB > 0) {
             if (!PROBE(16)) {
-                // per element: its list word (one b128 read per block), one address add, read, add, write
+                // per element: its list word (one b128 read per block), one address add, read, add, write.
+                // (Round 3 tried the add inside the MFMA instead -- accumulators initialised from the tile rows, written back
+                // after the last slab, no VALU arithmetic: +2 % on 256 -> 256, +4.6 % on 128 -> 128 at stride 8, but one
+                // 27 x C_in-term fp32 chain per output instead of 27 short ones: 10x the rounding error against the float64
+                // oracle, 5.1e-5 vs 4.7e-6 on the 384 -> 256 layer -- not kept; profiles/r03_dense_ablation.txt.)
                 const OutT* ol = out_list + item.k * BM + item.start + 4 * lq;
                 const int colb = (16 * wn + li) * 4;
                 char* accb = reinterpret_cast<char*>(acc_lds);
@@ -674,12 +649,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int k_vol, int 
     wp[idx] = kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f;
 }
 
-template <int BM, int WN, int WM, int KS, bool VEC, bool SKEW = false>
+template <int BM, int WN, int WM, int KS, bool VEC>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
     const size_t lds = Cfg::lds_bytes(p.k_vol);
     LIDIFF_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded");
-    auto kern = spconv_fwd_kernel<BM, WN, WM, KS, VEC, SKEW>;
+    auto kern = spconv_fwd_kernel<BM, WN, WM, KS, VEC>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -700,11 +675,8 @@ static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
     if (!vec) return launch_fwd<BM, WN, WM, 32, false>(p, st);
     // 64-channel stages halve the per-stage costs of dense maps; low-density maps (hint from the caller)
     // take the 32-channel kernel, whose tiles can pack several offsets into one stage
-    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0 && !(p.flags & LIDIFF_CONV_SPARSE_MAP)) {
-        if constexpr (WM == 1 && WN == 8)               // the dense 128-column layers: skewed wave halves on request
-            if (p.flags & LIDIFF_CONV_SKEW) return launch_fwd<BM, WN, WM, 64, true, true>(p, st);
+    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0 && !(p.flags & LIDIFF_CONV_SPARSE_MAP))
         return launch_fwd<BM, WN, WM, 64, true>(p, st);
-    }
     return launch_fwd<BM, WN, WM, 32, true>(p, st);
 }
 

@@ -145,15 +145,18 @@ def tile_order(coords: torch.Tensor, ts: int) -> torch.Tensor:
     return torch.argsort(keys).to(torch.int32)
 
 
-def rulebook_compact(nbr: torch.Tensor):
-    """ME-layout rulebook from a neighbour table: (pairs_in, pairs_out, offset_ptr[K+1])."""
+def rulebook_compact(nbr: torch.Tensor, total: int | None = None):
+    """ME-layout rulebook from a neighbour table: (pairs_in, pairs_out, offset_ptr[K+1]) -- pairs sorted by kernel offset,
+    then by output row.  total: the number of pairs when the caller knows it (e.g. a transposed kernel_size-2 / stride-2 map
+    has exactly one pair per output row) -- one pass, no host read; otherwise a counting pass, one read of the total, a fill pass."""
     require_device(nbr)
     k, m = nbr.shape
     dev = nbr.device
     ws = torch.empty(_lib.load().lidiff_rulebook_workspace_bytes(k, m), dtype=torch.uint8, device=dev)
     off = torch.empty(k + 1, dtype=torch.int32, device=dev)
-    call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), None, None, ptr(ws), stream_ptr())
-    total = int(off[-1].item())
+    if total is None:
+        call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), None, None, ptr(ws), stream_ptr())
+        total = int(off[-1].item())
     pin = torch.empty(total, dtype=torch.int32, device=dev)
     pout = torch.empty(total, dtype=torch.int32, device=dev)
     call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), ptr(pin), ptr(pout), ptr(ws), stream_ptr())

@@ -556,43 +556,6 @@ def test_spconv_dense_kernel_is_bit_identical_to_the_tile_kernel(device, kernel)
             assert torch.allclose(got[:m].cpu().double(), want, rtol=RTOL, atol=ATOL), (kind, cin, split, cout)
 
 
-@pytest.mark.parametrize("cin,cout,split,replicas", [(256, 256, 0, 1), (384, 256, 256, 2), (128, 128, 0, 2), (64, 128, 0, 1)])
-def test_spconv_skewed_wave_halves_are_bit_identical(device, fps_scan, cin, cout, split, replicas):
-    """LIDIFF_CONV_SKEW (the two waves of a SIMD take a stage's load / multiply phases in opposite order): scheduling only --
-    every accumulator sees the same products in the same order, so the output equals the plain tile kernel's bit for bit, on
-    a dense map of the bench scan (stride 8), with epilogue, split input and replicas."""
-    from lidiff_amd import ops
-    import lidiff_amd.MinkowskiEngine as ME
-    pts = noisy_scan_points(fps_scan, 0.5, 1, n_rep=4)
-    feats = torch.from_numpy(pts).to(device)
-    coord = torch.cat([torch.zeros(pts.shape[0], 1, device=device), torch.round(feats / 0.05)], 1)
-    field = ME.TensorField(features=feats, coordinates=coord, device=device)
-    field.sparse()
-    mgr = field.coordinate_manager
-    ts = 1
-    for _ in range(3):
-        ts = mgr.stride(ts, 2)
-    nbr = mgr.kernel_map(8, 8, 3)
-    m = nbr.shape[1]
-    g = torch.Generator().manual_seed(cin + cout)
-    x = torch.randn(replicas * m, cin, generator=g).to(device)
-    w = (torch.randn(27, cin, cout, generator=g) / np.sqrt(9 * cin)).to(device)
-    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(device), torch.randn(cout, generator=g).to(device)
-    res = torch.randn(replicas * m, cout, generator=g).to(device)
-    kw = dict(in_b=x[:, split:].contiguous() if split else None, scale=scale, shift=shift, residual=res, relu=True,
-              replicas=replicas)
-    xa = x[:, :split].contiguous() if split else x
-    prev = ops.CONV_FLAGS
-    try:
-        ops.CONV_FLAGS = 0
-        plain = ops.spconv_fwd(xa, w, nbr, m, **kw)
-        ops.CONV_FLAGS = 8
-        skew = ops.spconv_fwd(xa, w, nbr, m, **kw)
-    finally:
-        ops.CONV_FLAGS = prev
-    assert torch.isfinite(plain).all() and torch.equal(plain, skew)
-
-
 @pytest.mark.parametrize("cin,cout,split", [(32, 32, 0), (96, 96, 0), (128, 96, 96), (3, 32, 0), (64, 128, 0)])
 def test_spconv_centre_tail_vs_oracle(device, cin, cout, split):
     """Low-density kernel_size-3 maps as centre pass + tail rows (ops.TailMap / spconv_centre_tail): the pairs of the 26

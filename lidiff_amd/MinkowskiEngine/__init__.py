@@ -146,11 +146,16 @@ class CoordinateManager:
                 self.aux[key] = (nbr.index_select(1, order.long()).contiguous(), order)
         return self.aux[key]
 
-    def is_sparse_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False) -> bool:
+    def is_sparse_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False, c_out: int = 128) -> bool:
         """Performance hint for lidiff_spconv_fwd (LIDIFF_CONV_SPARSE_MAP), from voxel counts the host already
         holds (no device sync): does the kernel map bring only a few pairs per offset and 128-row tile?
         r = M(2 ts) / M(ts) close to 1 means the voxels of stride ts are isolated (each coarse voxel holds ~1 of
-        them), i.e. few neighbours.  Results do not depend on the hint."""
+        them), i.e. few neighbours.  Results do not depend on the hint.
+        The hint selects the kernel family whose tiles can pack several offsets into one stage.  Measured on the 180k-point
+        scan (profiles/r03_hint_sweep.txt): for the 128-column tiles it pays up to ~2 neighbours per voxel (r >= 0.85); the
+        narrow tiles (C_out 96 / 64: 3 x 2 and 4 x 2 wave grids, eight offsets per stage) win up to ~7 neighbours per voxel --
+        +38 % on 64 -> 64 at stride 4 (4.3 neighbours, r = 0.69), +36 % on 96 -> 96 at stride 2 with 3.6 (r = 0.73), equal at
+        11 (r = 0.38) -- so they take it for r >= 0.5."""
         m = lambda ts: self.maps[ts].coords.shape[0] if ts in self.maps else 0
         if ks == 1:
             return False
@@ -158,8 +163,8 @@ class CoordinateManager:
             if transposed:
                 return True
             return m(ts_out) >= 0.67 * max(1, m(ts_in))
-        coarse = m(2 * ts_in)                         # measured on the 180k-point scan: pays for r >= ~0.85
-        return coarse > 0 and coarse >= 0.85 * m(ts_in)   # (<= ~2 neighbours per voxel), not at r = 0.69 (4.3)
+        coarse = m(2 * ts_in)
+        return coarse > 0 and coarse >= (0.85 if c_out % 128 == 0 else 0.5) * m(ts_in)
 
     def prebuild(self, max_stride: int = 16, tail_maps: bool = True, up_orders: bool = False):
         """Every map the networks will ask for, built now (MinkGlobalEnc / MinkUNetDiff / MinkUNet: four stride-2 levels, a
@@ -455,7 +460,8 @@ class _ConvBase(nn.Module):
                 mgr.kernel_map(ts_out, ts, self.kernel_size, True), ts_out, False)
 
     def sparse_hint(self, x: SparseTensor, ts_out: int) -> bool:
-        return x.coordinate_manager.is_sparse_map(x.tensor_stride, ts_out, self.kernel_size, self.transposed)
+        return x.coordinate_manager.is_sparse_map(x.tensor_stride, ts_out, self.kernel_size, self.transposed,
+                                                  self.out_channels)
 
     def forward(self, x: SparseTensor) -> SparseTensor:
         nbr, nbr_sw, ts_out, flip = self.maps(x)

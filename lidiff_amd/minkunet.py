@@ -109,7 +109,10 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
         hit = mgr.up_order(x.tensor_stride, ts_out)
         if hit is not None:
             (nbr, order), hint = hit, False
-    if _CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and m_out >= 1024:
+    # centre + tail only on really isolated voxels (<= ~2 neighbours each: the 128-column rule of is_sparse_map); the wider
+    # hint of the narrow tiles keeps the one-launch kernel with packed stages (3.6 neighbours per voxel: 429 vs 495 us)
+    if (_CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and m_out >= 1024
+            and mgr.is_sparse_map(ts_out, ts_out, 3)):
         f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
                                    residual=residual, relu=relu, replicas=x.replicas)
     else:
@@ -325,8 +328,17 @@ class MinkUNetDiff(_Base):
     def get_timestep_embedding(self, timesteps):
         assert timesteps.dim() == 1
         half = self.embed_dim // 2
-        freq = np.exp(np.arange(0, half) * -(np.log(10000) / (half - 1)))
-        freq = torch.from_numpy(freq).float().to(timesteps.device)
+        # the frequency table is a constant: kept on the device (a per-forward host -> device copy of it is a synchronous
+        # pageable transfer -- the host then waits for the stream to drain before it can queue the network's launches:
+        # ~0.5 ms of idle GPU per denoising step, profiles/r03_idle_gaps.txt)
+        key = (str(timesteps.device), half)
+        freq = self._freq_cache.get(key) if hasattr(self, "_freq_cache") else None
+        if freq is None:
+            f = np.exp(np.arange(0, half) * -(np.log(10000) / (half - 1)))
+            freq = torch.from_numpy(f).float().to(timesteps.device)
+            if not hasattr(self, "_freq_cache"):
+                self._freq_cache = {}
+            self._freq_cache[key] = freq
         emb = timesteps[:, None] * freq[None, :]
         emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
         if self.embed_dim % 2 == 1:
@@ -380,6 +392,30 @@ class MinkUNetDiff(_Base):
         w_t, w_p = (lin1.weight[:, :c], lin1.weight[:, c:]) if t_first else (lin1.weight[:, c:], lin1.weight[:, :c])
         return lat @ w_p.t(), TF.linear(temp(temp_emb), w_t, lin1.bias)
 
+    def _condition_table(self, name, parts, temp_emb):
+        """w = latemp(cat(latent(part.F), temp)) evaluated on the PART rows of all replicas (one batch; see _condition)."""
+        feats = parts[0].F if len(parts) == 1 else torch.cat([q.F for q in parts], dim=0)
+        h_p, h_t = self._condition_terms(name, feats, temp_emb)
+        return getattr(self, f"latemp_{name}")[2](TF.leaky_relu(h_p + h_t, 0.1))                  # [sum M_p, C]
+
+    _tables = None
+
+    def precompute_conditioning(self, part_feats, t):
+        """The eight conditioning tables of a forward (fused plan, one batch) from the part latents and the timestep alone --
+        ~50 small launches that need nothing of x.  DiffCompletion queues them right behind the condition encoders, BEFORE
+        the host blocks on the map sizes of x_t: queued inside forward() they come when the host has no lead over the GPU
+        and the device idles ~1 ms per step waiting for launches (profiles/r03_idle_gaps.txt).  Returns a dict for
+        forward(..., cond=...); None when the plan does not apply."""
+        parts = part_feats if isinstance(part_feats, (tuple, list)) else (part_feats,)
+        if not _fusable(self) or t.shape[0] != 1:
+            return None
+        temp_emb = self.get_timestep_embedding(t)
+        out = {"temp_emb": temp_emb, "parts": tuple(parts)}
+        for name in _LEVELS:
+            if getattr(self, f"latemp_{name}")[2].out_features % 4 == 0:
+                out[name] = self._condition_table(name, parts, temp_emb)
+        return out
+
     def _condition_hidden(self, name, x, part, temp_emb, out=None):
         """leaky(lin1(cat(latent(match), temp))) for the rows of x's coordinate map: gather + time bias + activation
         are one kernel."""
@@ -410,9 +446,9 @@ class MinkUNetDiff(_Base):
                 # Linear are row-wise too and the WHOLE MLP commutes with the gather -- w = table[idx] with the
                 # table evaluated on the part rows (one row for the single-voxel unconditional branch: broadcast)
                 # (the part rows of all replicas go through the small MLPs together: one launch per Linear)
-                feats = parts[0].F if len(parts) == 1 else torch.cat([q.F for q in parts], dim=0)
-                h_p, h_t = self._condition_terms(name, feats, temp_emb)
-                tables = lin2(TF.leaky_relu(h_p + h_t, 0.1))                        # [sum M_p, C]
+                tables = None if self._tables is None else self._tables.get(name)
+                if tables is None:
+                    tables = self._condition_table(name, parts, temp_emb)
                 lo = 0
                 for r, q in enumerate(parts):
                     table = tables[lo:lo + q.F.shape[0]]
@@ -450,15 +486,25 @@ class MinkUNetDiff(_Base):
         return x * _run_mlp(latemp, torch.cat((t, p) if t_first else (p, t), -1))
 
     # -- minkunet.py:420-497 --------------------------------------------------------------
-    def forward(self, x, x_sparse, part_feats, t):
+    def forward(self, x, x_sparse, part_feats, t, cond=None):
         """part_feats: the partial-scan latent, or (fused plan only) a tuple of R of them -- then the R conditioned
         forwards over the same x run as ONE stacked pass (same maps, same weights; every conv one launch with R
         replicas) and the result is a tuple of R per-point outputs.  That is the classifier-free-guidance pair of
-        pipeline:148-153 / models.py:98-103 without running the network twice."""
+        pipeline:148-153 / models.py:98-103 without running the network twice.
+        cond: precompute_conditioning(part_feats, t) of exactly these latents and timestep (optional, same results)."""
         multi = isinstance(part_feats, (tuple, list))
         if multi and not _fusable(self):
             return tuple(self.forward(x, x_sparse, q, t) for q in part_feats)
-        temp_emb = self.get_timestep_embedding(t)
+        parts_now = tuple(part_feats) if multi else (part_feats,)
+        use = cond is not None and _fusable(self) and len(cond["parts"]) == len(parts_now) and \
+            all(a is b for a, b in zip(cond["parts"], parts_now))
+        self._tables = cond if use else None
+        try:
+            return self._forward(x, x_sparse, part_feats, t, multi, cond["temp_emb"] if use else self.get_timestep_embedding(t))
+        finally:
+            self._tables = None
+
+    def _forward(self, x, x_sparse, part_feats, t, multi, temp_emb):
         f0 = _run_stem(self.stem, x_sparse)                      # the stem sees no conditioning: shared
         feats = [f0.replicate(len(part_feats)) if multi else f0]
         for name in _LEVELS[:4]:

@@ -701,6 +701,8 @@ class TailMap:
                  ptr(ws), stream_ptr())
 
 
+# (The centre pass keeps the narrow 3 x 2 / 4 x 2 wave grids of the hinted maps: the 96-column tile of the dense family, which
+# would read every input row once instead of twice, measured 8 % slower -- profiles/r03_hint_sweep.txt.)
 def spconv_centre_tail(in_a, w, tmap: TailMap, m_out, **kw):
     """A kernel_size-3 / stride-1 convolution on a low-density map as two launches: the pairs of the 26 non-centre
     offsets multiplied offset by offset (weight stationary) into one row per pair, then the centre offset as a dense pass

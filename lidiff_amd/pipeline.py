@@ -254,7 +254,18 @@ class DiffCompletion(nn.Module):
             self._warm_state = state                 # packed weights / folded BatchNorm now exist, queued on the main stream
             return out
 
+    # tools/debug/step_timeline.py: a list here collects (step start, conditions encoded, x_t adopted, network done) events
+    timeline = None
+
+    def _mark(self, marks):
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            marks.append(e)
+
     def classfree_forward(self, x_t, x_cond, x_uncond, t, parts=None):
+        marks = [] if self.timeline is not None else None
+        self._mark(marks)
         if self.overlap_maps and x_t.F.device.type == "cuda":
             self._step_start = torch.cuda.Event()
             self._step_start.record(torch.cuda.current_stream(self.device))
@@ -264,11 +275,19 @@ class DiffCompletion(nn.Module):
                 # pass over x_t's maps: every sparse conv is ONE launch with two stacked feature matrices
                 if parts is None:
                     parts = self.encode_conditions(x_cond, x_uncond)      # queued on the main stream ...
+                self._mark(marks)
+                # the conditioning tables of all eight levels need only the latents and t: queued now, while the host still has
+                # a lead over the GPU (prepare() below blocks it on the map sizes of x_t)
+                cond = self.model.precompute_conditioning(parts, t)
                 # ... x_t's maps meanwhile, on the side stream -- and the part -> full matches of every level, which need
                 # only coordinates (the condition's coarsest map and x_t's maps), not the encoders' features
                 self.prepare(x_t, also=lambda f: self._match_levels(f, parts), up_orders=minknet._UP_ORDERED)
                 x_t_sparse = self._adopt(x_t).sparse()
-                e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t)
+                self._mark(marks)
+                e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t, cond=cond)
+                self._mark(marks)
+                if marks is not None:
+                    self.timeline.append(marks)
                 e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
                 return e_uncond + self.w_uncond * (e_cond - e_uncond)
         # two forwards, as the reference runs them (pair_cfg = False); forward() joins the side stream for the conditions

@@ -88,16 +88,16 @@ class SceneMaps:
             ts = self.mgr.stride(ts, 2)
         self.mgr.check()
 
-    def table(self, level, kind):
+    def table(self, level, kind, cout=128):
         """(nbr on the device, m_in, m_out, sparse hint) exactly as _ConvBase.maps / sparse_hint produce them."""
         mgr, ts = self.mgr, 1 << level
         m = lambda t: mgr.maps[t].coords.shape[0]
         if kind == "k3":
-            return mgr.kernel_map(ts, ts, 3), m(ts), m(ts), mgr.is_sparse_map(ts, ts, 3)
+            return mgr.kernel_map(ts, ts, 3), m(ts), m(ts), mgr.is_sparse_map(ts, ts, 3, c_out=cout)
         if kind == "down":
-            return mgr.kernel_map(ts, 2 * ts, 2), m(ts), m(2 * ts), mgr.is_sparse_map(ts, 2 * ts, 2)
+            return mgr.kernel_map(ts, 2 * ts, 2), m(ts), m(2 * ts), mgr.is_sparse_map(ts, 2 * ts, 2, c_out=cout)
         if kind == "up":
-            return mgr.kernel_map(2 * ts, ts, 2, True), m(2 * ts), m(ts), mgr.is_sparse_map(2 * ts, ts, 2, True)
+            return mgr.kernel_map(2 * ts, ts, 2, True), m(2 * ts), m(ts), mgr.is_sparse_map(2 * ts, ts, 2, True, c_out=cout)
         return None, m(ts), m(ts), False
 
 
@@ -114,7 +114,7 @@ def scenes(device, fps_scan):
 
 def _layer_case(device, scene, level, kind, cin, cout, split, replicas=1):
     from lidiff_amd import ops
-    nbr, m_in, m_out, hint = scene.table(level, kind)
+    nbr, m_in, m_out, hint = scene.table(level, kind, cout)
     g = torch.Generator().manual_seed(1000 * level + cin + cout)
     k = 1 if nbr is None else nbr.shape[0]
     x = torch.randn(replicas * m_in, cin, generator=g)

@@ -104,15 +104,15 @@ def main():
             rows = (tord[:, None] * 128 + torch.arange(128, device=dev)[None, :]).reshape(-1)
             order = rows[rows < m].to(torch.int32)
             nbr = nbr.index_select(1, order.long()).contiguous()
-        hint = {"k3": mgr.is_sparse_map(ts, ts, 3), "down": mgr.is_sparse_map(ts, ts * 2, 2),
-                "up": mgr.is_sparse_map(ts * 2, ts, 2, True), "k1": False}[kind]
+        hint = {"k3": mgr.is_sparse_map(ts, ts, 3, c_out=cout), "down": mgr.is_sparse_map(ts, ts * 2, 2, c_out=cout),
+                "up": mgr.is_sparse_map(ts * 2, ts, 2, True, c_out=cout), "k1": False}[kind]
         if args.sparse_hint >= 0:
             hint = bool(args.sparse_hint)
         if args.up_ordered and kind == "up":
             (nbr, order), hint = mgr.up_order(ts * 2, ts), False
         if args.centre_tail and kind == "k3":
             tmap = ops.TailMap(nbr)
-            conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out)
+            conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out, replicas=args.replicas, sparse_map=hint)
         elif args.kernel == "bf16" and ops.bf16_conv_applies(cin, 0, cout):
             conv = lambda: ops.spconv_fwd_bf16(x, w, nbr, m_out, planes=args.planes, replicas=args.replicas)
         else:

@@ -143,18 +143,49 @@ def cpu_baseline(scan_np, seed=42, threads=0):
                       f"{cores} OpenMP threads / {torch.get_num_threads()} torch threads on {model}"}
 
 
-def traffic_from_profile(variant):
-    """(HBM GB per launch of the dominant kernel, source) from the newest committed PMC passes (tools/pmc_bench.sh ->
-    profiles/rNN_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); (None, None) if no profile
-    belongs to that kernel.  PMC counters cannot be collected from inside this process, so this is a STATIC number of
-    the same kernel on the same workload, labelled as such in the line."""
+VARIANT_KERNELS = {"bn128": ("<128, 8, 1",), "bn96": ("<128, 6, 1", "<128, 3, 2"), "bn64": ("<128, 4, 2",),
+                   "bn32": ("<128, 2, 4",), "bn16": ("<128, 1, 8",)}
+COORD_KERNELS = ("insert_kernel", "flag_count_kernel", "scan_write_kernel", "inverse_kernel", "mean_", "kernel_map_",
+                 "floor_kernel")
+
+
+def pmc_profile():
+    """The newest committed PMC passes (tools/pmc_bench.sh -> profiles/rNN_pmc_traffic.json) or (None, None)."""
     import glob
-    want = {"bn128": "<128, 8, 1", "bn96": "<128, 6, 1", "bn64": "<128, 4, 2", "bn32": "<128, 2, 4"}.get(variant)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-        js = json.load(open(path))
-        if want is not None and want in js.get("kernel", ""):
-            return js["traffic_bytes_per_launch"] / 1e9, os.path.relpath(path, ROOT)
-    return None, None
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
+    return (json.load(open(paths[0])), os.path.relpath(paths[0], ROOT)) if paths else (None, None)
+
+
+def traffic_from_profile(variants, per="launch"):
+    """HBM-side bytes of the conv variants `variants` from the committed PMC passes: FETCH_SIZE x2 (gfx950 correction) +
+    WRITE_SIZE, summed over their kernel instantiations -- per launch, or in total over the profiled command.  PMC counters
+    cannot be collected from inside this process, so this is a STATIC number of the same kernels on the same command,
+    labelled as such in the line.  (None, None) if no profile holds those kernels."""
+    js, src = pmc_profile()
+    if js is None:
+        return None, None
+    if "kernels" not in js:                                    # round-1/2 format: the dominant kernel only
+        want = VARIANT_KERNELS.get(variants[0], ("?",))[0]
+        return (js["traffic_bytes_per_launch"] / 1e9, src) if want in js.get("kernel", "") else (None, None)
+    keys = [p for v in variants for p in VARIANT_KERNELS.get(v, ())]
+    rows = [v for k, v in js["kernels"].items() if "spconv_fwd_kernel" in k and any(p in k for p in keys)]
+    if not rows:
+        return None, None
+    total = sum(r["traffic_bytes_total"] for r in rows)
+    return (total / sum(r["launches"] for r in rows) if per == "launch" else total) / 1e9, src
+
+
+def coords_traffic_from_profile():
+    """(GB per denoising step moved by the coordinate kernels of ALL three fields of a step, source) from the same passes."""
+    js, src = pmc_profile()
+    if js is None or "kernels" not in js:
+        return None, None
+    steps = [int(x) for x in __import__("re").findall(r"--steps (\d+) --warmup (\d+)", js.get("command", ""))[0]] \
+        if "--steps" in js.get("command", "") else None
+    rows = [v for k, v in js["kernels"].items() if any(c in k for c in COORD_KERNELS)]
+    if not rows or not steps:
+        return None, None
+    return sum(r["traffic_bytes_total"] for r in rows) / sum(steps) / 1e9, src
 
 
 def coords_roofline(scan_np, device, iters=5):
@@ -201,7 +232,11 @@ def coords_roofline(scan_np, device, iters=5):
     return {"kernel": "coordinate pipeline of one 180000-point x_t (sigma 1): voxel hash + mean, 4 strided maps, 5 ks3 / 4 ks2 / "
                       "4 transposed kernel maps (coords.hip; includes the host reads of the map sizes)",
             "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-            "traffic": None, "ms": ms, "algorithmic_mbytes": nbytes / 1e6, "voxels_per_level": m}
+            "traffic": coords_traffic_from_profile()[0],
+            "traffic_unit": "GB per denoising step moved by the coordinate kernels of ALL three fields of a step (x_t, x_cond, x_uncond: "
+                            "hash insert / flag / scan / inverse / mean / kernel maps; rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; static: "
+                            + str(coords_traffic_from_profile()[1]) + ") -- `achieved` is one x_t's pyramid alone",
+            "ms": ms, "algorithmic_mbytes": nbytes / 1e6, "voxels_per_level": m}
 
 
 def train_leg(scan_np, device, steps=3, warmup=1):
@@ -347,6 +382,8 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world > 1:       # N ranks share the host: each keeps to its share of the cores (the step's host side is one Python thread)
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     # one tiny collective over RCCL before anything is timed: every rank must be seen (the data path itself has none)
     ranks_seen = int(ldist.sum_over_ranks(1.0, device=device))
 
@@ -439,7 +476,7 @@ def main():
         dom = max(summ, key=lambda v: summ[v]["ms"])
         d = summ[dom]
         tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = traffic_from_profile(dom)
+        traffic, traffic_src = traffic_from_profile([dom])
         step_flops = sum(v["flops"] for v in summ.values()) / args.steps
         out["roofline"] = {
             "kernel": f"spconv_fwd_kernel, BN={dom[2:]} output-channel tile ({dom})", "bound": "mfma",
@@ -467,7 +504,11 @@ def main():
             out["roofline_narrow"] = {
                 "kernel": "spconv_fwd_kernel, output-channel tiles below 128 (bn96 / bn64 / bn32: the stride-1/2 layers, "
                           "centre + tail passes included)", "bound": "hbm", "achieved": nb / (nms * 1e-3) / 1e9,
-                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nb / (nms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nb / (nms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "traffic": traffic_from_profile(sorted(narrow))[0],
+                "traffic_unit": "GB per launch, averaged over these variants' launches (HBM-side, rocprofv3 PMC FETCH_SIZE x2 + "
+                                "WRITE_SIZE; static: " + str(traffic_from_profile(sorted(narrow))[1]) + ")",
+                "algorithmic_gbytes_per_launch": nb / sum(v["launches"] for v in narrow.values()) / 1e9,
                 "ms_per_step": nms / args.steps, "launches_per_step": sum(v["launches"] for v in narrow.values()) / args.steps,
                 "note": "algorithmic bytes 4 (M_in C_in + M_out C_out) + 4 K C_in C_out + 8 P per launch / HIP-event time, "
                         "from a second pass of the same steps with every conv launch timed (not the pass behind `value`)",

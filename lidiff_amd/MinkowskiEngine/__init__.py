@@ -186,6 +186,11 @@ class CoordinateManager:
             if tail_maps and self.maps[ts].coords.shape[0] >= 1024 and self.is_sparse_map(ts, ts, 3):
                 self.tail_map(ts)
 
+    def prebuild_rulebooks(self):
+        """The ME-layout rulebooks of every kernel map built so far (the weight-gradient kernel walks them), with one host
+        read for all of them (ops.build_rulebooks) instead of one per map in the middle of the backward pass."""
+        ops.build_rulebooks([t for t in self.kmaps.values() if isinstance(t, torch.Tensor) and t.dim() == 2])
+
     def tensors(self):
         """Every device tensor this manager holds (for record_stream when it was built on another stream)."""
         out = [self.status]

@@ -30,6 +30,7 @@ def prebuild_maps(field):
     with torch.no_grad():
         field.sparse()
         field.coordinate_manager.prebuild(tail_maps=False)
+        field.coordinate_manager.prebuild_rulebooks()      # the backward's rulebooks: one host read for all of them
     return field
 
 

@@ -297,6 +297,23 @@ class _RepeatSegments(torch.autograd.Function):
         return torch.stack(out), None
 
 
+class _BatchRows(torch.autograd.Function):
+    """t[b] for every row of a coordinate map (b = the row's batch index): the same values as _RepeatSegments, from the
+    batch column itself -- no host read of the rows per batch (torch.unique(...).tolist() is a device -> host sync per level
+    and step).  Backward: one masked column sum per batch (B is 2 in LiDiff's training), deterministic."""
+
+    @staticmethod
+    def forward(ctx, t, bidx):
+        ctx.save_for_backward(bidx)
+        ctx.nb = t.shape[0]
+        return t.index_select(0, bidx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (bidx,) = ctx.saved_tensors
+        return torch.stack([(g * (bidx == b).unsqueeze(1)).sum(dim=0) for b in range(ctx.nb)]), None
+
+
 class MinkUNetDiff(_Base):
     """The denoiser (minkunet.py:144-497)."""
 
@@ -369,14 +386,15 @@ class MinkUNetDiff(_Base):
 
     def _per_batch_rows(self, t, x):
         """minkunet.py:427-428 etc.: ``repeat_interleave(t, rows per batch)`` -- rows of a coordinate map are grouped
-        by ascending batch index, so the backward is one column sum per batch segment (torch's own backward of
+        by ascending batch index, so row r takes t[batch of r]: a gather through the map's batch column, without reading the
+        rows per batch back to the host; the backward is one masked column sum per batch (torch's own backward of
         repeat_interleave is an index_add of M_l x C atomics into B rows: 5 ms per call at 360k rows)."""
         aux = x.coordinate_manager.aux                  # lives and dies with the step's coordinate manager
-        key = ("rows_per_batch", x.tensor_stride)
-        counts = aux.get(key)
-        if counts is None:
-            counts = aux[key] = self._rows_per_batch(x).tolist()
-        return _RepeatSegments.apply(t, counts)
+        key = ("batch_index", x.tensor_stride)
+        bidx = aux.get(key)
+        if bidx is None:
+            bidx = aux[key] = x.C[:, 0].long()
+        return _BatchRows.apply(t, bidx)
 
     def _condition_terms(self, name, part_feats, temp_emb):
         """The two summands of lin1(cat(latent(match), temp)) before the gather (fused plan): the row-wise MLPs run on

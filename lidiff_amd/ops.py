@@ -502,10 +502,34 @@ def rulebook_of(nbr: torch.Tensor):
     return rb
 
 
+def build_rulebooks(tables) -> None:
+    """rulebook_of() for several neighbour tables with ONE host read: every table's counting pass is queued first, the
+    totals come back together, then the fill passes (a training step walks ~13 kernel maps in its backward; one read each
+    left the GPU idle while the host waited -- profiles/r03_train_idle_gaps.txt)."""
+    todo = [t for t in tables if t is not None and getattr(t, "_lidiff_rulebook", None) is None]
+    if not todo:
+        return
+    require_device(*todo)
+    offs = []
+    for nbr in todo:
+        k, m = nbr.shape
+        ws = torch.empty(_lib.load().lidiff_rulebook_workspace_bytes(k, m), dtype=torch.uint8, device=nbr.device)
+        off = torch.empty(k + 1, dtype=torch.int32, device=nbr.device)
+        call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), None, None, ptr(ws), stream_ptr())
+        offs.append((off, ws))
+    totals = torch.stack([off[-1] for off, _ in offs]).tolist()                      # the one read
+    for nbr, (off, ws), total in zip(todo, offs, totals):
+        k, m = nbr.shape
+        pin = torch.empty(total, dtype=torch.int32, device=nbr.device)
+        pout = torch.empty(total, dtype=torch.int32, device=nbr.device)
+        call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), ptr(pin), ptr(pout), ptr(ws), stream_ptr())
+        nbr._lidiff_rulebook = (pin, pout, off, int(total))
+
+
 def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None, bf16: bool = False) -> torch.Tensor:
     """Weight gradient of spconv_fwd (training path, models.py:180-217): dW[k] = gather(in)[pairs_k]^T @
-    grad_out[pairs_k] by the MFMA kernel lidiff_spconv_bwd_w over the map's rulebook; channel counts that are not
-    multiples of 4 (the 3-channel stem) go through row gathers + one library GEMM per offset.
+    grad_out[pairs_k] by the MFMA kernel lidiff_spconv_bwd_w over the map's rulebook; input channel counts that are not
+    multiples of 4 (the 3-channel stem) are zero-padded to the next multiple for the kernel.
     bf16: operands rounded to bf16, fp32 sums (lidiff_spconv_bwd_w_bf16) -- the bf16 training configuration."""
     require_device(in_a, grad_out, nbr, in_b)
     in_a = in_a.contiguous()
@@ -534,7 +558,15 @@ def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None, bf16: bool = False) -> 
             ev[1].record()
             prof.dw.append(ev)
         return dw
+    # channel counts that are not multiples of 4 (the 3-channel stem, models.py: in_channels = 3): zero-pad the input columns
+    # to the next multiple of 4 and take the MFMA kernel -- the padded columns' gradient rows are dropped.  (Rounds 1-2 looped
+    # over the offsets with two row gathers and a library GEMM each: 27 small launch triples and a host read per step.)
     x = in_a if in_b is None else torch.cat([in_a, in_b], dim=1)
+    c_in = x.shape[1]
+    if c_out % 4 == 0:
+        pad = (-c_in) % 4
+        xp = torch.nn.functional.pad(x, (0, pad)) if pad else x
+        return spconv_bwd_w(xp, grad_out, nbr, k, bf16=False)[:, :c_in, :].contiguous()
     if nbr is None:                                   # kernel_size 1: identity map
         return (x.t() @ grad_out).unsqueeze(0)
     pin, pout, off, _ = rulebook_of(nbr)

@@ -382,6 +382,23 @@ def test_spconv_backward_vs_oracle_autograd(device, kind, ks, stride, cin, cout)
         ops.DETERMINISTIC_DW = True
 
 
+def test_stem_weight_gradient_pads_the_input_columns(device):
+    """dW of the 3-channel stem convolution (minkunet.py:155: in_channels = 3): ops.spconv_bwd_w zero-pads the input columns
+    to 4 and runs the MFMA kernel; against torch autograd through the oracle's convolution (float64)."""
+    from lidiff_amd import ops
+    coords = random_cloud(3000, 7, 31, batch=2)
+    uniq, _, _ = me.voxelize(coords)
+    nbr = me.kernel_map(uniq, uniq, 3, 1)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(uniq.shape[0], 3, generator=g)
+    w = (torch.randn(27, 3, 32, generator=g) / 3.0).double().requires_grad_(True)
+    up = torch.randn(uniq.shape[0], 32, generator=g)
+    (me.conv_forward(x.double(), w, nbr) * up.double()).sum().backward()
+    got = ops.spconv_bwd_w(x.to(device), up.to(device), dev_i32(nbr, device), 27)
+    assert got.shape == (27, 3, 32)
+    assert torch.allclose(got.cpu().double(), w.grad, rtol=RTOL, atol=ATOL), (got.cpu().double() - w.grad).abs().max().item()
+
+
 def test_gather_scatter_rows(device):
     from lidiff_amd import ops
     g = torch.Generator().manual_seed(0)

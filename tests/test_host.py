@@ -221,6 +221,24 @@ def test_repeat_segments_matches_repeat_interleave_autograd():
     assert torch.allclose(t.grad, ref_in.grad, rtol=1e-12, atol=0)
 
 
+def test_batch_rows_matches_repeat_interleave_autograd():
+    """The same broadcast from the map's batch column (no rows-per-batch read back to the host): forward and gradient of
+    torch.repeat_interleave over batch-grouped rows, an empty batch included."""
+    from lidiff_amd.minkunet import _BatchRows
+    g = torch.Generator().manual_seed(1)
+    t = torch.randn(3, 5, generator=g, dtype=torch.float64, requires_grad=True)
+    counts = [4, 0, 7]
+    bidx = torch.repeat_interleave(torch.arange(3), torch.tensor(counts))
+    up = torch.randn(sum(counts), 5, generator=g, dtype=torch.float64)
+    out = _BatchRows.apply(t, bidx)
+    ref_in = t.detach().clone().requires_grad_(True)
+    ref = torch.repeat_interleave(ref_in, torch.tensor(counts), dim=0)
+    assert torch.equal(out, ref)
+    (out * up).sum().backward()
+    (ref * up).sum().backward()
+    assert torch.allclose(t.grad, ref_in.grad, rtol=1e-12, atol=0)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus N` with WORLD_SIZE unset (how the driver starts the N = 1 line, and how a SCALE run in
     the same form would start N > 1) spawns N ranks itself: the --dry-run leg runs the launcher, the rendezvous on

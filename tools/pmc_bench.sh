@@ -1,19 +1,24 @@
 #!/bin/bash
-# HBM traffic of the dominant bench kernel from rocprofv3 PMC passes over bench.py (separate passes,
-# --kernel-trace only: MI355X_MICROARCH.md "HBM", "rocprofv3 PMC slots").  Writes gpurun_out/pmc_bench/traffic.json;
-# copy it to profiles/r01_pmc_traffic.json to have bench.py report it as roofline.traffic.
+# HBM-side traffic of the bench's kernels from rocprofv3 PMC passes over the SAME command the driver runs
+# (python bench.py --steps 10 --warmup 2; separate passes per counter, --kernel-trace only: MI355X_MICROARCH.md "HBM",
+# "rocprofv3 PMC slots").  Writes gpurun_out/pmc_bench/traffic.json: one entry per lidiff kernel (every spconv_fwd_kernel
+# instantiation, the coordinate kernels) with FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, per launch.
+# Copy it to profiles/rNN_pmc_traffic.json: bench.py reports it as roofline.traffic / roofline_narrow.traffic /
+# roofline_hbm.traffic (labelled static: counters cannot be read inside the timed process).
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_bench
 mkdir -p $OUT
+STEPS=${PMC_STEPS:-10}
+WARM=${PMC_WARMUP:-2}
 cd /tmp && export TMPDIR=/tmp
 for pass in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/$pass -o p -- \
-    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline > $OUT/$pass.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/$pass -o p -- \
+    python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train > $OUT/$pass.log 2>&1
 done
 cd $R
 python - <<PY
-import csv, glob, json, os, collections
+import csv, glob, json, os, collections, re
 out = "$OUT"
 res = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -22,22 +27,27 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
         print(name, "no csv:", open(os.path.join(out, name + ".log")).read()[-500:]); continue
     agg = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(files[0])):
-        if row["Counter_Name"] != name or "spconv_fwd_kernel" not in row["Kernel_Name"]: continue
-        a = agg[row["Kernel_Name"].split("(")[0]]
+        if row["Counter_Name"] != name or "lidiff::" not in row["Kernel_Name"]: continue
+        a = agg[re.sub(r"^void ", "", row["Kernel_Name"].split("(")[0])]
         a[0] += float(row["Counter_Value"]); a[1] += 1
-    res[name] = {k: {"sum_kb": v[0], "launches": v[1]} for k, v in agg.items()}
-dom = max(res.get("FETCH_SIZE", {}), key=lambda k: res["FETCH_SIZE"][k]["sum_kb"], default=None)
+    res[name] = agg
+kernels = {}
+for k, (kb, n) in res.get("FETCH_SIZE", {}).items():
+    w = res.get("WRITE_SIZE", {}).get(k, [0.0, 1])
+    kernels[k] = {"launches": n, "fetch_bytes_per_launch_raw": 1024.0 * kb / n, "fetch_bytes_per_launch": 2048.0 * kb / n,
+                  "write_bytes_per_launch": 1024.0 * w[0] / max(1, w[1]),
+                  "traffic_bytes_per_launch": 2048.0 * kb / n + 1024.0 * w[0] / max(1, w[1]),
+                  "traffic_bytes_total": 2048.0 * kb + 1024.0 * w[0]}
+conv = {k: v for k, v in kernels.items() if "spconv_fwd_kernel" in k}
+dom = max(conv, key=lambda k: conv[k]["traffic_bytes_total"], default=None)
+js = {"command": f"python bench.py --steps $STEPS --warmup $WARM (all {int('$STEPS') + int('$WARM')} steps counted)",
+      "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+              "(gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated; L2 -> fabric side: Infinity-Cache hits are included",
+      "kernels": kernels}
 if dom:
-    f, w = res["FETCH_SIZE"][dom], res.get("WRITE_SIZE", {}).get(dom, {"sum_kb": 0.0, "launches": 1})
-    js = {"kernel": dom, "launches": f["launches"],
-          "fetch_bytes_per_launch_raw": 1024.0 * f["sum_kb"] / f["launches"],
-          "fetch_bytes_per_launch": 2 * 1024.0 * f["sum_kb"] / f["launches"],     # gfx950: FETCH_SIZE reports 1/2 of wide reads
-          "write_bytes_per_launch": 1024.0 * w["sum_kb"] / max(1, w["launches"]),
-          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), separate passes over bench.py --steps 4 --warmup 1; "
-                  "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncalibrated"}
-    js["traffic_bytes_per_launch"] = js["fetch_bytes_per_launch"] + js["write_bytes_per_launch"]
-    json.dump(js, open(os.path.join(out, "traffic.json"), "w"), indent=1)
-    print(json.dumps(js, indent=1))
-for name, d in res.items():
-    for k, v in d.items(): print(name, k[:70], v)
+    js.update({"kernel": dom, **{k: conv[dom][k] for k in ("launches", "fetch_bytes_per_launch_raw", "fetch_bytes_per_launch",
+                                                           "write_bytes_per_launch", "traffic_bytes_per_launch")}})
+json.dump(js, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["traffic_bytes_total"])[:25]:
+    print(f"{k[:80]:<80} launches {v['launches']:5d}  traffic/launch {v['traffic_bytes_per_launch'] / 1e6:10.2f} MB")
 PY

@@ -393,10 +393,12 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         if constexpr (NB > 0) {
             if (!PROBE(16)) {
                 // per element: its list word (one b128 read per block), one address add, read, add, write.
-                // (Round 3 tried the add inside the MFMA instead -- accumulators initialised from the tile rows, written back
-                // after the last slab, no VALU arithmetic: +2 % on 256 -> 256, +4.6 % on 128 -> 128 at stride 8, but one
-                // 27 x C_in-term fp32 chain per output instead of 27 short ones: 10x the rounding error against the float64
-                // oracle, 5.1e-5 vs 4.7e-6 on the 384 -> 256 layer -- not kept; profiles/r03_dense_ablation.txt.)
+                // Round 3 tried two other forms, both measured and dropped (profiles/r03_dense_ablation.txt):
+                //  * the add inside the MFMA -- accumulators initialised from the tile rows, written back after the last slab, no
+                //    VALU arithmetic: +2 % on 256 -> 256, +4.6 % on 128 -> 128 at stride 8, but one 27 x C_in-term fp32 chain per
+                //    output instead of 27 short ones: 10x the rounding error against the float64 oracle (5.1e-5 vs 4.7e-6);
+                //  * list words, addresses and tile reads issued in FRONT of the last slab's MFMAs (they do not depend on the
+                //    results): 252 VGPRs, 4-7 % SLOWER (98 -> 94 TFLOP/s on 256 -> 256, 84 -> 78 on 128 -> 128).
                 const OutT* ol = out_list + item.k * BM + item.start + 4 * lq;
                 const int colb = (16 * wn + li) * 4;
                 char* accb = reinterpret_cast<char*>(acc_lds);

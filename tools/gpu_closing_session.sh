@@ -1,20 +1,26 @@
 #!/bin/bash
-# Closing GPU session of a round: full GPU suite, smoke, default bench, rocprofv3 kernel stats of the bench command.
-set -u
-cd "$(dirname "$0")/.."
-R=$(pwd); OUT=$R/gpurun_out/closing; mkdir -p $OUT
-export PYTHONUNBUFFERED=1
-timeout 1800 python -m pytest tests -q -m gpu --durations=8 -rs 2>&1 | tail -30 > $OUT/pytest_gpu.txt; tail -4 $OUT/pytest_gpu.txt
-timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $OUT/smoke.txt
-timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; python -c "
-import json; j=json.load(open('$OUT/bench_default.json')); r=j['roofline']
-print('value %.2f ms %.2f frac %.3f step_frac %.3f alt %.2f cpu %.4f hbm %.4f narrow %.3f'%(j['value'], j['ms_per_step'], r['frac'], r['step_frac'], j['alt']['value'], j['cpu_baseline']['value'], j['roofline_hbm']['frac'], j['roofline_narrow']['frac']))"
+# Closing session of a round: the whole GPU suite (parity errors recorded), smoke, the driver's bench command, its rocprofv3
+# kernel stats, the per-layer table, the step timeline and the PMC traffic passes.  Copies nothing: see tools/collect_profiles.sh.
+cd "${GRAFT_REPO_ROOT:-.}"
+O=$PWD/gpurun_out/closing
+rm -rf $O; mkdir -p $O
+R=$PWD
+export LIDIFF_PARITY_LOG=$O/parity_errors.jsonl
+timeout 1700 python -m pytest tests -m gpu -q --durations=10 > $O/pytest.txt 2>&1
+echo "pytest rc=$?" >> $O/pytest.txt
+unset LIDIFF_PARITY_LOG
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 400 python bench.py --no-cpu-baseline --no-train --no-alt --no-coords-roofline --layer-table $O/layer_table.txt > $O/bench_layers.json 2> /dev/null
+timeout 300 python tools/debug/step_timeline.py 2>&1 | grep -v amdgpu > $O/step_timeline.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline > $OUT/bench_under_rocprof.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train > $O/bench_prof.json 2> $O/bench_prof.err
 cd $R
-DB=$(find $OUT/prof -name '*.db' | head -1); python tools/rocpd_stats.py $DB --top 45 > $OUT/kernel_stats.md 2>&1; head -8 $OUT/kernel_stats.md; rm -rf $OUT/prof
-# the launcher path of the metric on this box's one GPU: RCCL initialised by torch.distributed.run (world size 1), and the
-# self-launching form refusing more ranks than there are devices
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --no-alt --no-coords-roofline > $OUT/bench_torchrun_n1.json 2> $OUT/bench_torchrun_n1.err; python -c "
-import json; j=json.load(open('$OUT/bench_torchrun_n1.json')); print('torchrun n=1: value %.2f n_gpus %d rccl_ranks_seen %d'%(j['value'], j['n_gpus'], j['rccl_ranks_seen']))"
-timeout 120 python bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_gpus2.out 2> $OUT/bench_gpus2.err; echo "bench --gpus 2 on a 1-GPU box: rc=$?"; grep -h "GPU(s) visible\|only" $OUT/bench_gpus2.err | tail -2
+DB=$(find $O/prof -name "*results.db" | head -1)
+{ echo "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train (the driver's step count; 12 steps incl. warm-up)"; echo; python tools/rocpd_stats.py $DB --top 60; } > $O/kernel_stats.md 2>&1
+python tools/rocpd_gaps.py $DB --min-us 10 --top 15 --last-ms 300 > $O/idle_gaps.txt 2>&1
+rm -rf $O/prof
+bash tools/pmc_bench.sh > $O/pmc.txt 2>&1
+cp gpurun_out/pmc_bench/traffic.json $O/pmc_traffic.json
+rm -rf gpurun_out/pmc_bench/FETCH_SIZE gpurun_out/pmc_bench/WRITE_SIZE
+tail -3 $O/pytest.txt; cat $O/smoke.txt | tail -1; cut -c1-300 $O/bench_default.json; head -8 $O/kernel_stats.md | cut -c1-150; head -3 $O/step_timeline.txt; head -2 $O/idle_gaps.txt

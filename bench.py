@@ -85,7 +85,7 @@ def run_steps(pipe, x_init, xs, tvals, first, count, cache_condition=False):
     parts = pipe.encode_conditions(x_cond, x_uncond) if cache_condition else None
     for j in range(first, first + count):
         t = torch.full((1,), tvals[j], dtype=torch.int64, device=x_init.device)
-        noise_t = pipe.classfree_forward(x_t, x_cond, x_uncond, t, parts)
+        noise_t = pipe.classfree_forward(x_t, x_cond, x_uncond, t, parts, t_host=tvals[j])
         input_noise = x_t.F.reshape(1, -1, 3) - x_init
         if j == first or tvals[j] >= tvals[j - 1]:
             pipe.new_scheduler()                       # a new scan's trajectory starts
@@ -93,7 +93,7 @@ def run_steps(pipe, x_init, xs, tvals, first, count, cache_condition=False):
         nxt = xs[j + 1] if j + 1 < len(xs) else xs[j]
         x_t = pipe.points_to_tensor(nxt)               # open loop: next sigma's points (see docstring)
         if parts is None:
-            x_cond, x_uncond = pipe.reset_partial_pcd(x_cond, x_uncond)
+            x_cond, x_uncond = pipe.reset_partial_pcd(x_cond, x_uncond, next_t=tvals[j + 1] if j + 1 < first + count else None)
     return x_t
 
 

@@ -17,6 +17,7 @@ order (level 0) / in finer-row order (strided maps) -- SURVEY.md Appendix A.7.
 """
 from __future__ import annotations
 
+import contextlib
 import enum
 import math
 
@@ -63,44 +64,93 @@ class CoordinateManager:
         self.kmaps: dict[tuple, torch.Tensor] = {}
         self.aux: dict = {}                             # derived per-map caches (match indices, ...)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self._async = None                              # (build stream, second build stream) -- set_async()
+        self._ready = None                              # event: the field's points exist (recorded on the consumer's stream)
+        self._on_level = None                           # callable(ts): queued on the second stream when level ts exists
+
+    # -- asynchronous, on-demand building (DiffCompletion, round 3) ------------------------------------------------------
+    def set_async(self, side, side2, ready=None, on_level=None):
+        """Build every map of this manager ON DEMAND on `side` (the map-size reads synchronise that stream only) while the
+        consumer's stream keeps running what is already queued; consumers join through lidiff_amd._lib.call().  on_level(ts)
+        runs on `side2` as soon as the coordinate map of stride ts exists (the part -> full match of that level)."""
+        from .. import _lib
+        _lib.register_build_stream(side)
+        _lib.register_build_stream(side2)
+        self._async, self._ready, self._on_level = (side, side2), ready, on_level
+        if ready is not None:
+            side.wait_event(ready)
+            side2.wait_event(ready)
+
+    def clear_async(self):
+        self._async = self._on_level = None
+
+    @contextlib.contextmanager
+    def building(self, second: bool = False):
+        """Context of every map-building call: the build stream when set_async() is on, the current stream otherwise."""
+        if self._async is None:
+            yield
+            return
+        from .. import _lib
+        st = self._async[1 if second else 0]
+        with torch.cuda.stream(st):
+            yield
+        _lib.mark_pending(st)
+
+    def _level_built(self, ts: int):
+        if self._async is not None and self._on_level is not None:
+            side, side2 = self._async
+            ev = torch.cuda.Event()
+            ev.record(side)
+            side2.wait_event(ev)
+            with self.building(second=True):
+                self._on_level(ts)
 
     def insert(self, coords_i32: torch.Tensor):
-        uniq, inverse, first_idx, table = ops.vox_unique(coords_i32, self.status)
+        with self.building():
+            uniq, inverse, first_idx, table = ops.vox_unique(coords_i32, self.status)
         self.maps[1] = CoordinateMap(uniq, table, 1)
+        self._level_built(1)
         return inverse, first_idx
 
     def stride(self, ts: int, s: int) -> int:
         ts_out = ts * s
         if ts_out not in self.maps:
-            coarse, parent, table = ops.map_stride(self.maps[ts].coords, ts_out, self.status)
+            with self.building():
+                coarse, parent, table = ops.map_stride(self.maps[ts].coords, ts_out, self.status)
             self.maps[ts_out] = CoordinateMap(coarse, table, ts_out)
             self.parents[ts_out] = parent
+            self._level_built(ts_out)
         return ts_out
 
     def kernel_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False) -> torch.Tensor:
         key = (ts_in, ts_out, ks, transposed)
         nbr = self.kmaps.get(key)
         if nbr is None:
-            if transposed:      # input = coarse map (ts_in), output = existing fine map (ts_out)
-                if ks != 2 or ts_in != 2 * ts_out or ts_in not in self.parents:
-                    raise RuntimeError("transposed convolution supported for kernel_size=2, stride=2 "
-                                       "onto a map created by the matching strided convolution")
-                nbr = ops.kernel_map_up(self.maps[ts_out].coords, self.parents[ts_in], ts_out)
-            elif ks == 2 and ts_out == 2 * ts_in and ts_out in self.parents:
-                # the strided convolution's map straight from the parent array of the stride map (no lookups)
-                nbr = ops.kernel_map_down(self.maps[ts_in].coords, self.parents[ts_out], ts_in,
-                                          self.maps[ts_out].coords.shape[0])
-            else:
-                nbr = ops.kernel_map(self.maps[ts_out].coords, self.maps[ts_in].table, ks, ts_in,
-                                     self_map=(ts_in == ts_out and ks == 3))
+            with self.building():
+                nbr = self._build_kernel_map(ts_in, ts_out, ks, transposed)
             self.kmaps[key] = nbr
         return nbr
+
+    def _build_kernel_map(self, ts_in, ts_out, ks, transposed):
+        if transposed:      # input = coarse map (ts_in), output = existing fine map (ts_out)
+            if ks != 2 or ts_in != 2 * ts_out or ts_in not in self.parents:
+                raise RuntimeError("transposed convolution supported for kernel_size=2, stride=2 "
+                                   "onto a map created by the matching strided convolution")
+            return ops.kernel_map_up(self.maps[ts_out].coords, self.parents[ts_in], ts_out)
+        if ks == 2 and ts_out == 2 * ts_in and ts_out in self.parents:
+            # the strided convolution's map straight from the parent array of the stride map (no lookups)
+            return ops.kernel_map_down(self.maps[ts_in].coords, self.parents[ts_out], ts_in,
+                                       self.maps[ts_out].coords.shape[0])
+        return ops.kernel_map(self.maps[ts_out].coords, self.maps[ts_in].table, ks, ts_in,
+                              self_map=(ts_in == ts_out and ks == 3))
 
     def tail_map(self, ts: int):
         """ops.TailMap of the kernel_size-3 map on stride ts (non-centre pairs by offset + CSR by output row); cached."""
         key = ("tail", ts)
         if key not in self.aux:
-            self.aux[key] = ops.TailMap(self.kernel_map(ts, ts, 3))
+            nbr = self.kernel_map(ts, ts, 3)
+            with self.building():
+                self.aux[key] = ops.TailMap(nbr)
         return self.aux[key]
 
     ORDER_MIN_ROWS = 30000      # smaller maps fit the L2 anyway
@@ -127,6 +177,7 @@ class CoordinateManager:
         return hit, order
 
     UP_ORDER_MIN_ROWS = 4096
+    MAX_STRIDE = 16             # the coarsest level of LiDiff's networks (four stride-2 stages)
 
     def up_order(self, ts_in: int, ts_out: int):
         """(neighbour table with its columns grouped by kernel offset, that row order) of the transposed kernel_size-2 /
@@ -142,8 +193,9 @@ class CoordinateManager:
             else:
                 # the ME-layout rulebook of the map lists its pairs by offset, then by output row: its output-row column IS the
                 # order (one pair per row => a permutation), built by three small kernels without a host read
-                _, order, _ = ops.rulebook_compact(nbr, total=nbr.shape[1])
-                self.aux[key] = (nbr.index_select(1, order.long()).contiguous(), order)
+                with self.building():
+                    _, order, _ = ops.rulebook_compact(nbr, total=nbr.shape[1])
+                    self.aux[key] = (nbr.index_select(1, order.long()).contiguous(), order)
         return self.aux[key]
 
     def is_sparse_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False, c_out: int = 128) -> bool:
@@ -163,8 +215,17 @@ class CoordinateManager:
             if transposed:
                 return True
             return m(ts_out) >= 0.67 * max(1, m(ts_in))
+        if self._async is not None and 2 * ts_in not in self.maps and ts_in in self.maps and ts_in < self.MAX_STRIDE:
+            self.stride(ts_in, 2)                     # on-demand building: the hint of a level needs the next level's size
         coarse = m(2 * ts_in)
         return coarse > 0 and coarse >= (0.85 if c_out % 128 == 0 else 0.5) * m(ts_in)
+
+    def prebuild_strides(self, max_stride: int = 16):
+        """The strided coordinate maps alone (levels 2 .. max_stride): everything that needs only coordinates -- e.g. the
+        part -> full matches of MinkUNetDiff -- can start as soon as these exist."""
+        ts = 1
+        while ts < max_stride:
+            ts = self.stride(ts, 2)
 
     def prebuild(self, max_stride: int = 16, tail_maps: bool = True, up_orders: bool = False):
         """Every map the networks will ask for, built now (MinkGlobalEnc / MinkUNetDiff / MinkUNet: four stride-2 levels, a
@@ -323,13 +384,15 @@ class TensorField:
     def sparse(self) -> "SparseTensor":
         mgr = self.coordinate_manager
         if self.inverse_mapping is None:
-            ci = self._C if self._C.dtype == torch.int32 else ops.coords_floor(self._C)
+            with mgr.building():
+                ci = self._C if self._C.dtype == torch.int32 else ops.coords_floor(self._C)
             self.inverse_mapping, _ = mgr.insert(ci)
         if self._sparse is not None:
             return self._sparse
         m = mgr.maps[1].coords.shape[0]
-        sp = SparseTensor(_VoxelMean.apply(self._F.float(), self.inverse_mapping, m),
-                          tensor_stride=1, coordinate_manager=mgr)
+        with mgr.building():
+            f = _VoxelMean.apply(self._F.float(), self.inverse_mapping, m)
+        sp = SparseTensor(f, tensor_stride=1, coordinate_manager=mgr)
         if not (torch.is_grad_enabled() and self._F.requires_grad):
             self._sparse = sp        # same features for every caller of this field (no graph attached)
         return sp

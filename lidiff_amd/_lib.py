@@ -83,6 +83,35 @@ def load() -> C.CDLL:
     return _lib
 
 
+# --- asynchronous map building (CoordinateManager.set_async): coordinate maps are built on side streams while the caller's
+# stream runs the convolutions that are already queued.  Every launch through call() on a stream that is NOT a build stream first
+# joins the build streams that have queued work since the last join (one event each) -- so a consumer can never run ahead of the
+# map it reads, whichever operator it goes through.
+_BUILD_STREAMS: set = set()
+_PENDING: set = set()
+
+
+def register_build_stream(stream) -> None:
+    _BUILD_STREAMS.add(stream)
+
+
+def mark_pending(stream) -> None:
+    _PENDING.add(stream)
+
+
+def join_pending() -> None:
+    if not _PENDING:
+        return
+    cur = torch.cuda.current_stream()
+    if cur in _BUILD_STREAMS:
+        return
+    for st in list(_PENDING):
+        ev = torch.cuda.Event()
+        ev.record(st)
+        cur.wait_event(ev)
+    _PENDING.clear()
+
+
 def ptr(t: torch.Tensor | None):
     return None if t is None else t.data_ptr()
 
@@ -93,6 +122,8 @@ def stream_ptr():
 
 def call(name: str, *args):
     """Invoke an int-returning entry point; non-zero status -> RuntimeError (ME raises too)."""
+    if _PENDING:
+        join_pending()
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {load().lidiff_last_error().decode()}")

@@ -88,12 +88,18 @@ class DiffCompletion(nn.Module):
     # size; on the stream of the convolutions each read drains the queue.  With overlap_maps the chain of a field runs
     # on a side stream while the main stream is busy with another tensor's convolutions: the conditions of step i + 1
     # under the UNet of step i, the maps of x_t under the condition encoders.  Every step still builds everything anew.
+    # x_t's maps built ON DEMAND on the side streams while the network's first layers already run (round 3): with the condition
+    # encoders issued one step ahead nothing else hides the chain behind x_t's points (voxelise -> 4 strided maps -> 13 kernel
+    # maps -> tail maps -> up orders -> 5 matches: 2.2-3 ms with its map-size reads, profiles/r03_step_boundary_trace.txt),
+    # but the stem needs only the first ~0.4 ms of it.  LIDIFF_LAZY_XT=0: the whole pyramid first (round-2 behaviour).
+    lazy_x_t = os.environ.get("LIDIFF_LAZY_XT", "1") != "0"
     overlap_maps = os.environ.get("LIDIFF_OVERLAP_MAPS", "1") not in ("0", "lazy")
     eager_maps = os.environ.get("LIDIFF_OVERLAP_MAPS", "1") != "lazy"      # False: maps are built when a layer first asks
 
     def _streams(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
+            self._side2 = torch.cuda.Stream(device=self.device)     # second side stream: the matches next to the kernel maps
         return torch.cuda.current_stream(self.device), self._side
 
     def prepare(self, field, tail_maps=True, also=None, up_orders=False):
@@ -108,7 +114,8 @@ class DiffCompletion(nn.Module):
                 field._keep = field.sparse()
                 field.coordinate_manager.prebuild(tail_maps=tail_maps, up_orders=up_orders)
                 if also is not None:
-                    also(field)
+                    for ts in sorted(field.coordinate_manager.maps):
+                        also(field, ts)
             return field
         main, side = self._streams()
         if field.ready is None:                      # produced on the main stream just now
@@ -116,22 +123,48 @@ class DiffCompletion(nn.Module):
             field.ready.record(main)
         side.wait_event(field.ready)
         with torch.cuda.stream(side), torch.no_grad():
+            self._stamp("prepare: enter")
             sp = field.sparse()
-            field.coordinate_manager.prebuild(tail_maps=tail_maps, up_orders=up_orders)
+            self._stamp("prepare: voxelised")
+            joined = None
             if also is not None:
-                also(field)
+                # `also(field, ts)` (the part -> full match of one level: a brute-force search, five of them ~1.1 ms) needs
+                # coordinates only: each level's search is queued on a second side stream as soon as that level's map exists,
+                # NEXT TO the rest of the strided maps, the kernel maps, tail maps and up orders of this stream.  The chain behind
+                # x_t's points is what the network waits for once the condition encoders are through (tools/debug/chain_probe.py:
+                # 2.45 ms in series on an idle GPU, of which the searches are 1.14).
+                mgr, ts = field.coordinate_manager, 1
+                while True:
+                    forked = torch.cuda.Event()
+                    forked.record(side)
+                    self._side2.wait_event(forked)
+                    with torch.cuda.stream(self._side2):
+                        also(field, ts)
+                    if ts == 16:
+                        break
+                    ts = mgr.stride(ts, 2)
+                joined = torch.cuda.Event()
+                joined.record(self._side2)
+                self._stamp("prepare: strides + matches queued")
+            field.coordinate_manager.prebuild(tail_maps=tail_maps, up_orders=up_orders)
+            self._stamp("prepare: maps built")
+            if joined is not None:
+                side.wait_event(joined)
             field.prepared = torch.cuda.Event()
             field.prepared.record(side)
         field._keep = sp
         return field
 
-    def _match_levels(self, field, parts):
+    def _match_level(self, field, parts, ts):
         mgr = field.coordinate_manager
-        empty = torch.empty((0, 0), device=self.device)
         for part in parts:
             if part.C.shape[0] > 1:                  # a one-voxel part (the unconditional branch) needs no match
-                for ts in sorted(mgr.maps):
-                    self.model.match_index(ME.SparseTensor(empty, tensor_stride=ts, coordinate_manager=mgr), part)
+                self.model.match_index(ME.SparseTensor(self._empty(), tensor_stride=ts, coordinate_manager=mgr), part)
+
+    def _empty(self):
+        if getattr(self, "_empty_t", None) is None:
+            self._empty_t = torch.empty((0, 0), device=self.device)
+        return self._empty_t
 
     def _adopt(self, field):
         """Make a prepared field's tensors safe to use on the current stream."""
@@ -145,8 +178,14 @@ class DiffCompletion(nn.Module):
             field.ready = torch.cuda.Event()         # consumed: a later prepare() of the same field is a no-op anyway
         return field
 
+    # The encoders of the NEXT step's conditions and (with next_t) its conditioning tables, queued on the side stream under this
+    # step's UNet as well (round 3).  Nothing is cached: every step still rebuilds its conditions from the points and encodes them
+    # (pipeline:86-90,140-146) -- the work is only issued one step ahead, where ~150 launches that cannot fill the chip (3.2 ms on
+    # the main stream, profiles/r03_step_timeline.txt) run beside convolutions that can.  Off: LIDIFF_ENCODE_AHEAD=0.
+    encode_ahead = os.environ.get("LIDIFF_ENCODE_AHEAD", "1") != "0"
+
     # pipeline:86-90
-    def reset_partial_pcd(self, x_part, x_uncond):
+    def reset_partial_pcd(self, x_part, x_uncond, next_t=None):
         if not self.overlap_maps or x_part.F.device.type != "cuda":
             x_part = self.points_to_tensor(x_part.F.reshape(1, -1, 3).detach())
             x_uncond = self.points_to_tensor(torch.zeros_like(x_part.F.reshape(1, -1, 3)))
@@ -169,6 +208,18 @@ class DiffCompletion(nn.Module):
             x_uncond = self.points_to_tensor(torch.zeros_like(pts))
             self.prepare(x_part)
             self.prepare(x_uncond, tail_maps=False)       # one voxel: nothing to gain from tail maps
+            if (self.encode_ahead and self.pair_cfg and not self.cache_condition
+                    and getattr(self, "_warm_state", None) == self._encoder_state() and not self.partial_enc.training):
+                # (only while the encoder's weights are the ones a main-stream pass has packed / folded: _encoder_state)
+                with torch.no_grad():
+                    parts = (self.partial_enc(x_part), self.partial_enc(x_uncond))
+                    cond = None
+                    if next_t is not None:
+                        t = torch.full((1,), int(next_t), dtype=torch.int64, device=self.device)
+                        cond = self.model.precompute_conditioning(parts, t)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                x_part._encoded = (parts, cond, None if next_t is None else int(next_t), done, x_uncond)
         return x_part, x_uncond
 
     # pipeline:92-105
@@ -229,6 +280,22 @@ class DiffCompletion(nn.Module):
         return ver, ptrs, self.partial_enc.training
 
     def encode_conditions(self, x_cond, x_uncond):
+        ahead = getattr(x_cond, "_encoded", None)
+        if ahead is not None and ahead[4] is x_uncond:
+            # encoded one step ahead on the side stream (reset_partial_pcd): join, hand the tensors over to this stream
+            parts, cond, t_next, done, _ = ahead
+            x_cond._encoded = None
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(done)
+            self._adopt(x_cond), self._adopt(x_uncond)
+            for q in parts:
+                q.F.record_stream(main)
+            if cond is not None:
+                for v in cond.values():
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(main)
+            self._cond_ahead = (cond, t_next, parts)
+            return parts
         with torch.no_grad():
             self.prepare(x_cond)                     # no-ops for fields reset_partial_pcd has prepared already
             self.prepare(x_uncond, tail_maps=False)
@@ -256,6 +323,12 @@ class DiffCompletion(nn.Module):
 
     # tools/debug/step_timeline.py: a list here collects (step start, conditions encoded, x_t adopted, network done) events
     timeline = None
+    host_stamps = None          # tools/debug/step_timeline.py --host: (label, time.perf_counter()) of the host thread
+
+    def _stamp(self, label):
+        if self.host_stamps is not None:
+            import time
+            self.host_stamps.append((label, time.perf_counter()))
 
     def _mark(self, marks):
         if marks is not None:
@@ -263,8 +336,11 @@ class DiffCompletion(nn.Module):
             e.record(torch.cuda.current_stream(self.device))
             marks.append(e)
 
-    def classfree_forward(self, x_t, x_cond, x_uncond, t, parts=None):
+    def classfree_forward(self, x_t, x_cond, x_uncond, t, parts=None, t_host=None):
+        """t_host: the timestep as a host integer when the caller has it (saves nothing but lets the tables that were computed
+        one step ahead be matched to this step without reading t back from the device)."""
         marks = [] if self.timeline is not None else None
+        self._stamp("step: enter")
         self._mark(marks)
         if self.overlap_maps and x_t.F.device.type == "cuda":
             self._step_start = torch.cuda.Event()
@@ -276,16 +352,46 @@ class DiffCompletion(nn.Module):
                 if parts is None:
                     parts = self.encode_conditions(x_cond, x_uncond)      # queued on the main stream ...
                 self._mark(marks)
+                self._stamp("step: conditions")
                 # the conditioning tables of all eight levels need only the latents and t: queued now, while the host still has
                 # a lead over the GPU (prepare() below blocks it on the map sizes of x_t)
-                cond = self.model.precompute_conditioning(parts, t)
+                ahead, self._cond_ahead = getattr(self, "_cond_ahead", None), None
+                if ahead is not None and ahead[0] is not None and ahead[2] is parts and t_host is not None and ahead[1] == int(t_host):
+                    cond = ahead[0]                  # computed with the encoders, one step ahead
+                else:
+                    cond = self.model.precompute_conditioning(parts, t)
                 # ... x_t's maps meanwhile, on the side stream -- and the part -> full matches of every level, which need
                 # only coordinates (the condition's coarsest map and x_t's maps), not the encoders' features
-                self.prepare(x_t, also=lambda f: self._match_levels(f, parts), up_orders=minknet._UP_ORDERED)
-                x_t_sparse = self._adopt(x_t).sparse()
+                lazy = (self.lazy_x_t and self.overlap_maps and self.eager_maps and x_t.F.device.type == "cuda"
+                        and x_t.prepared is None and getattr(x_t, "_keep", None) is None and x_t.inverse_mapping is None)
+                if lazy:
+                    main, side = self._streams()
+                    if x_t.ready is None:
+                        x_t.ready = torch.cuda.Event()
+                        x_t.ready.record(main)
+                    x_t.F.record_stream(side), x_t.C.record_stream(side)
+                    mgr = x_t.coordinate_manager
+                    mgr.set_async(side, self._side2, ready=x_t.ready, on_level=lambda ts: self._match_level(x_t, parts, ts))
+                    try:
+                        x_t_sparse = x_t.sparse()
+                        self._mark(marks)
+                        self._stamp("step: x_t voxelised")
+                        e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t, cond=cond)
+                    finally:
+                        mgr.clear_async()
+                    # everything the side streams allocated for this field is read on this stream until the step ends
+                    mgr.record_stream(main)
+                    for tt in (x_t_sparse.F, x_t.inverse_mapping):
+                        tt.record_stream(main)
+                else:
+                    self.prepare(x_t, also=lambda f, ts: self._match_level(f, parts, ts), up_orders=minknet._UP_ORDERED)
+                    self._stamp("step: x_t prepared")
+                    x_t_sparse = self._adopt(x_t).sparse()
+                    self._mark(marks)
+                    self._stamp("step: adopted")
+                    e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t, cond=cond)
                 self._mark(marks)
-                e_cond, e_uncond = self.model(x_t, x_t_sparse, parts, t, cond=cond)
-                self._mark(marks)
+                self._stamp("step: network queued")
                 if marks is not None:
                     self.timeline.append(marks)
                 e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
@@ -296,25 +402,27 @@ class DiffCompletion(nn.Module):
         e_uncond = self.forward(x_t, x_t_sparse, x_uncond, t)
         return e_uncond + self.w_uncond * (e_cond - e_uncond)
 
-    def denoise_step(self, x_init, x_t, x_cond, x_uncond, t_int: int, noise=None, parts=None):
+    def denoise_step(self, x_init, x_t, x_cond, x_uncond, t_int: int, noise=None, parts=None, next_t=None):
         """One iteration of completion_loop (pipeline:158-167): CFG network pair, DPM-Solver++
         update on the per-point offsets, re-voxelisation of x_t and the two conditions (`parts`: the
         encoded conditions of a cache_condition run, which then skips their re-voxelisation too)."""
         t = torch.full((1,), t_int, dtype=torch.int64, device=self.device)
-        noise_t = self.classfree_forward(x_t, x_cond, x_uncond, t, parts)
+        noise_t = self.classfree_forward(x_t, x_cond, x_uncond, t, parts, t_host=t_int)
         input_noise = x_t.F.reshape(t.shape[0], -1, 3) - x_init
         x_new = x_init + self.dpm_scheduler.step(noise_t, t_int, input_noise, noise=noise)["prev_sample"]
         x_t = self.points_to_tensor(x_new)
         if parts is None:
-            x_cond, x_uncond = self.reset_partial_pcd(x_cond, x_uncond)
+            x_cond, x_uncond = self.reset_partial_pcd(x_cond, x_uncond, next_t=next_t)
         return x_t, x_cond, x_uncond
 
     # pipeline:155-169
     def completion_loop(self, x_init, x_t, x_cond, x_uncond, noises=None):
         parts = self.encode_conditions(x_cond, x_uncond) if self.cache_condition and self.pair_cfg else None
-        for i, t_int in enumerate(self.dpm_scheduler.host_timesteps):
+        ts = self.dpm_scheduler.host_timesteps
+        for i, t_int in enumerate(ts):
             x_t, x_cond, x_uncond = self.denoise_step(x_init, x_t, x_cond, x_uncond, t_int,
-                                                      None if noises is None else noises[i], parts)
+                                                      None if noises is None else noises[i], parts,
+                                                      next_t=ts[i + 1] if i + 1 < len(ts) else None)
         x_t.coordinate_manager.check()
         return x_t.F.cpu().detach().numpy()
 

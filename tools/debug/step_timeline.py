@@ -26,6 +26,7 @@ if __name__ == "__main__":
             bench.run_steps(pipe, x_init, xs[:2], tvals[:2], w, 1)
         torch.cuda.synchronize()
         pipe.timeline = []
+        pipe.host_stamps = []
         t0 = time.perf_counter()
         bench.run_steps(pipe, x_init, xs, tvals, 0, a.steps)
         torch.cuda.synchronize()
@@ -37,3 +38,16 @@ if __name__ == "__main__":
           f"UNet {seg[:, 2].mean():.2f}  between steps (scheduler, next field) {between.mean():.2f} ms")
     for j, r in enumerate(seg):
         print(f"  step {j} (t={tvals[j]}): encoders {r[0]:.2f}  wait {r[1]:.2f}  UNet {r[2]:.2f}")
+    # host thread: where its time goes between the stamps (ms, averaged over the steps after the first two)
+    st = pipe.host_stamps
+    seg = {}
+    order = []
+    for (la, ta), (lb, tb) in zip(st, st[1:]):
+        k = f"{la} -> {lb}"
+        if k not in seg:
+            order.append(k)
+        seg.setdefault(k, []).append((tb - ta) * 1e3)
+    print("host thread (ms per occurrence, mean over all occurrences):")
+    for k in order:
+        v = seg[k]
+        print(f"  {k:<70} {np.mean(v[2:] if len(v) > 4 else v):7.3f}  x{len(v)}")

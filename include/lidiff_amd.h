@@ -28,13 +28,14 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 18
+#define LIDIFF_ABI_VERSION 19
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
 #define LIDIFF_CONV_DENSE_KERNEL 2  /* lidiff_spconv_fwd flags: software-pipelined kernel for the dense 128-column layers */
 #define LIDIFF_CONV_DENSE_ONE_WAVE 4 /* ... in its four-wave form (one wave per SIMD, 32 columns per wave) */
+#define LIDIFF_CONV_TILE_ONLY 8     /* identity maps (nbr == NULL) through the tile kernel as well, not the row kernel (A/B measurements, tests) */
 
 int lidiff_abi_version(void);
 const char* lidiff_last_error(void);
@@ -166,6 +167,10 @@ int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int3
  *   software-pipelined kernel (spconv_dense.hip: ring of four LDS-DMA images requested three stages ahead, counted
  *   vmcnt barrier, fragments read one stage ahead); bit-identical results, same speed as the tile kernels on the
  *   bench workload -- kept selectable, not the default.
+ *   Identity maps (nbr == NULL, no row order; channel widths multiples of 16 with c_in in {32, 64, 96, 128, 192}, c_out a
+ *   multiple of 32) run as a streaming row GEMM (spconv_rows.hip: W column tile resident in LDS, rows straight from HBM
+ *   into the MFMA operands, no barrier, 16-byte stores) with bit-identical results; LIDIFF_CONV_TILE_ONLY keeps them on
+ *   the tile kernel.  lidiff_spconv_fwd_kernel_id answers which kernel a call will take.
  * tail / tail_ptr / tail_idx (all null, or all set): rows added to the convolution sum BEFORE the epilogue through a
  *   CSR over the output rows: out[o] += sum over q in [tail_ptr[o], tail_ptr[o+1]) of tail[tail_idx[q], :]
  *   (tail [replicas * tail_rows, c_out]).  This is how a low-density kernel_size-3 map (stride-1 / 2 levels of a noisy
@@ -181,6 +186,27 @@ int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int3
                       int32_t relu, const int32_t* row_order, int32_t replicas, int32_t flags,
                       const float* tail, const int32_t* tail_ptr, const int32_t* tail_idx, int64_t tail_rows,
                       void* stream);
+
+/* Which kernel lidiff_spconv_fwd runs for these arguments: 0 = tile kernel (spconv.hip), 1 = dense kernel (spconv_dense.hip),
+ * 2 = row kernel (spconv_rows.hip).  has_nbr / has_row_order: whether those pointers are non-null.  For profilers and tests. */
+int32_t lidiff_spconv_fwd_kernel_id(int32_t c_in_a, int32_t c_in_b, int32_t c_out, int32_t k_vol, int32_t has_nbr,
+                                    int32_t has_row_order, int32_t flags);
+
+/* Sparse convolution forward over a map in which every output row has exactly ONE pair, given as a pair list grouped by
+ * kernel offset (ME-layout rulebook, lidiff_rulebook_compact): for p in [offset_ptr[k], offset_ptr[k+1])
+ *     out[pair_out[p], :] = epilogue( [in_a | in_b][pair_in[p], :] @ w[k] )          (pair_out == NULL: out row p)
+ * -- MinkowskiConvolutionTranspose with kernel_size 2 / stride 2 (minkunet.py:36: every fine voxel has one parent) and the
+ * tail pass of the centre + tail scheme above (one output row per pair, pair_out == NULL, m_out == n_pairs).  A streaming
+ * row GEMM (spconv_rows.hip): the offset's W column tile resident in LDS, gathered rows straight from HBM into the MFMA
+ * operands, 16-byte stores; results bit-identical to lidiff_spconv_fwd over the same map.  Input widths multiples of 16
+ * summing to 32 / 64 / 96 / 128, c_out a multiple of 32 (lidiff_spconv_fwd_pairs_supported answers 1 / 0); epilogue and
+ * replicas as lidiff_spconv_fwd (m_in / m_out per replica; the pair list is shared). */
+int32_t lidiff_spconv_fwd_pairs_supported(int32_t c_in_a, int32_t c_in_b, int32_t c_out);
+int lidiff_spconv_fwd_pairs(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b, const float* w_packed,
+                            int32_t k_vol, const int32_t* pair_in, const int32_t* pair_out, const int32_t* offset_ptr,
+                            int64_t n_pairs, int64_t m_in, int64_t m_out, int32_t c_out, float* out,
+                            const float* ep_scale, const float* ep_shift, const float* residual, int32_t relu,
+                            int32_t replicas, void* stream);
 
 /* lidiff_spconv_fwd with bf16 matrix operands and fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Features, BatchNorm and
  * the epilogue stay fp32 in HBM; each gathered input value is cut into `planes` bf16 pieces (round to nearest even:

@@ -194,9 +194,17 @@ class CoordinateManager:
                 # the ME-layout rulebook of the map lists its pairs by offset, then by output row: its output-row column IS the
                 # order (one pair per row => a permutation), built by three small kernels without a host read
                 with self.building():
-                    _, order, _ = ops.rulebook_compact(nbr, total=nbr.shape[1])
+                    pin, order, off = ops.rulebook_compact(nbr, total=nbr.shape[1])
                     self.aux[key] = (nbr.index_select(1, order.long()).contiguous(), order)
+                    self.aux[("up_pairs", ts_in, ts_out)] = (pin, order, off)
         return self.aux[key]
+
+    def up_pairs(self, ts_in: int, ts_out: int):
+        """The same map as a pair list grouped by offset -- (input row, output row, offset_ptr [9]) -- for
+        ops.spconv_fwd_pairs (one pair per output row: the map IS its rulebook), or None for small maps."""
+        if self.up_order(ts_in, ts_out) is None:
+            return None
+        return self.aux[("up_pairs", ts_in, ts_out)]
 
     def is_sparse_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False, c_out: int = 128) -> bool:
         """Performance hint for lidiff_spconv_fwd (LIDIFF_CONV_SPARSE_MAP), from voxel counts the host already
@@ -264,7 +272,7 @@ class CoordinateManager:
                 if isinstance(t, torch.Tensor):
                     out.append(t)
                 elif isinstance(t, ops.TailMap):
-                    out += [q for q in (t.ptr, t.nbr, t.idx) if q is not None]
+                    out += [q for q in (t.ptr, t.nbr, t.idx, t.pair_in, t.off) if q is not None]
         return out
 
     def record_stream(self, stream):

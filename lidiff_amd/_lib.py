@@ -39,6 +39,10 @@ SIGNATURES = {
     "lidiff_spconv_pack_weights": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
     "lidiff_spconv_fwd": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i32, _i32,
                                  _p, _p, _p, _i64, _p]),
+    "lidiff_spconv_fwd_kernel_id": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "lidiff_spconv_fwd_pairs_supported": (_i32, [_i32, _i32, _i32]),
+    "lidiff_spconv_fwd_pairs": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _i32,
+                                       _i32, _p]),
     "lidiff_spconv_packed_weight_bf16_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "lidiff_spconv_pack_weights_bf16": (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "lidiff_spconv_fwd_bf16": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p]),
@@ -61,7 +65,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 
 

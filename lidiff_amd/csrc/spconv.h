@@ -56,4 +56,8 @@ __global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n, int 
 bool dense_kernel_applies(const ConvParams& p);
 int launch_fwd_dense(const ConvParams& p, hipStream_t st);
 
+// spconv_rows.hip: identity maps (kernel_size 1 / the centre pass) as a streaming row GEMM.
+bool rows_kernel_applies(const ConvParams& p);
+int launch_fwd_rows(const ConvParams& p, hipStream_t st);
+
 }  // namespace lidiff

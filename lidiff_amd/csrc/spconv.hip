@@ -710,6 +710,18 @@ extern "C" int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t
     return 0;
 }
 
+extern "C" int32_t lidiff_spconv_fwd_kernel_id(int32_t c_in_a, int32_t c_in_b, int32_t c_out, int32_t k_vol, int32_t has_nbr,
+                                               int32_t has_row_order, int32_t flags) {
+    static const int32_t some = 0;                       // any non-null address: only nullness is looked at
+    ConvParams p{};
+    p.nbr = has_nbr ? &some : nullptr; p.row_order = has_row_order ? &some : nullptr;
+    p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out; p.k_vol = k_vol; p.flags = flags;
+    p.m_in = p.m_out = 1;
+    if (!(flags & LIDIFF_CONV_TILE_ONLY) && rows_kernel_applies(p)) return 2;
+    if ((flags & LIDIFF_CONV_DENSE_KERNEL) && dense_kernel_applies(p)) return 1;
+    return 0;
+}
+
 extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
                                  const float* w_packed, const int32_t* nbr, int32_t k_vol, int64_t m_in,
                                  int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
@@ -742,6 +754,8 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     LIDIFF_CHECK_ARG(c_in_b == 0 || c_in_a % 32 == 0, "with two inputs c_in_a must be a multiple of 32 (slab size)");
     const bool vec = c_in_a % 32 == 0 && c_in_b % 32 == 0 && al16(in_a) && al16(in_b);   // else: scalar gather
     hipStream_t st = (hipStream_t)stream;
+    // identity maps: consecutive rows, one offset -- the streaming row GEMM of spconv_rows.hip (bit-identical results)
+    if (!(flags & LIDIFF_CONV_TILE_ONLY) && al16(in_a) && al16(in_b) && rows_kernel_applies(p)) return launch_fwd_rows(p, st);
     // dense 128-column layers: the software-pipelined kernel of spconv_dense.hip on request (bit-identical results,
     // measured equal to the tile kernels below on the bench workload: DESIGN.md section 4.2)
     if ((flags & LIDIFF_CONV_DENSE_KERNEL) && dense_kernel_applies(p)) return launch_fwd_dense(p, st);

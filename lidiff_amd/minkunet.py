@@ -109,6 +109,13 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
         hit = mgr.up_order(x.tensor_stride, ts_out)
         if hit is not None:
             (nbr, order), hint = hit, False
+            if ops.pairs_kernel_applies(x.F.shape[1], 0 if extra is None else extra.shape[1], conv.out_channels):
+                pin, pout, off = mgr.up_pairs(x.tensor_stride, ts_out)       # one pair per output row: the streaming row kernel
+                f = ops.spconv_fwd_pairs(x.F, conv.kernel, pin, pout, off, m_out, in_b=extra, scale=scale, shift=shift,
+                                         residual=residual, relu=relu, replicas=x.replicas)
+                out = ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
+                out.replicas = x.replicas
+                return out
     # centre + tail only on really isolated voxels (<= ~2 neighbours each: the 128-column rule of is_sparse_map); the wider
     # hint of the narrow tiles keeps the one-launch kernel with packed stages (3.6 neighbours per voxel: 429 vs 495 us)
     if (_CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and m_out >= 1024

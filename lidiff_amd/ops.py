@@ -246,12 +246,15 @@ DETERMINISTIC_DW = True
 # Kernel choice for the dense 128-column layers: "tile" (spconv.hip, default), "dense" (spconv_dense.hip, eight waves),
 # "dense1" (its four-wave form).  Results are bit-identical; DESIGN.md section 4.2 has the measurements.
 DENSE_KERNEL = os.environ.get("LIDIFF_CONV_KERNEL", "tile")
-# extra lidiff_spconv_fwd flag bits (include/lidiff_amd.h LIDIFF_CONV_*), e.g. 8 = LIDIFF_CONV_SKEW
+# extra lidiff_spconv_fwd flag bits (include/lidiff_amd.h LIDIFF_CONV_*), e.g. 8 = LIDIFF_CONV_TILE_ONLY
 CONV_FLAGS = int(os.environ.get("LIDIFF_CONV_FLAGS", "0"))
 
 
-def conv_variant(c_out: int) -> str:
-    """Which template instantiation lidiff_spconv_fwd dispatches to (BN = output-channel tile)."""
+def conv_variant(c_out: int, kernel_id: int = 0) -> str:
+    """Which kernel / template instantiation lidiff_spconv_fwd dispatches to (BN = output-channel tile of the tile kernel;
+    "rows" = the streaming row kernel of identity maps, lidiff_spconv_fwd_kernel_id == 2)."""
+    if kernel_id == 2:
+        return "rows"
     return ("bn128" if c_out % 128 == 0 else "bn96" if c_out % 96 == 0 else "bn64" if c_out % 64 == 0
             else "bn32" if c_out % 32 == 0 else "bn16")
 
@@ -309,7 +312,8 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     [R * M_in, C], the result [R * m_out, C_out].
     row_order: int32 permutation of the output rows (tile_order()); `nbr` must then hold its columns in that
     order (nbr[:, row_order]).  Results do not depend on it.
-    kernel: "tile" | "dense" | "dense1" (default: DENSE_KERNEL) -- which kernel runs a dense 128-column layer.
+    kernel: "tile" | "dense" | "dense1" (default: DENSE_KERNEL) -- which kernel runs a dense 128-column layer;
+    "tile_only" keeps identity maps off the row kernel (spconv_rows.hip) as well.
     offset: convolve with the single kernel offset w[offset] over the identity map (nbr must be None): the centre of a
     kernel_size-3 map.  tail = (rows [R * P, C_out], ptr int32 [m_out + 1], idx int32 [P]): rows added to the sum before
     the epilogue, out[o] += sum(rows[idx[ptr[o]:ptr[o + 1]]]) -- the other offsets' contributions (TailMap)."""
@@ -352,20 +356,70 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert t_rows.shape == (replicas * n_tail, c_out) and t_rows.is_contiguous() and t_rows.dtype == torch.float32
         assert t_ptr.dtype == torch.int32 and t_ptr.shape == (m_out + 1,) and t_idx.dtype == torch.int32
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
+    flags = int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6, "tile_only": 8}[kernel or DENSE_KERNEL] | CONV_FLAGS
     prof = PROFILER
-    timed = prof is not None and prof.wants(conv_variant(c_out))
+    variant = None
+    if prof is not None:
+        variant = conv_variant(c_out, _lib.load().lidiff_spconv_fwd_kernel_id(c_a, c_b, c_out, k, int(nbr is not None),
+                                                                             int(row_order is not None), flags))
+    timed = prof is not None and prof.wants(variant)
     start = end = None
     if timed:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
-         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas),
-         int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6}[kernel or DENSE_KERNEL] | CONV_FLAGS,
+         c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas), flags,
          ptr(t_rows), ptr(t_ptr), ptr(t_idx), n_tail, stream_ptr())
     if timed:
         end.record()
     if prof is not None:
-        prof.launches.append((conv_variant(c_out), start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
+        prof.launches.append((variant, start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
+    return out
+
+
+def pairs_kernel_applies(c_a: int, c_b: int, c_out: int) -> bool:
+    """Shapes lidiff_spconv_fwd_pairs takes (input widths multiples of 16 summing to 32 / 64 / 96 / 128, C_out % 32 == 0)."""
+    return bool(_lib.load().lidiff_spconv_fwd_pairs_supported(c_a, c_b, c_out)) and not (CONV_FLAGS & 8)
+
+
+def spconv_fwd_pairs(in_a: torch.Tensor, w: torch.Tensor, pair_in: torch.Tensor, pair_out: torch.Tensor | None,
+                     offset_ptr: torch.Tensor, m_out: int, in_b: torch.Tensor | None = None, scale=None, shift=None,
+                     residual=None, relu: bool = False, replicas: int = 1) -> torch.Tensor:
+    """Sparse convolution over a map in which every output row has exactly ONE pair, given as a pair list grouped by kernel
+    offset (lidiff_spconv_fwd_pairs; include/lidiff_amd.h): out[pair_out[p]] = epilogue(in[pair_in[p]] @ w[offset of p]),
+    offset_ptr [K + 1] the pair ranges of the offsets; pair_out None = one output row per pair, in list order (then m_out ==
+    number of pairs).  The transposed kernel_size-2 / stride-2 convolutions (MinkowskiConvolutionTranspose, minkunet.py:36) and
+    the tail pass of spconv_centre_tail.  Same epilogue / replica arguments as spconv_fwd; bit-identical results."""
+    require_device(in_a, w, pair_in, pair_out, offset_ptr, in_b, scale, shift, residual)
+    wp = packed_weights(w)
+    k, c_in, c_out = w.shape
+    in_a = in_a.contiguous()
+    c_a, c_b = in_a.shape[1], 0
+    if in_b is not None:
+        in_b = in_b.contiguous()
+        c_b = in_b.shape[1]
+    assert c_a + c_b == c_in and in_a.shape[0] % replicas == 0
+    m_in = in_a.shape[0] // replicas
+    n = pair_in.shape[0]
+    assert pair_in.dtype == torch.int32 and offset_ptr.dtype == torch.int32 and offset_ptr.shape == (k + 1,)
+    assert pair_out is None or (pair_out.dtype == torch.int32 and pair_out.shape == (n,))
+    assert pair_out is not None or m_out == n
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == (replicas * m_out, c_out)
+    out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
+    prof = PROFILER
+    timed = prof is not None and prof.wants("rows")
+    start = end = None
+    if timed:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+    call("lidiff_spconv_fwd_pairs", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), k, ptr(pair_in), ptr(pair_out), ptr(offset_ptr),
+         n, m_in, m_out, c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), stream_ptr())
+    if timed:
+        end.record()
+    if prof is not None:
+        prof.launches.append(("rows", start, end, m_in, m_out, c_in, c_out, k, None, replicas))
     return out
 
 
@@ -725,12 +779,14 @@ class TailMap:
         self.ptr = torch.empty(m + 1, dtype=torch.int32, device=dev)
         call("lidiff_tail_map", ptr(nbr), k, m, 13, ptr(off), ptr(self.ptr), 0, None, None, ptr(ws), stream_ptr())
         self.n = int(off[-1].item())                                     # the one host read of this map
-        self.nbr = self.idx = None
+        self.nbr = self.idx = self.pair_in = None
+        self.off = off                                                   # [28] pair ranges of the offsets (13: empty)
         if self.n:
             self.nbr = torch.empty((k, self.n), dtype=torch.int32, device=dev)
             self.idx = torch.empty(self.n, dtype=torch.int32, device=dev)
             call("lidiff_tail_map", ptr(nbr), k, m, 13, ptr(off), ptr(self.ptr), self.n, ptr(self.nbr), ptr(self.idx),
                  ptr(ws), stream_ptr())
+            self.pair_in = self.nbr.amax(0)                              # the pair list form of the same map (one entry per column)
 
 
 # (The centre pass keeps the narrow 3 x 2 / 4 x 2 wave grids of the hinted maps: the 96-column tile of the dense family, which
@@ -742,6 +798,10 @@ def spconv_centre_tail(in_a, w, tmap: TailMap, m_out, **kw):
     replicas = kw.get("replicas", 1)
     tail = None
     if tmap.n > 0:
-        rows = spconv_fwd(in_a, w, tmap.nbr, tmap.n, in_b=kw.get("in_b"), replicas=replicas)
+        in_b = kw.get("in_b")
+        if pairs_kernel_applies(in_a.shape[1], 0 if in_b is None else in_b.shape[1], w.shape[-1]):
+            rows = spconv_fwd_pairs(in_a, w, tmap.pair_in, None, tmap.off, tmap.n, in_b=in_b, replicas=replicas)
+        else:
+            rows = spconv_fwd(in_a, w, tmap.nbr, tmap.n, in_b=in_b, replicas=replicas)
         tail = (rows, tmap.ptr, tmap.idx)
     return spconv_fwd(in_a, w, None, m_out, tail=tail, offset=13, **kw)

@@ -573,6 +573,124 @@ def test_spconv_dense_kernel_is_bit_identical_to_the_tile_kernel(device, kernel)
             assert torch.allclose(got[:m].cpu().double(), want, rtol=RTOL, atol=ATOL), (kind, cin, split, cout)
 
 
+ROW_KERNEL_SHAPES = [(32, 0, 32), (32, 0, 64), (64, 0, 64), (64, 0, 128), (96, 0, 96), (96, 64, 96), (128, 96, 96),
+                     (128, 0, 128), (128, 0, 256), (192, 128, 128), (64, 32, 32), (192, 0, 96)]
+
+
+@pytest.mark.parametrize("cin,split,cout", ROW_KERNEL_SHAPES)
+def test_spconv_row_kernel_is_bit_identical_to_the_tile_kernel(device, cin, split, cout):
+    """spconv_rows.hip (identity maps as a streaming row GEMM: W tile in LDS, rows from HBM straight into the MFMA
+    operands, transposed product, 16-byte stores) on every input width it accepts -- row counts of 1, 15, 16, 17 and
+    thousands (ragged last block, fewer blocks than waves, several blocks per wave), fused ME.cat, replicas 1 / 2, every
+    epilogue combination, the centre pass with tail rows through the CSR -- bit for bit against the tile kernel (same MFMA
+    sequence per output, same tail order) and against the float64 oracle."""
+    from lidiff_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    lib = _lib.load()
+    assert lib.lidiff_spconv_fwd_kernel_id(split or cin, cin - split if split else 0, cout, 1, 0, 0, 0) == 2
+    assert lib.lidiff_spconv_fwd_kernel_id(split or cin, cin - split if split else 0, cout, 1, 0, 0, 8) == 0      # TILE_ONLY
+    assert lib.lidiff_spconv_fwd_kernel_id(split or cin, cin - split if split else 0, cout, 1, 0, 1, 0) == 0      # row order
+    assert lib.lidiff_spconv_fwd_kernel_id(split or cin, cin - split if split else 0, cout, 27, 1, 0, 0) == 0     # a real map
+    w = torch.randn(cin, cout, generator=g) / np.sqrt(cin)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    for m, reps, epi in ((1, 1, 0), (15, 2, 1), (16, 1, 2), (17, 2, 3), (4099, 2, 3), (70001, 1, 3), (33333, 2, 0)):
+        x = torch.randn(reps * m, cin, generator=g)
+        res = torch.randn(reps * m, cout, generator=g)
+        xd = x.to(device)
+        a = xd[:, :split].contiguous() if split else xd
+        kw = dict(in_b=xd[:, split:].contiguous() if split else None, replicas=reps,
+                  scale=sc.to(device) if epi & 1 else None, shift=sh.to(device) if epi & 1 else None,
+                  residual=res.to(device) if epi & 2 else None, relu=bool(epi & 2))
+        got = ops.spconv_fwd(a, w.to(device), None, m, **kw)
+        ref = ops.spconv_fwd(a, w.to(device), None, m, kernel="tile_only", **kw)
+        assert torch.equal(got, ref), (m, reps, epi, (got - ref).abs().max().item())
+        want = x.double() @ w.double()
+        if epi & 1:
+            want = want * sc.double() + sh.double()
+        if epi & 2:
+            want = torch.relu(want + res.double())
+        assert torch.allclose(got.cpu().double(), want, rtol=RTOL, atol=ATOL), (m, reps, epi)
+    # the centre pass of a kernel_size-3 map with its tail rows
+    for cloud in (random_cloud(6000, 40, 11, batch=2, dup=0.05), random_cloud(1500, 4, 13)):
+        uniq, _, _ = me.voxelize(cloud)
+        nbr = dev_i32(me.kernel_map(uniq, uniq, 3, 1), device)
+        m = uniq.shape[0]
+        tmap = ops.TailMap(nbr)
+        assert tmap.n > 0
+        w3 = (torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)).to(device)
+        x = torch.randn(2 * m, cin, generator=g).to(device)
+        a = x[:, :split].contiguous() if split else x
+        in_b = x[:, split:].contiguous() if split else None
+        rows = ops.spconv_fwd(a, w3, tmap.nbr, tmap.n, in_b=in_b, replicas=2)
+        kw = dict(in_b=in_b, replicas=2, scale=sc.to(device), shift=sh.to(device), relu=True, tail=(rows, tmap.ptr, tmap.idx),
+                  offset=13)
+        got = ops.spconv_fwd(a, w3, None, m, **kw)
+        assert torch.equal(got, ops.spconv_fwd(a, w3, None, m, kernel="tile_only", **kw))
+
+
+@pytest.mark.parametrize("cin,split,cout", [(32, 0, 32), (64, 0, 64), (96, 0, 96), (128, 96, 96), (128, 0, 128), (64, 32, 128),
+                                            (128, 0, 256)])
+def test_spconv_pair_list_kernel_is_bit_identical_to_the_tile_kernel(device, cin, split, cout):
+    """lidiff_spconv_fwd_pairs (spconv_rows.hip, gathered rows, one W tile per kernel offset) on the two map kinds it serves
+    -- the transposed kernel_size-2 / stride-2 map as its rulebook (every fine voxel one pair; uneven, partly EMPTY offsets
+    included) and the tail-pass map of centre + tail (one output row per pair) -- bit for bit against the tile kernel over
+    the same map (plain and offset-grouped row order), with fused ME.cat, epilogue, residual and replicas 1 / 2, and against
+    the float64 oracle."""
+    from lidiff_amd import _lib, ops
+    assert _lib.load().lidiff_spconv_fwd_pairs_supported(split or cin, cin - split if split else 0, cout) == 1
+    assert _lib.load().lidiff_spconv_fwd_pairs_supported(192, 0, 128) == 0 and _lib.load().lidiff_spconv_fwd_pairs_supported(3, 0, 32) == 0
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    st = status(device)
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).to(device), torch.randn(cout, generator=g).to(device)
+    for cloud, reps in ((random_cloud(9000, 30, 31, batch=2), 2), (random_cloud(5000, 6, 32), 1), (random_cloud(20, 40, 33), 2)):
+        fine, _, _, _ = ops.vox_unique(dev_i32(cloud, device), st)
+        coarse, parent, _ = ops.map_stride(fine, 2, st)
+        up = ops.kernel_map_up(fine, parent, 1)                        # [8, m_fine]: input rows are COARSE voxels
+        m_in, m_out = coarse.shape[0], fine.shape[0]
+        pin, pout, off = ops.rulebook_compact(up, total=m_out)
+        w = (torch.randn(8, cin, cout, generator=g) / np.sqrt(cin)).to(device)
+        x = torch.randn(reps * m_in, cin, generator=g).to(device)
+        res = torch.randn(reps * m_out, cout, generator=g).to(device)
+        a = x[:, :split].contiguous() if split else x
+        kw = dict(in_b=x[:, split:].contiguous() if split else None, scale=sc, shift=sh, residual=res, relu=True, replicas=reps)
+        got = ops.spconv_fwd_pairs(a, w, pin, pout, off, m_out, **kw)
+        ref = ops.spconv_fwd(a, w, up, m_out, sparse_map=True, **kw)
+        assert torch.equal(got, ref), (cin, cout, m_out, (got - ref).abs().max().item())
+        grouped = ops.spconv_fwd(a, w, up.index_select(1, pout.long()).contiguous(), m_out, row_order=pout, **kw)
+        assert torch.equal(got, grouped)
+        up_np = up.cpu().numpy()
+        want = me.conv_forward(x[:m_in].cpu().double(), w.cpu().double(), up_np)
+        want = torch.relu(want * sc.cpu().double() + sh.cpu().double() + res[:m_out].cpu().double())
+        assert torch.allclose(got[:m_out].cpu().double(), want, rtol=RTOL, atol=ATOL)
+    # a map whose offsets 1..7 are all empty: every fine voxel sits in the corner of its parent cell
+    even = random_cloud(3000, 20, 34)
+    even[:, 1:] *= 2
+    fine, _, _, _ = ops.vox_unique(dev_i32(even, device), st)
+    coarse, parent, _ = ops.map_stride(fine, 2, st)
+    up = ops.kernel_map_up(fine, parent, 1)
+    pin, pout, off = ops.rulebook_compact(up, total=fine.shape[0])
+    assert int((off[1:] - off[:-1] > 0).sum()) == 1
+    w = (torch.randn(8, cin, cout, generator=g) / np.sqrt(cin)).to(device)
+    x = torch.randn(coarse.shape[0], cin, generator=g).to(device)
+    a = x[:, :split].contiguous() if split else x
+    in_b = x[:, split:].contiguous() if split else None
+    assert torch.equal(ops.spconv_fwd_pairs(a, w, pin, pout, off, fine.shape[0], in_b=in_b),
+                       ops.spconv_fwd(a, w, up, fine.shape[0], in_b=in_b))
+    # the tail pass: one output row per pair, 26 uneven offsets
+    for cloud in (random_cloud(6000, 40, 11, batch=2, dup=0.05), random_cloud(1500, 4, 13)):
+        uniq, _, _ = me.voxelize(cloud)
+        nbr = dev_i32(me.kernel_map(uniq, uniq, 3, 1), device)
+        tmap = ops.TailMap(nbr)
+        w3 = (torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)).to(device)
+        x = torch.randn(2 * uniq.shape[0], cin, generator=g).to(device)
+        a = x[:, :split].contiguous() if split else x
+        in_b = x[:, split:].contiguous() if split else None
+        assert torch.equal(tmap.pair_in, tmap.nbr.amax(0)) and int(tmap.off[-1]) == tmap.n
+        got = ops.spconv_fwd_pairs(a, w3, tmap.pair_in, None, tmap.off, tmap.n, in_b=in_b, replicas=2)
+        assert torch.equal(got, ops.spconv_fwd(a, w3, tmap.nbr, tmap.n, in_b=in_b, replicas=2))
+    assert int(st.item()) == 0
+
+
 @pytest.mark.parametrize("cin,cout,split", [(32, 32, 0), (96, 96, 0), (128, 96, 96), (3, 32, 0), (64, 128, 0)])
 def test_spconv_centre_tail_vs_oracle(device, cin, cout, split):
     """Low-density kernel_size-3 maps as centre pass + tail rows (ops.TailMap / spconv_centre_tail): the pairs of the 26

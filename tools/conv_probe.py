@@ -52,7 +52,7 @@ def main():
         if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(csrc, f)) for f in
                                                                  ("spconv.hip", "spconv_dense.hip", "spconv_bf16.hip", "coords.hip", "spconv.h")):
             subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-DLIDIFF_CONV_PROBE",
-                            "-shared", os.path.join(csrc, "spconv.hip"), os.path.join(csrc, "spconv_dense.hip"),
+                            "-shared", os.path.join(csrc, "spconv.hip"), os.path.join(csrc, "spconv_dense.hip"), os.path.join(csrc, "spconv_rows.hip"),
                             os.path.join(csrc, "spconv_bf16.hip"), os.path.join(csrc, "coords.hip"), "-o", lib], check=True)
         _lib.LIB_PATH = lib
         _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))

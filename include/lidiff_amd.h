@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 19
+#define LIDIFF_ABI_VERSION 20
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -83,6 +83,17 @@ int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out,
                       int32_t* coarse, int32_t* parent,
                       int32_t* d_m, int32_t* d_status, void* workspace, void* stream);
 
+/* The *_dev variants: the same kernels with the input row count read ON THE DEVICE (d_n_rows / d_m: the count the previous
+ * level's compaction wrote), n_rows_bound / m_bound being only what the grid, the buffers and the table pitch are sized for
+ * (an upper bound: the point count bounds every level).  They let a whole pyramid -- voxelise, the strided maps, the first
+ * levels' kernel_size-3 maps and tail-map counts -- be queued without a host read in between; the host then reads all sizes
+ * in ONE copy (lidiff_amd.ops.build_pyramid; the reference reads the size of every map as it is made,
+ * diff_completion_pipeline.py:162-166 through ME's coordinate manager).  Rows / columns beyond the true count are never
+ * written; tables keep the pitch of the bound (callers compact them with a strided copy once the sizes are known). */
+int lidiff_map_stride_dev(const int32_t* coords, int64_t n_rows_bound, const int32_t* d_n_rows, int32_t s_out,
+                          uint64_t* hkeys, int32_t* hvals, int64_t cap, int32_t* coarse, int32_t* parent,
+                          int32_t* d_m, int32_t* d_status, void* workspace, void* stream);
+
 /* Kernel map (rulebook) as a neighbour table -- MinkowskiConvolution ks=3 (minkunet.py:
  * 53-66,94,97,156,159,512,515) and ks=2/stride 2 (13-29) (ME: CoordinateMapManager::
  * kernel_map).  nbr[k*m_out + o] = row of the INPUT map holding out_coords[o] +
@@ -98,6 +109,9 @@ int lidiff_kernel_map(const int32_t* out_coords, int64_t m_out,
  * identity.  Fills nbr [27, m] itself (no pre-initialisation needed). */
 int lidiff_kernel_map_self(const int32_t* coords, int64_t m, const uint64_t* hkeys, const int32_t* hvals, int64_t cap,
                            int32_t step, int32_t* nbr, void* stream);
+/* ... with the row count on the device: nbr [27, m_bound] (pitch m_bound), columns >= *d_m stay -1. */
+int lidiff_kernel_map_self_dev(const int32_t* coords, int64_t m_bound, const int32_t* d_m, const uint64_t* hkeys,
+                               const int32_t* hvals, int64_t cap, int32_t step, int32_t* nbr, void* stream);
 
 /* The kernel_size-2 / stride-2 map of a strided convolution (fine map -> its coarse map, minkunet.py:13-29) from the
  * parent array lidiff_map_stride returned: nbr_down [8, m_coarse] -- the table lidiff_kernel_map(coarse coords, fine
@@ -136,6 +150,11 @@ int64_t lidiff_rulebook_workspace_bytes(int32_t k_vol, int64_t m_out);
 int64_t lidiff_tail_map_workspace_bytes(int32_t k_vol, int64_t m_out);
 int lidiff_tail_map(const int32_t* nbr, int32_t k_vol, int64_t m_out, int32_t skip, int32_t* offset_ptr,
                     int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx, void* workspace, void* stream);
+/* ... over a table of pitch m_bound whose row count lives on the device (both phases must use the same m_bound and
+ * workspace): row_ptr [m_bound + 1], of which [0, *d_m] is the CSR. */
+int lidiff_tail_map_dev(const int32_t* nbr, int32_t k_vol, int64_t m_bound, const int32_t* d_m, int32_t skip,
+                        int32_t* offset_ptr, int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx,
+                        void* workspace, void* stream);
 
 /* Weight layout of the sparse convolution.  MinkowskiConvolution.kernel is [K, c_in, c_out] row-major
  * (minkunet.py:17,36,53,61; [c_in, c_out] for kernel_size 1, :72).  The HIP kernel consumes it in MFMA

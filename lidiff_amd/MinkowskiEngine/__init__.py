@@ -67,6 +67,9 @@ class CoordinateManager:
         self._async = None                              # (build stream, second build stream) -- set_async()
         self._ready = None                              # event: the field's points exist (recorded on the consumer's stream)
         self._on_level = None                           # callable(ts): queued on the second stream when level ts exists
+        # True: insert() builds the whole pyramid (ops.build_pyramid: voxel map, the four strided maps, the kernel_size-3
+        # maps and tail-map counts of the first two levels) with ONE host read instead of one per map.  Same maps.
+        self.pyramid = False
 
     # -- asynchronous, on-demand building (DiffCompletion, round 3) ------------------------------------------------------
     def set_async(self, side, side2, ready=None, on_level=None):
@@ -106,11 +109,36 @@ class CoordinateManager:
                 self._on_level(ts)
 
     def insert(self, coords_i32: torch.Tensor):
+        if self.pyramid:
+            return self._insert_pyramid(coords_i32)
         with self.building():
             uniq, inverse, first_idx, table = ops.vox_unique(coords_i32, self.status)
         self.maps[1] = CoordinateMap(uniq, table, 1)
         self._level_built(1)
         return inverse, first_idx
+
+    def _insert_pyramid(self, coords_i32: torch.Tensor):
+        levels = int(math.log2(self.MAX_STRIDE))
+        with self.building():
+            pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2)
+        for lv in range(levels + 1):
+            ts = 1 << lv
+            self.maps[ts] = CoordinateMap(pyr.coords[lv], pyr.tables[lv], ts)
+            if lv:
+                self.parents[ts] = pyr.parents[lv]
+        for lv, (nbr, tail) in enumerate(zip(pyr.nbr3, pyr.tails)):
+            self.kmaps[(1 << lv, 1 << lv, 3, False)] = nbr
+            self.aux[("tail", 1 << lv)] = tail
+        # the per-level callbacks (DiffCompletion: the part -> full matches, 50-250 us kernels that fill the chip) are queued by
+        # flush_levels() -- TensorField.sparse() calls it behind the voxel mean, so that the first convolution's inputs are
+        # not stuck behind them
+        self._deferred_levels = [1 << lv for lv in range(levels + 1)]
+        return pyr.inverse, pyr.first_idx
+
+    def flush_levels(self):
+        for ts in getattr(self, "_deferred_levels", ()):
+            self._level_built(ts)
+        self._deferred_levels = []
 
     def stride(self, ts: int, s: int) -> int:
         ts_out = ts * s
@@ -151,6 +179,9 @@ class CoordinateManager:
             nbr = self.kernel_map(ts, ts, 3)
             with self.building():
                 self.aux[key] = ops.TailMap(nbr)
+        elif getattr(self.aux[key], "_pending", None) is not None:      # counted in build_pyramid(): fill, no host read
+            with self.building():
+                self.aux[key].fill()
         return self.aux[key]
 
     ORDER_MIN_ROWS = 30000      # smaller maps fit the L2 anyway
@@ -273,6 +304,7 @@ class CoordinateManager:
                     out.append(t)
                 elif isinstance(t, ops.TailMap):
                     out += [q for q in (t.ptr, t.nbr, t.idx, t.pair_in, t.off) if q is not None]
+                    out += [q for q in (getattr(t, "_pending", None) or ()) if isinstance(q, torch.Tensor)]
         return out
 
     def record_stream(self, stream):
@@ -396,10 +428,12 @@ class TensorField:
                 ci = self._C if self._C.dtype == torch.int32 else ops.coords_floor(self._C)
             self.inverse_mapping, _ = mgr.insert(ci)
         if self._sparse is not None:
+            mgr.flush_levels()
             return self._sparse
         m = mgr.maps[1].coords.shape[0]
         with mgr.building():
             f = _VoxelMean.apply(self._F.float(), self.inverse_mapping, m)
+        mgr.flush_levels()
         sp = SparseTensor(f, tensor_stride=1, coordinate_manager=mgr)
         if not (torch.is_grad_enabled() and self._F.requires_grad):
             self._sparse = sp        # same features for every caller of this field (no graph attached)

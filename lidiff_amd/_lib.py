@@ -29,6 +29,9 @@ SIGNATURES = {
     "lidiff_map_stride": (_i32, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "lidiff_kernel_map": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
     "lidiff_kernel_map_self": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p, _p]),
+    "lidiff_kernel_map_self_dev": (_i32, [_p, _i64, _p, _p, _p, _i64, _i32, _p, _p]),
+    "lidiff_map_stride_dev": (_i32, [_p, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "lidiff_tail_map_dev": (_i32, [_p, _i32, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p]),
     "lidiff_kernel_map_down": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p]),
     "lidiff_kernel_map_up": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_rulebook_compact": (_i32, [_p, _i32, _i64, _p, _p, _p, _p, _p]),
@@ -65,7 +68,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 _lib = None
 
 

@@ -38,11 +38,14 @@ __device__ __forceinline__ int4 strided_row(const int32_t* __restrict__ coords, 
 }
 
 // Phase 1: insert every row's key; the slot remembers the smallest row index that hit it.
-__global__ void insert_kernel(const int32_t* __restrict__ coords, int64_t n, int s,
+// (every kernel of the chain: d_n != nullptr means the row count lives on the device -- the output of the previous
+// level's compaction -- and `n` is only the bound the grid was sized for: no host read between the levels)
+__global__ void insert_kernel(const int32_t* __restrict__ coords, int64_t n, const int32_t* __restrict__ d_n, int s,
                               uint64_t* __restrict__ hkeys, int32_t* __restrict__ hvals,
                               uint32_t mask, int32_t* __restrict__ slot_of,
                               int32_t* __restrict__ d_status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_n) n = *d_n;
     if (i >= n) return;
     const int4 c = strided_row(coords, i, s);
     bool ok;
@@ -73,10 +76,11 @@ __global__ void insert_kernel(const int32_t* __restrict__ coords, int64_t n, int
 
 // Phase 2: a row is its voxel's first occurrence iff the slot kept its index.  The flag is
 // parked in bit 31 of slot_of; per-block counts feed the ordered compaction.
-__global__ void flag_count_kernel(const int32_t* __restrict__ hvals, int64_t n,
+__global__ void flag_count_kernel(const int32_t* __restrict__ hvals, int64_t n, const int32_t* __restrict__ d_n,
                                   int32_t* __restrict__ slot_of, int32_t* __restrict__ blk_counts) {
     __shared__ int wave_cnt[kWavesPerBlock];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_n) n = *d_n;
     bool first = false;
     if (i < n) {
         const int32_t slot = slot_of[i];
@@ -109,7 +113,7 @@ __device__ __forceinline__ int block_prefix_of_counts(const int32_t* __restrict_
 
 // Phase 3: ordered compaction of the first occurrences: row id = #first occurrences before
 // this point.  Writes the unique rows, the first-point index, and the row id into the table.
-__global__ void scan_write_kernel(const int32_t* __restrict__ coords, int64_t n, int s,
+__global__ void scan_write_kernel(const int32_t* __restrict__ coords, int64_t n, const int32_t* __restrict__ d_n, int s,
                                   const int32_t* __restrict__ slot_of,
                                   const int32_t* __restrict__ blk_counts,
                                   int32_t* __restrict__ hvals, int32_t* __restrict__ uniq,
@@ -118,6 +122,7 @@ __global__ void scan_write_kernel(const int32_t* __restrict__ coords, int64_t n,
     __shared__ int wave_cnt[kWavesPerBlock];
     const int base = block_prefix_of_counts(blk_counts, smem);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_n) n = *d_n;
     int32_t slot = 0;
     bool first = false;
     if (i < n) {
@@ -147,12 +152,13 @@ __global__ void scan_write_kernel(const int32_t* __restrict__ coords, int64_t n,
 // Phase 4: point -> row through the table.
 template <typename OutT>
 __global__ void inverse_kernel(const int32_t* __restrict__ hvals, const int32_t* __restrict__ slot_of,
-                               int64_t n, OutT* __restrict__ inverse) {
+                               int64_t n, const int32_t* __restrict__ d_n, OutT* __restrict__ inverse) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_n) n = *d_n;
     if (i < n) inverse[i] = (OutT)hvals[slot_of[i] & 0x7fffffff];
 }
 
-static int run_unique(const int32_t* coords, int64_t n, int s, uint64_t* hkeys, int32_t* hvals,
+static int run_unique(const int32_t* coords, int64_t n, const int32_t* d_n, int s, uint64_t* hkeys, int32_t* hvals,
                       int64_t cap, int32_t* uniq, int32_t* first_idx, void* inverse, bool inverse64,
                       int32_t* d_m, int32_t* d_status, void* workspace, hipStream_t st) {
     LIDIFF_CHECK_ARG(n >= 0 && n < (1ll << 30), "row count out of range");
@@ -167,14 +173,14 @@ static int run_unique(const int32_t* coords, int64_t n, int s, uint64_t* hkeys, 
     int32_t* slot_of = (int32_t*)workspace;
     int32_t* blk_counts = slot_of + n;
     const uint32_t mask = (uint32_t)(cap - 1);
-    insert_kernel<<<nblk, kBlock, 0, st>>>(coords, n, s, hkeys, hvals, mask, slot_of, d_status);
-    flag_count_kernel<<<nblk, kBlock, 0, st>>>(hvals, n, slot_of, blk_counts);
-    scan_write_kernel<<<nblk, kBlock, 0, st>>>(coords, n, s, slot_of, blk_counts, hvals, uniq,
+    insert_kernel<<<nblk, kBlock, 0, st>>>(coords, n, d_n, s, hkeys, hvals, mask, slot_of, d_status);
+    flag_count_kernel<<<nblk, kBlock, 0, st>>>(hvals, n, d_n, slot_of, blk_counts);
+    scan_write_kernel<<<nblk, kBlock, 0, st>>>(coords, n, d_n, s, slot_of, blk_counts, hvals, uniq,
                                                first_idx, d_m);
     if (inverse64)
-        inverse_kernel<int64_t><<<nblk, kBlock, 0, st>>>(hvals, slot_of, n, (int64_t*)inverse);
+        inverse_kernel<int64_t><<<nblk, kBlock, 0, st>>>(hvals, slot_of, n, d_n, (int64_t*)inverse);
     else
-        inverse_kernel<int32_t><<<nblk, kBlock, 0, st>>>(hvals, slot_of, n, (int32_t*)inverse);
+        inverse_kernel<int32_t><<<nblk, kBlock, 0, st>>>(hvals, slot_of, n, d_n, (int32_t*)inverse);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -314,12 +320,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 3))) 
 // centre are looked up; every hit also writes its mirror entry (each table slot is written by at most one row: no race, the
 // table equals kernel_map_kernel<3>'s bit for bit).  nbr must be pre-filled with -1.  Half the scattered requests of the
 // plain kernel on low-density maps -- and the number of requests is what bounds it.
+// (d_m != nullptr: the row count lives on the device; `m` stays the row pitch of the table, sized for the bound)
 __global__ __launch_bounds__(kBlock) void kernel_map_self_kernel(const int32_t* __restrict__ coords, int64_t m,
+                                                                const int32_t* __restrict__ d_m,
                                                                 const uint64_t* __restrict__ hkeys,
                                                                 const int32_t* __restrict__ hvals, uint32_t mask, int step,
                                                                 int32_t* __restrict__ nbr) {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= m) return;
+    if (o >= (d_m ? (int64_t)*d_m : m)) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[o];
     auto key_of = [&](int k, bool& ok) {
         const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
@@ -495,10 +503,13 @@ __global__ void rb_fill_kernel(const int32_t* __restrict__ nbr, int64_t m_out,
 // Tail map of a kernel_size-3 / stride-1 kernel map (include/lidiff_amd.h, lidiff_tail_map): the pairs of all offsets
 // but `skip` (the centre = identity) as P output rows sorted by (offset, output row) -- tail_nbr[k][p] = input row of pair p
 // at its own offset, -1 elsewhere -- plus a CSR over the map's output rows listing each row's pairs in ascending offset.
-__global__ void tail_count_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int skip, int32_t* __restrict__ counts) {
+// (d_m != nullptr: the row count lives on the device and m_out is the row pitch of the table / the bound of the grid)
+__global__ void tail_count_kernel(const int32_t* __restrict__ nbr, int64_t m_out, const int32_t* __restrict__ d_m, int skip,
+                                  int32_t* __restrict__ counts) {
     __shared__ int wave_cnt[kWavesPerBlock];
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = (int)blockIdx.y != skip && o < m_out && nbr[(int64_t)blockIdx.y * m_out + o] >= 0;
+    const int64_t rows = d_m ? (int64_t)*d_m : m_out;
+    const bool valid = (int)blockIdx.y != skip && o < rows && nbr[(int64_t)blockIdx.y * m_out + o] >= 0;
     const unsigned long long m = __ballot(valid);
     if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = __popcll(m);
     __syncthreads();
@@ -512,12 +523,13 @@ __global__ void tail_count_kernel(const int32_t* __restrict__ nbr, int64_t m_out
 // per-row pair counts of the tail map: FINAL == false: per-block sums only; FINAL == true: row_ptr[o] = blk_base[block] +
 // exclusive scan inside the block, row_ptr[m_out] = total (the block sums are scanned in between by scan_i32_kernel)
 template <bool FINAL>
-__global__ void tail_rowcnt_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int k_vol, int skip,
-                                   int32_t* __restrict__ blk_sums, int32_t* __restrict__ row_ptr) {
+__global__ void tail_rowcnt_kernel(const int32_t* __restrict__ nbr, int64_t m_out, const int32_t* __restrict__ d_m, int k_vol,
+                                   int skip, int32_t* __restrict__ blk_sums, int32_t* __restrict__ row_ptr) {
     __shared__ int wave_tot[kWavesPerBlock];
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = d_m ? (int64_t)*d_m : m_out;
     int c = 0;
-    if (o < m_out)
+    if (o < rows)
         for (int k = 0; k < k_vol; ++k) c += (k != skip && nbr[(int64_t)k * m_out + o] >= 0) ? 1 : 0;
     int incl = c;
     for (int off = 1; off < kWave; off <<= 1) {
@@ -572,14 +584,15 @@ __global__ void scan_i32_kernel(int32_t* __restrict__ data, int64_t n) {
     if (threadIdx.x == 0) data[n] = carry_s;
 }
 
-__global__ void tail_fill_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int skip, int64_t n_pairs,
-                                 const int32_t* __restrict__ scanned, const int32_t* __restrict__ row_ptr,
+__global__ void tail_fill_kernel(const int32_t* __restrict__ nbr, int64_t m_out, const int32_t* __restrict__ d_m, int skip,
+                                 int64_t n_pairs, const int32_t* __restrict__ scanned, const int32_t* __restrict__ row_ptr,
                                  int32_t* __restrict__ tail_nbr, int32_t* __restrict__ idx) {
     __shared__ int wave_cnt[kWavesPerBlock];
     const int k = blockIdx.y;
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = d_m ? (int64_t)*d_m : m_out;
     int v = -1;
-    if (k != skip && o < m_out) v = nbr[(int64_t)k * m_out + o];
+    if (k != skip && o < rows) v = nbr[(int64_t)k * m_out + o];
     const bool valid = v >= 0;
     const unsigned long long m = __ballot(valid);
     const int w = threadIdx.x / kWave;
@@ -1078,7 +1091,7 @@ int lidiff_coords_floor(const float* coords_f, int64_t n_rows, int32_t* coords_i
 int lidiff_vox_unique(const int32_t* coords, int64_t n_rows, uint64_t* hkeys, int32_t* hvals,
                       int64_t cap, int32_t* uniq, int32_t* first_idx, int64_t* inverse,
                       int32_t* d_m, int32_t* d_status, void* workspace, void* stream) {
-    return run_unique(coords, n_rows, 1, hkeys, hvals, cap, uniq, first_idx, inverse, true, d_m,
+    return run_unique(coords, n_rows, nullptr, 1, hkeys, hvals, cap, uniq, first_idx, inverse, true, d_m,
                       d_status, workspace, (hipStream_t)stream);
 }
 
@@ -1086,7 +1099,16 @@ int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out, uint
                       int32_t* hvals, int64_t cap, int32_t* coarse, int32_t* parent, int32_t* d_m,
                       int32_t* d_status, void* workspace, void* stream) {
     LIDIFF_CHECK_ARG(s_out >= 1, "stride must be >= 1");
-    return run_unique(coords, n_rows, s_out, hkeys, hvals, cap, coarse, nullptr, parent, false, d_m,
+    return run_unique(coords, n_rows, nullptr, s_out, hkeys, hvals, cap, coarse, nullptr, parent, false, d_m,
+                      d_status, workspace, (hipStream_t)stream);
+}
+
+int lidiff_map_stride_dev(const int32_t* coords, int64_t n_rows_bound, const int32_t* d_n_rows, int32_t s_out,
+                          uint64_t* hkeys, int32_t* hvals, int64_t cap, int32_t* coarse, int32_t* parent, int32_t* d_m,
+                          int32_t* d_status, void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(s_out >= 1, "stride must be >= 1");
+    LIDIFF_CHECK_ARG(d_n_rows != nullptr, "d_n_rows");
+    return run_unique(coords, n_rows_bound, d_n_rows, s_out, hkeys, hvals, cap, coarse, nullptr, parent, false, d_m,
                       d_status, workspace, (hipStream_t)stream);
 }
 
@@ -1150,8 +1172,21 @@ int lidiff_kernel_map_self(const int32_t* coords, int64_t m, const uint64_t* hke
     if (m == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     LIDIFF_CHECK_HIP(hipMemsetAsync(nbr, 0xff, (size_t)27 * m * sizeof(int32_t), st));
-    kernel_map_self_kernel<<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>(coords, m, hkeys, hvals, (uint32_t)(cap - 1),
-                                                                             step, nbr);
+    kernel_map_self_kernel<<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>(coords, m, nullptr, hkeys, hvals,
+                                                                             (uint32_t)(cap - 1), step, nbr);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_kernel_map_self_dev(const int32_t* coords, int64_t m_bound, const int32_t* d_m, const uint64_t* hkeys,
+                               const int32_t* hvals, int64_t cap, int32_t step, int32_t* nbr, void* stream) {
+    LIDIFF_CHECK_ARG(cap > 0 && (cap & (cap - 1)) == 0, "cap must be a power of two");
+    LIDIFF_CHECK_ARG(step >= 1 && d_m != nullptr, "step must be >= 1, d_m set");
+    if (m_bound == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    LIDIFF_CHECK_HIP(hipMemsetAsync(nbr, 0xff, (size_t)27 * m_bound * sizeof(int32_t), st));
+    kernel_map_self_kernel<<<(unsigned)ceil_div(m_bound, kBlock), kBlock, 0, st>>>(coords, m_bound, d_m, hkeys, hvals,
+                                                                                   (uint32_t)(cap - 1), step, nbr);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -1213,8 +1248,9 @@ int64_t lidiff_tail_map_workspace_bytes(int32_t k_vol, int64_t m_out) {
     return ((int64_t)(k_vol + 1) * ceil_div(m_out > 0 ? m_out : 1, kBlock) + 32) * (int64_t)sizeof(int32_t);
 }
 
-int lidiff_tail_map(const int32_t* nbr, int32_t k_vol, int64_t m_out, int32_t skip, int32_t* offset_ptr,
-                    int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx, void* workspace, void* stream) {
+static int tail_map_impl(const int32_t* nbr, int32_t k_vol, int64_t m_out, const int32_t* d_m, int32_t skip,
+                         int32_t* offset_ptr, int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx,
+                         void* workspace, void* stream) {
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && m_out >= 0, "bad shape");
     LIDIFF_CHECK_ARG(nbr != nullptr && offset_ptr != nullptr && row_ptr != nullptr && workspace != nullptr, "null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -1226,21 +1262,33 @@ int lidiff_tail_map(const int32_t* nbr, int32_t k_vol, int64_t m_out, int32_t sk
             LIDIFF_CHECK_HIP(hipMemsetAsync(row_ptr, 0, sizeof(int32_t), st));
             return 0;
         }
-        tail_count_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, skip, counts);
+        tail_count_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, d_m, skip, counts);
         rb_scan_kernel<<<1, 1024, 0, st>>>(counts, nblk * k_vol, nblk, k_vol, offset_ptr);
         int32_t* blk_sums = counts + (int64_t)k_vol * nblk + 8;       // behind the per-offset block counts
-        tail_rowcnt_kernel<false><<<nblk, kBlock, 0, st>>>(nbr, m_out, k_vol, skip, blk_sums, row_ptr);
+        tail_rowcnt_kernel<false><<<nblk, kBlock, 0, st>>>(nbr, m_out, d_m, k_vol, skip, blk_sums, row_ptr);
         scan_i32_kernel<<<1, 1024, 0, st>>>(blk_sums, nblk);
-        tail_rowcnt_kernel<true><<<nblk, kBlock, 0, st>>>(nbr, m_out, k_vol, skip, blk_sums, row_ptr);
+        tail_rowcnt_kernel<true><<<nblk, kBlock, 0, st>>>(nbr, m_out, d_m, k_vol, skip, blk_sums, row_ptr);
         LIDIFF_CHECK_LAUNCH();
         return 0;
     }
     LIDIFF_CHECK_ARG(idx != nullptr && n_pairs >= 0, "phase 2 needs tail_nbr, idx and the pair count of phase 1");
     if (n_pairs == 0 || m_out == 0) return 0;
     LIDIFF_CHECK_HIP(hipMemsetAsync(tail_nbr, 0xFF, (size_t)k_vol * n_pairs * sizeof(int32_t), st));
-    tail_fill_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, skip, n_pairs, counts, row_ptr, tail_nbr, idx);
+    tail_fill_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_out, d_m, skip, n_pairs, counts, row_ptr, tail_nbr, idx);
     LIDIFF_CHECK_LAUNCH();
     return 0;
+}
+
+int lidiff_tail_map(const int32_t* nbr, int32_t k_vol, int64_t m_out, int32_t skip, int32_t* offset_ptr,
+                    int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx, void* workspace, void* stream) {
+    return tail_map_impl(nbr, k_vol, m_out, nullptr, skip, offset_ptr, row_ptr, n_pairs, tail_nbr, idx, workspace, stream);
+}
+
+int lidiff_tail_map_dev(const int32_t* nbr, int32_t k_vol, int64_t m_bound, const int32_t* d_m, int32_t skip,
+                        int32_t* offset_ptr, int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx,
+                        void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(d_m != nullptr, "d_m");
+    return tail_map_impl(nbr, k_vol, m_bound, d_m, skip, offset_ptr, row_ptr, n_pairs, tail_nbr, idx, workspace, stream);
 }
 
 int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c, float* dst,

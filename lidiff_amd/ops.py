@@ -76,6 +76,85 @@ def map_stride(coords: torch.Tensor, s_out: int, status: torch.Tensor):
     return coarse[:m], parent, table
 
 
+PYRAMID_TRACE = None     # debugging: a list -> build_pyramid appends (label, host time) pairs (tools/debug/step_timeline.py)
+
+
+def _trace(label):
+    if PYRAMID_TRACE is not None:
+        import time
+        ev = None
+        if label in ("enter", "tails queued", "done"):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        PYRAMID_TRACE.append((label, time.perf_counter(), ev))
+
+
+class Pyramid:
+    """What build_pyramid() hands over: per level the coordinate rows, hash table and (levels >= 1) the parent array of the
+    finer level; for the first `tail_levels` levels also the kernel_size-3 self map and the phase-1 state of its tail map."""
+    __slots__ = ("coords", "tables", "parents", "inverse", "first_idx", "nbr3", "tails")
+
+
+def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, tail_levels: int = 2) -> Pyramid:
+    """Voxelise int32 coords [N, 4] (vox_unique), the `strides` strided maps below it (map_stride, tensor strides 2, 4, ...),
+    and for the first `tail_levels` levels the kernel_size-3 map onto itself plus the COUNT phase of its tail map -- all queued
+    back to back on the current stream with every row count staying on the device (the *_dev entry points), followed by
+    ONE host read of all sizes.  Same maps, bit for bit, as the call-by-call path (which reads each size as it is made:
+    1 + strides + tail_levels reads); buffers are sized for the point count, which bounds every level."""
+    require_device(coords, status)
+    assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+    coords = coords.contiguous()
+    n, dev = coords.shape[0], coords.device
+    lib = _lib.load()
+    _trace("enter")
+    counts = torch.zeros(strides + 1 + tail_levels, dtype=torch.int32, device=dev)
+    cptr = lambda i: counts.data_ptr() + 4 * i
+    st = stream_ptr()
+    tables = [HashTable(n, dev)]
+    rows = [torch.empty((n, 4), dtype=torch.int32, device=dev)]
+    first_idx = torch.empty(n, dtype=torch.int32, device=dev)
+    inverse = torch.empty(n, dtype=torch.int64, device=dev)
+    keep = [_workspace(n, dev)]
+    call("lidiff_vox_unique", ptr(coords), n, ptr(tables[0].keys), ptr(tables[0].vals), tables[0].cap, ptr(rows[0]),
+         ptr(first_idx), ptr(inverse), cptr(0), ptr(status), ptr(keep[0]), st)
+    _trace("level 0 queued")
+    parents = [None]
+    for lv in range(1, strides + 1):
+        _trace(f"level {lv}: alloc")
+        tables.append(HashTable(n, dev))
+        rows.append(torch.empty((n, 4), dtype=torch.int32, device=dev))
+        parents.append(torch.empty(n, dtype=torch.int32, device=dev))
+        keep.append(_workspace(n, dev))
+        call("lidiff_map_stride_dev", ptr(rows[lv - 1]), n, cptr(lv - 1), 1 << lv, ptr(tables[lv].keys), ptr(tables[lv].vals),
+             tables[lv].cap, ptr(rows[lv]), ptr(parents[lv]), cptr(lv), ptr(status), ptr(keep[lv]), st)
+    _trace("strides queued")
+    tails = []
+    for lv in range(min(tail_levels, strides + 1)):
+        nbr = torch.empty((27, n), dtype=torch.int32, device=dev)
+        call("lidiff_kernel_map_self_dev", ptr(rows[lv]), n, cptr(lv), ptr(tables[lv].keys), ptr(tables[lv].vals),
+             tables[lv].cap, 1 << lv, ptr(nbr), st)
+        ws = torch.empty(lib.lidiff_tail_map_workspace_bytes(27, n), dtype=torch.uint8, device=dev)
+        off = torch.empty(28, dtype=torch.int32, device=dev)
+        row_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        call("lidiff_tail_map_dev", ptr(nbr), 27, n, cptr(lv), 13, ptr(off), ptr(row_ptr), 0, None, None, ptr(ws), st)
+        counts[strides + 1 + lv:strides + 2 + lv].copy_(off[27:28])
+        tails.append((nbr, ws, off, row_ptr))
+    _trace("tails queued")
+    host = counts.tolist()                                     # THE host read of this pyramid
+    _trace("sizes read")
+    out = Pyramid()
+    out.coords = [rows[lv][:host[lv]] for lv in range(strides + 1)]
+    out.tables, out.inverse, out.first_idx = tables, inverse, first_idx[:host[0]]
+    out.parents = [None] + [parents[lv][:host[lv - 1]] for lv in range(1, strides + 1)]
+    out.nbr3, out.tails = [], []
+    for lv, (nbr, ws, off, row_ptr) in enumerate(tails):
+        m = host[lv]
+        out.nbr3.append(nbr[:, :m].contiguous())               # the table at its own pitch (27 x M ints: a ~10 us copy)
+        out.tails.append(TailMap(None, phase1=(nbr, n, counts[lv:lv + 1], ws, off, row_ptr, host[strides + 1 + lv], m)))
+    _trace("done")
+    return out
+
+
 def vox_mean(feats: torch.Tensor, inverse: torch.Tensor, m: int):
     """UNWEIGHTED_AVERAGE features (pipeline:77).  Returns (out[M,C], counts[M]).  Deterministic (fixed-point sums)."""
     require_device(feats, inverse)
@@ -769,7 +848,10 @@ class TailMap:
       ptr [M + 1], idx [P]   CSR over the map's output rows: the pairs landing on output row o, in ascending offset.
     Built once per coordinate map from its neighbour table (shared by every convolution on the map)."""
 
-    def __init__(self, nbr: torch.Tensor):
+    def __init__(self, nbr: torch.Tensor | None, phase1=None):
+        if phase1 is not None:          # build_pyramid(): counts taken with the row count on the device, size already read
+            self._from_phase1(*phase1)
+            return
         require_device(nbr)
         k, m = nbr.shape
         assert k == 27 and nbr.dtype == torch.int32 and nbr.is_contiguous()
@@ -787,6 +869,26 @@ class TailMap:
             call("lidiff_tail_map", ptr(nbr), k, m, 13, ptr(off), ptr(self.ptr), self.n, ptr(self.nbr), ptr(self.idx),
                  ptr(ws), stream_ptr())
             self.pair_in = self.nbr.amax(0)                              # the pair list form of the same map (one entry per column)
+
+    def _from_phase1(self, nbr_bound, m_bound, d_m, ws, off, row_ptr, n, m):
+        """Phase 2 over the table of pitch m_bound whose phase 1 ran in build_pyramid(); filled when first asked for."""
+        self.n, self.off, self.ptr = int(n), off, row_ptr[:m + 1]
+        self.nbr = self.idx = self.pair_in = None
+        self._pending = (nbr_bound, m_bound, d_m, ws, row_ptr) if self.n else None
+
+    def fill(self):
+        """The pair arrays (nbr / idx / pair_in) of a map that came out of build_pyramid(): no host read (n is known)."""
+        pend = getattr(self, "_pending", None)
+        if pend is not None:
+            nbr_bound, m_bound, d_m, ws, row_ptr = pend
+            dev = nbr_bound.device
+            self.nbr = torch.empty((27, self.n), dtype=torch.int32, device=dev)
+            self.idx = torch.empty(self.n, dtype=torch.int32, device=dev)
+            call("lidiff_tail_map_dev", ptr(nbr_bound), 27, m_bound, ptr(d_m), 13, ptr(self.off), ptr(row_ptr), self.n,
+                 ptr(self.nbr), ptr(self.idx), ptr(ws), stream_ptr())
+            self.pair_in = self.nbr.amax(0)
+            self._pending = None
+        return self
 
 
 # (The centre pass keeps the narrow 3 x 2 / 4 x 2 wave grids of the hinted maps: the 96-column tile of the dense family, which

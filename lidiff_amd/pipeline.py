@@ -78,6 +78,7 @@ class DiffCompletion(nn.Module):
         field = ME.TensorField(features=x_feats[:, 1:], coordinates=x_coord,
                                quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
                                minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
+        field.coordinate_manager.pyramid = self.single_read and field.F.device.type == "cuda"
         if self.overlap_maps and field.F.device.type == "cuda":
             field.ready = torch.cuda.Event()         # its points exist once the current stream gets here
             field.ready.record(torch.cuda.current_stream(self.device))
@@ -93,6 +94,9 @@ class DiffCompletion(nn.Module):
     # maps -> tail maps -> up orders -> 5 matches: 2.2-3 ms with its map-size reads, profiles/r03_step_boundary_trace.txt),
     # but the stem needs only the first ~0.4 ms of it.  LIDIFF_LAZY_XT=0: the whole pyramid first (round-2 behaviour).
     lazy_x_t = os.environ.get("LIDIFF_LAZY_XT", "1") != "0"
+    # every field's pyramid (voxel map, four strided maps, the first two levels' kernel_size-3 maps and tail-map counts) queued
+    # with the row counts staying on the device and ONE host read at its end (ops.build_pyramid) instead of seven
+    single_read = os.environ.get("LIDIFF_SINGLE_READ", "1") != "0"
     overlap_maps = os.environ.get("LIDIFF_OVERLAP_MAPS", "1") not in ("0", "lazy")
     eager_maps = os.environ.get("LIDIFF_OVERLAP_MAPS", "1") != "lazy"      # False: maps are built when a layer first asks
 

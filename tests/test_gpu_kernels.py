@@ -573,6 +573,48 @@ def test_spconv_dense_kernel_is_bit_identical_to_the_tile_kernel(device, kernel)
             assert torch.allclose(got[:m].cpu().double(), want, rtol=RTOL, atol=ATOL), (kind, cin, split, cout)
 
 
+def test_single_read_pyramid_equals_the_map_by_map_build(device):
+    """ops.build_pyramid / CoordinateManager.pyramid -- voxelise, four strided maps, the kernel_size-3 self maps and tail-map
+    counts of the first two levels queued with the row counts on the device and ONE host read -- against the map-by-map
+    build (one read per map): every coordinate row, parent array, hash lookup result, neighbour table and tail map
+    identical, on dense / sparse / one-voxel / two-batch clouds; and the oracle's maps for one of them."""
+    import lidiff_amd.MinkowskiEngine as ME
+    one = np.zeros((180, 4), np.int32)
+    tiny = random_cloud(3, 50, 8)
+    for cloud in (random_cloud(40000, 40, 3, batch=3), random_cloud(9000, 300, 41, dup=0.0), one, tiny,
+                  random_cloud(5000, 6, 42, batch=2)):
+        mgrs = []
+        for pyramid in (False, True):
+            mgr = ME.CoordinateManager(device)
+            mgr.pyramid = pyramid
+            inv, first = mgr.insert(dev_i32(cloud, device))
+            ts = 1
+            for _ in range(4):
+                ts = mgr.stride(ts, 2)
+            mgrs.append((mgr, inv, first))
+        (a, inv_a, first_a), (b, inv_b, first_b) = mgrs
+        assert torch.equal(inv_a, inv_b) and torch.equal(first_a, first_b)
+        for ts in (1, 2, 4, 8, 16):
+            assert torch.equal(a.maps[ts].coords, b.maps[ts].coords), ts
+            if ts > 1:
+                assert torch.equal(a.parents[ts], b.parents[ts]), ts
+            assert torch.equal(a.kernel_map(ts, ts, 3), b.kernel_map(ts, ts, 3)), ts        # looks the rows up in the tables
+            if ts < 16:
+                assert torch.equal(a.kernel_map(ts, 2 * ts, 2), b.kernel_map(ts, 2 * ts, 2))
+                assert torch.equal(a.kernel_map(2 * ts, ts, 2, True), b.kernel_map(2 * ts, ts, 2, True))
+        for ts in (1, 2):
+            ta, tb = a.tail_map(ts), b.tail_map(ts)
+            assert ta.n == tb.n and torch.equal(ta.ptr, tb.ptr) and torch.equal(ta.off, tb.off)
+            if ta.n:
+                assert torch.equal(ta.nbr, tb.nbr) and torch.equal(ta.idx, tb.idx) and torch.equal(ta.pair_in, tb.pair_in)
+        a.check(); b.check()
+    o_uniq, o_inv, _ = me.voxelize(cloud)
+    assert np.array_equal(b.maps[1].coords.cpu().numpy(), o_uniq) and np.array_equal(inv_b.cpu().numpy(), o_inv)
+    o_c2, o_par = me.stride_map(o_uniq, 2)
+    assert np.array_equal(b.maps[2].coords.cpu().numpy(), o_c2) and np.array_equal(b.parents[2].cpu().numpy(), o_par)
+    assert np.array_equal(b.kernel_map(1, 1, 3).cpu().numpy(), me.kernel_map(o_uniq, o_uniq, 3, 1))
+
+
 ROW_KERNEL_SHAPES = [(32, 0, 32), (32, 0, 64), (64, 0, 64), (64, 0, 128), (96, 0, 96), (96, 64, 96), (128, 96, 96),
                      (128, 0, 128), (128, 0, 256), (192, 128, 128), (64, 32, 32), (192, 0, 96)]
 

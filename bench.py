@@ -144,7 +144,7 @@ def cpu_baseline(scan_np, seed=42, threads=0):
 
 
 VARIANT_KERNELS = {"bn128": ("<128, 8, 1",), "bn96": ("<128, 6, 1", "<128, 3, 2"), "bn64": ("<128, 4, 2",),
-                   "bn32": ("<128, 2, 4",), "bn16": ("<128, 1, 8",), "rows": ("spconv_rows_kernel",)}
+                   "bn32": ("<128, 2, 4",), "bn16": ("<128, 1, 8",), "rows": ("spconv_rows_kernel",), "thin": ("spconv_thin_kernel",)}
 COORD_KERNELS = ("insert_kernel", "flag_count_kernel", "scan_write_kernel", "inverse_kernel", "mean_", "kernel_map_",
                  "floor_kernel")
 
@@ -168,7 +168,7 @@ def traffic_from_profile(variants, per="launch"):
         want = VARIANT_KERNELS.get(variants[0], ("?",))[0]
         return (js["traffic_bytes_per_launch"] / 1e9, src) if want in js.get("kernel", "") else (None, None)
     keys = [p for v in variants for p in VARIANT_KERNELS.get(v, ())]
-    rows = [v for k, v in js["kernels"].items() if ("spconv_fwd_kernel" in k or "spconv_rows_kernel" in k) and any(p in k for p in keys)]
+    rows = [v for k, v in js["kernels"].items() if ("spconv_fwd_kernel" in k or "spconv_rows_kernel" in k or "spconv_thin_kernel" in k) and any(p in k for p in keys)]
     if not rows:
         return None, None
     total = sum(r["traffic_bytes_total"] for r in rows)
@@ -498,7 +498,7 @@ def main():
         }
     if vprof is not None or (prof is not None and args.all_variants):
         vs = (vprof or prof).summary()
-        narrow = {k: v for k, v in vs.items() if k in ("bn96", "bn64", "bn32", "bn16", "rows") and v["timed"]}
+        narrow = {k: v for k, v in vs.items() if k in ("bn96", "bn64", "bn32", "bn16", "rows", "thin") and v["timed"]}
         if narrow:
             nb, nms = sum(v["bytes"] for v in narrow.values()), sum(v["ms"] for v in narrow.values())
             out["roofline_narrow"] = {

@@ -207,7 +207,8 @@ int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int3
                       void* stream);
 
 /* Which kernel lidiff_spconv_fwd runs for these arguments: 0 = tile kernel (spconv.hip), 1 = dense kernel (spconv_dense.hip),
- * 2 = row kernel (spconv_rows.hip).  has_nbr / has_row_order: whether those pointers are non-null.  For profilers and tests. */
+ * 2 = row kernel (spconv_rows.hip), 3 = thin-input kernel (c_in <= 4, c_out == 32: the stems; spconv_rows.hip; equal to the
+ * tile kernel up to fp32 summation order).  has_nbr / has_row_order: whether those pointers are non-null.  For profilers and tests. */
 int32_t lidiff_spconv_fwd_kernel_id(int32_t c_in_a, int32_t c_in_b, int32_t c_out, int32_t k_vol, int32_t has_nbr,
                                     int32_t has_row_order, int32_t flags);
 

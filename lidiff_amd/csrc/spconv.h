@@ -59,5 +59,8 @@ int launch_fwd_dense(const ConvParams& p, hipStream_t st);
 // spconv_rows.hip: identity maps (kernel_size 1 / the centre pass) as a streaming row GEMM.
 bool rows_kernel_applies(const ConvParams& p);
 int launch_fwd_rows(const ConvParams& p, hipStream_t st);
+// ... and inputs of <= 4 channels (the stems) as a plain VALU kernel.
+bool thin_kernel_applies(const ConvParams& p);
+int launch_fwd_thin(const ConvParams& p, hipStream_t st);
 
 }  // namespace lidiff

@@ -718,6 +718,7 @@ extern "C" int32_t lidiff_spconv_fwd_kernel_id(int32_t c_in_a, int32_t c_in_b, i
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out; p.k_vol = k_vol; p.flags = flags;
     p.m_in = p.m_out = 1;
     if (!(flags & LIDIFF_CONV_TILE_ONLY) && rows_kernel_applies(p)) return 2;
+    if (!(flags & LIDIFF_CONV_TILE_ONLY) && thin_kernel_applies(p)) return 3;
     if ((flags & LIDIFF_CONV_DENSE_KERNEL) && dense_kernel_applies(p)) return 1;
     return 0;
 }
@@ -756,6 +757,8 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     hipStream_t st = (hipStream_t)stream;
     // identity maps: consecutive rows, one offset -- the streaming row GEMM of spconv_rows.hip (bit-identical results)
     if (!(flags & LIDIFF_CONV_TILE_ONLY) && al16(in_a) && al16(in_b) && rows_kernel_applies(p)) return launch_fwd_rows(p, st);
+    // inputs of <= 4 channels (the stems): nothing to multiply, a VALU kernel over the table
+    if (!(flags & LIDIFF_CONV_TILE_ONLY) && thin_kernel_applies(p)) return launch_fwd_thin(p, st);
     // dense 128-column layers: the software-pipelined kernel of spconv_dense.hip on request (bit-identical results,
     // measured equal to the tile kernels below on the bench workload: DESIGN.md section 4.2)
     if ((flags & LIDIFF_CONV_DENSE_KERNEL) && dense_kernel_applies(p)) return launch_fwd_dense(p, st);

@@ -221,10 +221,69 @@ int dispatch_rows_nj(const ConvParams& p, const PairList& pl, int64_t n_pos, hip
     return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Thin inputs (C_in <= 4: the networks' stems see the 3 point coordinates, minkunet.py:94): 2 x 27 x 3 x 32 FLOPs per output row
+// are nothing -- the layer is the 27 table entries and the 128 output bytes per row.  The MFMA kernels cannot even vectorise a
+// 12-byte row (scalar gather path: 105 us for the stem's first convolution on the bench scan).  Plain VALU kernel: one lane per
+// output row with its 32 accumulators, table reads coalesced over the rows, W (K x C_in x 32 floats) broadcast from LDS, the
+// wave's 64 x 32 output tile turned through LDS into 1 KB stores.  Offsets ascending, channels ascending, fused multiply-adds.
+constexpr int kThinCo = 32;
+
+__global__ __launch_bounds__(256) void spconv_thin_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* w_s = reinterpret_cast<float*>(smem);                       // [K][c_in][32]
+    float* o_s = w_s + p.k_vol * p.c_in * kThinCo;                     // [4 waves][64 rows][33]
+    // out of the packed layout (one 32-channel slab, two 16-column tiles): W[k][ci][col] sits at lane = col & 15, e = ci
+    for (int e = threadIdx.x; e < p.k_vol * p.c_in * kThinCo; e += 256) {
+        const int col = e % kThinCo, ci = (e / kThinCo) % p.c_in, k = e / (kThinCo * p.c_in);
+        w_s[e] = p.wp[((int64_t)k * 2 + (col >> 4)) * 512 + (col & 15) * 4 + ci];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t rows = p.m_out * p.replicas;
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = row < rows;
+    const int rep = live ? (int)(row / p.m_out) : 0;
+    const int64_t o = live ? row - (int64_t)rep * p.m_out : 0;
+    const float* in = p.in_a + (int64_t)rep * p.m_in * p.c_in;
+    float acc[kThinCo];
+#pragma unroll
+    for (int c = 0; c < kThinCo; ++c) acc[c] = 0.f;
+    for (int k = 0; k < p.k_vol; ++k) {
+        const int idx = !live ? -1 : (p.nbr ? p.nbr[(int64_t)k * p.m_out + o] : (int)o);
+        if (idx < 0) continue;
+        const float* x = in + (int64_t)idx * p.c_in;
+        const float* wk = w_s + k * p.c_in * kThinCo;
+        for (int ci = 0; ci < p.c_in; ++ci) {
+            const float xv = x[ci];
+#pragma unroll
+            for (int c = 0; c < kThinCo; ++c) acc[c] = fmaf(xv, wk[ci * kThinCo + c], acc[c]);
+        }
+    }
+    float* tile = o_s + wave * 64 * 33;
+#pragma unroll
+    for (int c = 0; c < kThinCo; ++c) tile[lane * 33 + c] = acc[c];
+    // (a wave's accesses to its own LDS tile are in order: no barrier needed between its writes and its reads)
+    const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    for (int e = lane; e < 64 * kThinCo; e += 64) {                   // 64 consecutive floats of the wave's 64 x 32 tile per pass
+        const int r = e >> 5, c = e & 31;
+        if (row0 + r >= rows) break;
+        float v = tile[r * 33 + c];
+        if (p.scale) v *= p.scale[c];
+        if (p.shift) v += p.shift[c];
+        const int64_t oo = (row0 + r) * kThinCo + c;
+        if (p.residual) v += p.residual[oo];
+        if (p.relu) v = fmaxf(v, 0.f);
+        p.out[oo] = v;
+    }
+}
+
 bool rows_shapes_ok(int c_in_a, int c_in_b, int c_out, bool gather) {
     if (c_in_a % 16 != 0 || c_in_b % 16 != 0 || c_out % 32 != 0) return false;
     const int nj = (c_in_a + c_in_b) >> 4;
     return nj == 2 || nj == 4 || nj == 6 || nj == 8 || (nj == 12 && !gather);
+    // (256 input channels -- 64-column W tiles -- were built and measured: 348 vs 340 us on the 256 -> 256 transposed layer,
+    // 260 vs 254 on 256 -> 128: the tile kernel keeps them)
 }
 
 }  // namespace
@@ -232,6 +291,19 @@ bool rows_shapes_ok(int c_in_a, int c_in_b, int c_out, bool gather) {
 bool rows_kernel_applies(const ConvParams& p) {
     if (p.nbr != nullptr || p.row_order != nullptr || p.k_vol != 1 || p.m_in != p.m_out) return false;
     return rows_shapes_ok(p.c_in_a, p.c_in_b, p.c_out, false);
+}
+
+bool thin_kernel_applies(const ConvParams& p) {
+    return p.in_b == nullptr && p.c_in_b == 0 && p.c_in_a >= 1 && p.c_in_a <= 4 && p.c_out == kThinCo && p.row_order == nullptr &&
+           p.tail == nullptr && (p.nbr != nullptr || (p.k_vol == 1 && p.m_in == p.m_out));
+}
+
+int launch_fwd_thin(const ConvParams& p, hipStream_t st) {
+    const size_t lds = ((size_t)p.k_vol * p.c_in * kThinCo + 4 * 64 * 33) * sizeof(float);
+    const int64_t rows = p.m_out * p.replicas;
+    hipLaunchKernelGGL(spconv_thin_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), lds, st, p);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
 }
 
 int launch_fwd_rows(const ConvParams& p, hipStream_t st) {

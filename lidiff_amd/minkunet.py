@@ -118,8 +118,9 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
                 return out
     # centre + tail only on really isolated voxels (<= ~2 neighbours each: the 128-column rule of is_sparse_map); the wider
     # hint of the narrow tiles keeps the one-launch kernel with packed stages (3.6 neighbours per voxel: 429 vs 495 us)
+    # (not for the 3-channel stem: the thin-input kernel walks the whole table in one launch)
     if (_CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and m_out >= 1024
-            and mgr.is_sparse_map(ts_out, ts_out, 3)):
+            and x.F.shape[1] > 4 and mgr.is_sparse_map(ts_out, ts_out, 3)):
         f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
                                    residual=residual, relu=relu, replicas=x.replicas)
     else:

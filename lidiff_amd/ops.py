@@ -334,6 +334,8 @@ def conv_variant(c_out: int, kernel_id: int = 0) -> str:
     "rows" = the streaming row kernel of identity maps, lidiff_spconv_fwd_kernel_id == 2)."""
     if kernel_id == 2:
         return "rows"
+    if kernel_id == 3:
+        return "thin"
     return ("bn128" if c_out % 128 == 0 else "bn96" if c_out % 96 == 0 else "bn64" if c_out % 64 == 0
             else "bn32" if c_out % 32 == 0 else "bn16")
 

@@ -615,6 +615,41 @@ def test_single_read_pyramid_equals_the_map_by_map_build(device):
     assert np.array_equal(b.kernel_map(1, 1, 3).cpu().numpy(), me.kernel_map(o_uniq, o_uniq, 3, 1))
 
 
+@pytest.mark.parametrize("cin", [3, 4, 1])
+def test_spconv_thin_input_kernel_vs_oracle_and_tile_kernel(device, cin):
+    """The stems' convolution (C_in <= 4 -> 32: spconv_thin_kernel, a VALU kernel over the neighbour table) against the
+    float64 oracle and the tile kernel (equal up to fp32 summation order), kernel_size 3 and 1, ragged row counts, replicas,
+    every epilogue combination."""
+    from lidiff_amd import _lib, ops
+    assert _lib.load().lidiff_spconv_fwd_kernel_id(cin, 0, 32, 27, 1, 0, 0) == 3
+    assert _lib.load().lidiff_spconv_fwd_kernel_id(cin, 0, 32, 27, 1, 0, 8) == 0 and _lib.load().lidiff_spconv_fwd_kernel_id(cin, 0, 64, 27, 1, 0, 0) == 0
+    g = torch.Generator().manual_seed(90 + cin)
+    for cloud, reps, epi in ((random_cloud(7000, 12, 51, batch=2), 2, 3), (random_cloud(300, 3, 52), 1, 0),
+                             (random_cloud(5, 40, 53), 2, 1), (random_cloud(20000, 60, 54), 1, 2)):
+        uniq, _, _ = me.voxelize(cloud)
+        m = uniq.shape[0]
+        for k in (27, 1):
+            nbr_np = me.kernel_map(uniq, uniq, 3, 1) if k == 27 else None
+            nbr = None if nbr_np is None else dev_i32(nbr_np, device)
+            x = torch.randn(reps * m, cin, generator=g)
+            w = torch.randn(k, cin, 32, generator=g) / np.sqrt(cin * max(1, k // 3))
+            sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+            res = torch.randn(reps * m, 32, generator=g)
+            kw = dict(replicas=reps, scale=sc.to(device) if epi & 1 else None, shift=sh.to(device) if epi & 1 else None,
+                      residual=res.to(device) if epi & 2 else None, relu=bool(epi & 2))
+            got = ops.spconv_fwd(x.to(device), w.to(device), nbr, m, **kw)
+            assert torch.equal(got, ops.spconv_fwd(x.to(device), w.to(device), nbr, m, **kw))
+            ref = ops.spconv_fwd(x.to(device), w.to(device), nbr, m, kernel="tile_only", **kw)
+            assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), (got - ref).abs().max().item()
+            for r in range(reps):
+                want = me.conv_forward(x[r * m:(r + 1) * m].double(), (w if k > 1 else w[0]).double(), nbr_np)
+                if epi & 1:
+                    want = want * sc.double() + sh.double()
+                if epi & 2:
+                    want = torch.relu(want + res[r * m:(r + 1) * m].double())
+                assert torch.allclose(got[r * m:(r + 1) * m].cpu().double(), want, rtol=RTOL, atol=ATOL), (cin, k, r)
+
+
 ROW_KERNEL_SHAPES = [(32, 0, 32), (32, 0, 64), (64, 0, 64), (64, 0, 128), (96, 0, 96), (96, 64, 96), (128, 96, 96),
                      (128, 0, 128), (128, 0, 256), (192, 128, 128), (64, 32, 32), (192, 0, 96)]
 

@@ -110,7 +110,12 @@ def main():
             hint = bool(args.sparse_hint)
         if args.up_ordered and kind == "up":
             (nbr, order), hint = mgr.up_order(ts * 2, ts), False
-        if args.centre_tail and kind == "k3":
+        plist = None
+        if args.up_ordered and kind == "up" and ops.pairs_kernel_applies(cin, 0, cout):
+            plist = mgr.up_pairs(ts * 2, ts)
+        if plist is not None:
+            conv = lambda: ops.spconv_fwd_pairs(x, w, plist[0], plist[1], plist[2], m_out, replicas=args.replicas)
+        elif args.centre_tail and kind == "k3":
             tmap = ops.TailMap(nbr)
             conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out, replicas=args.replicas, sparse_map=hint)
         elif args.kernel == "bf16" and ops.bf16_conv_applies(cin, 0, cout):

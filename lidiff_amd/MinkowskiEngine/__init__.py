@@ -428,12 +428,14 @@ class TensorField:
                 ci = self._C if self._C.dtype == torch.int32 else ops.coords_floor(self._C)
             self.inverse_mapping, _ = mgr.insert(ci)
         if self._sparse is not None:
-            mgr.flush_levels()
+            if mgr._async is None:
+                mgr.flush_levels()
             return self._sparse
         m = mgr.maps[1].coords.shape[0]
         with mgr.building():
             f = _VoxelMean.apply(self._F.float(), self.inverse_mapping, m)
-        mgr.flush_levels()
+        if mgr._async is None:          # (on-demand building: the consumer flushes behind its first layers, MinkUNetDiff._forward)
+            mgr.flush_levels()
         sp = SparseTensor(f, tensor_stride=1, coordinate_manager=mgr)
         if not (torch.is_grad_enabled() and self._F.requires_grad):
             self._sparse = sp        # same features for every caller of this field (no graph attached)

@@ -45,7 +45,19 @@ def main():
                 pipe.new_scheduler()
             _ = x_init + pipe.dpm_scheduler.step(noise_t, tvals[j], input_noise)["prev_sample"]
             ev("scheduler queued")
-            x_t = pipe.points_to_tensor(xs[min(j + 1, len(xs) - 1)])
+            import lidiff_amd.MinkowskiEngine as ME
+            pts = xs[min(j + 1, len(xs) - 1)]
+            x_feats = ME.utils.batched_coordinates(list(pts[:]), dtype=torch.float32, device=dev)
+            ev("  batched_coordinates")
+            x_coord = torch.round(x_feats / pipe.hparams["data"]["resolution"])
+            ev("  round")
+            x_t = ME.TensorField(features=x_feats[:, 1:], coordinates=x_coord,
+                                 quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                                 minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=dev)
+            ev("  TensorField")
+            x_t.coordinate_manager.pyramid = pipe.single_read
+            x_t.ready = torch.cuda.Event()
+            x_t.ready.record(torch.cuda.current_stream(dev))
             ev("next points queued")
             x_cond, x_uncond = pipe.reset_partial_pcd(x_cond, x_uncond, next_t=tvals[j + 1] if j + 1 < steps else None)
             ev("conditions reset")

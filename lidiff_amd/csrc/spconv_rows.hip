@@ -27,8 +27,8 @@
 
 namespace lidiff {
 
-namespace {
-
+// (kernels and helpers live in lidiff:: itself, not in an anonymous namespace: profiler tools cut kernel names at the first
+// parenthesis, and "lidiff::(anonymous namespace)::..." would lose its name)
 constexpr int kRowsWaves = 8;
 
 struct PairList {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void spconv_rows_kernel(const Conv
 }
 
 template <int NJ, int NT16, bool GATHER>
-int launch_rows(const ConvParams& p, const PairList& pl, int64_t n_pos, hipStream_t st) {
+static int launch_rows(const ConvParams& p, const PairList& pl, int64_t n_pos, hipStream_t st) {
     constexpr int NS = (NJ + 1) / 2;
     const size_t lds = (size_t)NS * NT16 * 512 * 4 + (size_t)NT16 * 32 * 4;     // W tile + scale / shift
     auto kern = spconv_rows_kernel<NJ, NT16, GATHER>;
@@ -199,7 +199,7 @@ int launch_rows(const ConvParams& p, const PairList& pl, int64_t n_pos, hipStrea
 }
 
 template <int NJ, bool GATHER>
-int dispatch_rows(const ConvParams& p, const PairList& pl, int64_t n_pos, hipStream_t st) {
+static int dispatch_rows(const ConvParams& p, const PairList& pl, int64_t n_pos, hipStream_t st) {
     if (p.c_out % 128 == 0) return launch_rows<NJ, 8, GATHER>(p, pl, n_pos, st);
     if (p.c_out % 96 == 0) return launch_rows<NJ, 6, GATHER>(p, pl, n_pos, st);
     if (p.c_out % 64 == 0) return launch_rows<NJ, 4, GATHER>(p, pl, n_pos, st);
@@ -207,7 +207,7 @@ int dispatch_rows(const ConvParams& p, const PairList& pl, int64_t n_pos, hipStr
 }
 
 template <bool GATHER>
-int dispatch_rows_nj(const ConvParams& p, const PairList& pl, int64_t n_pos, hipStream_t st) {
+static int dispatch_rows_nj(const ConvParams& p, const PairList& pl, int64_t n_pos, hipStream_t st) {
     switch (p.c_in >> 4) {
         case 2: return dispatch_rows<2, GATHER>(p, pl, n_pos, st);
         case 4: return dispatch_rows<4, GATHER>(p, pl, n_pos, st);
@@ -278,15 +278,13 @@ __global__ __launch_bounds__(256) void spconv_thin_kernel(const ConvParams p) {
     }
 }
 
-bool rows_shapes_ok(int c_in_a, int c_in_b, int c_out, bool gather) {
+static bool rows_shapes_ok(int c_in_a, int c_in_b, int c_out, bool gather) {
     if (c_in_a % 16 != 0 || c_in_b % 16 != 0 || c_out % 32 != 0) return false;
     const int nj = (c_in_a + c_in_b) >> 4;
     return nj == 2 || nj == 4 || nj == 6 || nj == 8 || (nj == 12 && !gather);
     // (256 input channels -- 64-column W tiles -- were built and measured: 348 vs 340 us on the 256 -> 256 transposed layer,
     // 260 vs 254 on 256 -> 128: the tile kernel keeps them)
 }
-
-}  // namespace
 
 bool rows_kernel_applies(const ConvParams& p) {
     if (p.nbr != nullptr || p.row_order != nullptr || p.k_vol != 1 || p.m_in != p.m_out) return false;

@@ -35,6 +35,7 @@ extern "C" {
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
 #define LIDIFF_CONV_DENSE_KERNEL 2  /* lidiff_spconv_fwd flags: software-pipelined kernel for the dense 128-column layers */
 #define LIDIFF_CONV_DENSE_ONE_WAVE 4 /* ... in its four-wave form (one wave per SIMD, 32 columns per wave) */
+#define LIDIFF_CONV_TILE_128 16     /* 64-column layers on 128-row tiles as well (default: 256-row tiles for large maps; A/B measurements) */
 #define LIDIFF_CONV_TILE_ONLY 8     /* identity maps (nbr == NULL) through the tile kernel as well, not the row kernel (A/B measurements, tests) */
 
 int lidiff_abi_version(void);

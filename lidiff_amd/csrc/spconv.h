@@ -11,7 +11,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kChunk = 128;   // pair rows per stage
-constexpr int kWorkInts = 27 * 8 + 8;   // work list capacity: 27 offsets x up to 8 segments of 16 rows
 
 struct ConvParams {
     const float* in_a;

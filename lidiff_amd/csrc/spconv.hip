@@ -47,6 +47,7 @@ struct ConvCfg {
     static constexpr int RBW = RB / WM;          // row blocks per wave
     static constexpr int NCH = BM / kChunk;      // chunks per offset (upper bound)
     static constexpr int A_FLOATS = kChunk * KS; // one A image (16 / 32 KB)
+    static constexpr int WORK_INTS = 27 * (BM / 16) + 8;   // work list capacity: 27 offsets x up to BM / 16 segments of 16 rows
     static_assert(KS == 32 || KS == 64, "KS");
     static_assert(BM % kChunk == 0, "BM");
     static_assert(RB % WM == 0, "WM must divide 8");
@@ -60,7 +61,7 @@ struct ConvCfg {
         b += (size_t)(BM + 1) * BN * 4;                   // accumulator tile + one dummy row (branch-free flush)
         b += (size_t)k_vol * BM * 4;                      // in_list
         b += 32 * 4;                                      // cnt (k_vol <= 27; cnt[31] = #work items)
-        b += (size_t)kWorkInts * 4;                       // work list
+        b += (size_t)WORK_INTS * 4;                       // work list
         b += (size_t)BM * 4;                              // output row of every tile row
         b += (size_t)k_vol * BM * sizeof(OutT);           // out_list
         return (b + 15) & ~(size_t)15;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + (BM + 1) * BN);
     int32_t* cnt = in_list + p.k_vol * BM;
     int32_t* work = cnt + 32;
-    int32_t* orow = work + kWorkInts;                         // output row of every tile row
+    int32_t* orow = work + Cfg::WORK_INTS;                    // output row of every tile row
     // out_list[k][q] = byte offset of the accumulator row of pair q of offset k (its tile row x BN x 4).
     // Entries behind an offset's last pair point at the dummy row BM, so the flush needs no bounds test
     // and one add per element as its only address arithmetic.
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                 for (int q = 0; q < NSW; ++q) {
                     const int sid = (wm + WM * (q * BLQ)) / BPS;
                     const int wi = pack * SEG + sid;
-                    const int e = __builtin_amdgcn_readfirstlane(work[min(wi, kWorkInts - 1)]);
+                    const int e = __builtin_amdgcn_readfirstlane(work[min(wi, Cfg::WORK_INTS - 1)]);
                     const bool ok = wi < nwork;
                     d.k[q] = ok ? (e & 0xff) : 0;
                     d.start[q] = ok ? ((e >> 8) & 0xff) * SEGR : 0;
@@ -769,8 +770,21 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
         if (vec && (flags & LIDIFF_CONV_SPARSE_MAP)) return dispatch_fwd<128, 3, 2>(p, vec, st);
         return dispatch_fwd<128, 6, 1>(p, vec, st);
     }
-    if (c_out % 64 == 0) return dispatch_fwd<128, 4, 2>(p, vec, st);
-    if (c_out % 32 == 0) return dispatch_fwd<128, 2, 4>(p, vec, st);
+    if (c_out % 64 == 0) {
+        // 64-column kernel_size-3 layers (stride-2/4 levels: 1.5-10 neighbours per voxel): 256-row tiles -- the same 64 KB of
+        // accumulators as a 128 x 128 tile, twice the pairs per offset and stage for the same per-stage costs: 5-25 % faster
+        // on the bench maps (profiles/r03_tile256_probe.txt); the stride-2 "down" maps (8 offsets) lose 13-19 % and keep 128
+        // rows, as do maps too small to fill the chip with 256-row tiles (LIDIFF_CONV_TILE_128: always 128 rows)
+        if (vec && k_vol == 27 && !(flags & LIDIFF_CONV_TILE_128) && m_out * replicas >= 256 * 512)
+            return launch_fwd<256, 4, 2, 32, true>(p, st);
+        return dispatch_fwd<128, 4, 2>(p, vec, st);
+    }
+    if (c_out % 32 == 0) {
+        // 32 columns: the other way round -- kernel_size 3 loses 20-35 % on 256-row tiles, the stride-2 maps gain 20 %
+        if (vec && k_vol == 8 && !(flags & LIDIFF_CONV_TILE_128) && m_out * replicas >= 256 * 512)
+            return launch_fwd<256, 2, 4, 32, true>(p, st);
+        return dispatch_fwd<128, 2, 4>(p, vec, st);
+    }
     return dispatch_fwd<128, 1, 8>(p, vec, st);
 }
 

@@ -394,7 +394,8 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     row_order: int32 permutation of the output rows (tile_order()); `nbr` must then hold its columns in that
     order (nbr[:, row_order]).  Results do not depend on it.
     kernel: "tile" | "dense" | "dense1" (default: DENSE_KERNEL) -- which kernel runs a dense 128-column layer;
-    "tile_only" keeps identity maps off the row kernel (spconv_rows.hip) as well.
+    "tile_only" keeps identity maps off the row kernel (spconv_rows.hip) as well; "tile128" keeps 64-column layers on 128-row
+    tiles (large maps take 256-row tiles by default).
     offset: convolve with the single kernel offset w[offset] over the identity map (nbr must be None): the centre of a
     kernel_size-3 map.  tail = (rows [R * P, C_out], ptr int32 [m_out + 1], idx int32 [P]): rows added to the sum before
     the epilogue, out[o] += sum(rows[idx[ptr[o]:ptr[o + 1]]]) -- the other offsets' contributions (TailMap)."""
@@ -437,7 +438,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert t_rows.shape == (replicas * n_tail, c_out) and t_rows.is_contiguous() and t_rows.dtype == torch.float32
         assert t_ptr.dtype == torch.int32 and t_ptr.shape == (m_out + 1,) and t_idx.dtype == torch.int32
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
-    flags = int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6, "tile_only": 8}[kernel or DENSE_KERNEL] | CONV_FLAGS
+    flags = int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6, "tile_only": 8, "tile128": 16}[kernel or DENSE_KERNEL] | CONV_FLAGS
     prof = PROFILER
     variant = None
     if prof is not None:

@@ -650,6 +650,42 @@ def test_spconv_thin_input_kernel_vs_oracle_and_tile_kernel(device, cin):
                 assert torch.allclose(got[r * m:(r + 1) * m].cpu().double(), want, rtol=RTOL, atol=ATOL), (cin, k, r)
 
 
+@pytest.mark.parametrize("cin,split,cout", [(64, 0, 64), (32, 0, 64), (96, 64, 64)])
+def test_spconv_256_row_tiles_vs_128_row_tiles_and_oracle(device, cin, split, cout):
+    """64-column layers on maps of >= 131 072 rows (replicas included) run on 256-row tiles (same accumulator LDS as a
+    128 x 128 tile, twice the pairs per offset and stage): the 128-row kernel's results up to the order in which a tile adds
+    its offsets (a tile decides from its own pair counts whether it packs several offsets into a stage, and packed stages
+    add in a different fixed order: 1 ulp), run-to-run identical, on a stride-4-like map (~6 neighbours per voxel), a
+    low-density one (packed stages: more than 8 segments per offset possible) and a ragged last tile; against the oracle
+    on a sample of rows."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(7 + cin)
+    for cloud, reps, hint in ((random_cloud(200000, 42, 61), 2, False), (random_cloud(80000, 90, 62, batch=2), 2, True),
+                              (random_cloud(140000, 30, 63), 2, False)):
+        uniq, _, _ = me.voxelize(cloud)
+        nbr_np = me.kernel_map(uniq, uniq, 3, 1)
+        nbr = dev_i32(nbr_np, device)
+        m = uniq.shape[0]
+        assert m * reps >= 256 * 512, m
+        x = torch.randn(reps * m, cin, generator=g)
+        w = torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)
+        sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        res = torch.randn(reps * m, cout, generator=g)
+        xd = x.to(device)
+        a = xd[:, :split].contiguous() if split else xd
+        kw = dict(in_b=xd[:, split:].contiguous() if split else None, scale=sc.to(device), shift=sh.to(device),
+                  residual=res.to(device), relu=True, replicas=reps, sparse_map=hint)
+        got = ops.spconv_fwd(a, w.to(device), nbr, m, **kw)
+        ref = ops.spconv_fwd(a, w.to(device), nbr, m, kernel="tile128", **kw)
+        assert torch.equal(got, ops.spconv_fwd(a, w.to(device), nbr, m, **kw))
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), (cin, cout, m, (got - ref).abs().max().item())
+        rows = np.random.default_rng(5).choice(m, 4000, replace=False)
+        sub = nbr_np[:, rows]
+        want = me.conv_forward(x[:m].double(), w.double(), sub)
+        want = torch.relu(want * sc.double() + sh.double() + res[:m][rows].double())
+        assert torch.allclose(got[:m][rows].cpu().double(), want, rtol=RTOL, atol=ATOL)
+
+
 ROW_KERNEL_SHAPES = [(32, 0, 32), (32, 0, 64), (64, 0, 64), (64, 0, 128), (96, 0, 96), (96, 64, 96), (128, 96, 96),
                      (128, 0, 128), (128, 0, 256), (192, 128, 128), (64, 32, 32), (192, 0, 96)]
 

@@ -13,6 +13,22 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 400 python bench.py --no-cpu-baseline --no-train --no-alt --no-coords-roofline --layer-table $O/layer_table.txt > $O/bench_layers.json 2> /dev/null
 timeout 300 python tools/debug/step_timeline.py 2>&1 | grep -v amdgpu > $O/step_timeline.txt
+timeout 300 python tools/debug/boundary_probe.py 2>&1 | grep -v amdgpu > $O/step_boundary.txt
+# row kernels against the tile kernel (flag 8 = LIDIFF_CONV_TILE_ONLY): identity maps, centre + tail, transposed maps
+{
+  C=""; for s in "0,96,96" "0,128,96" "0,32,32" "1,32,64" "2,64,64" "2,64,128" "2,192,128" "3,128,128" "3,128,256"; do C="$C$s,k1,0,0;$s,k1,0,8;"; done
+  echo "# kernel_size 1 (identity map), CFG pair stacked: python tools/conv_probe.py --replicas 2 --cases ... (flags 0 = row kernel, 8 = tile kernel)"
+  timeout 600 python tools/conv_probe.py --replicas 2 --iters 30 --cases "${C%;}" 2>&1 | grep -v amdgpu
+  C=""; for s in "0,96,96" "0,128,96" "0,32,32" "1,32,32" "1,96,96"; do C="$C$s,k3,1,0;$s,k3,1,8;"; done
+  echo "# kernel_size 3 as centre + tail (--centre-tail): tail pass + centre pass"
+  timeout 600 python tools/conv_probe.py --replicas 2 --iters 30 --centre-tail --cases "${C%;}" 2>&1 | grep -v amdgpu
+  C=""; for s in "3,256,256" "2,256,128" "2,128,128" "1,128,96" "0,96,96"; do C="$C$s,up,0,0;$s,up,0,8;"; done
+  echo "# transposed kernel_size 2 / stride 2 (--up-ordered): pair-list kernel vs tile kernel with offset-grouped rows"
+  timeout 600 python tools/conv_probe.py --replicas 2 --iters 30 --up-ordered --cases "${C%;}" 2>&1 | grep -v amdgpu
+  echo "# the stem (3 -> 32, one replica): thin-input kernel vs tile kernel, and vs centre + tail on the tile kernel"
+  timeout 300 python tools/conv_probe.py --replicas 1 --iters 30 --cases "0,3,32,k3,1,0;0,3,32,k3,1,8" 2>&1 | grep -v amdgpu
+  timeout 300 python tools/conv_probe.py --replicas 1 --iters 30 --centre-tail --cases "0,3,32,k3,1,8" 2>&1 | grep -v amdgpu
+} > $O/row_kernel_probe.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train > $O/bench_prof.json 2> $O/bench_prof.err
 cd $R

@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["coords.hip", "spconv.hip", "spconv_dense.hip", "spconv_rows.hip", "spconv_bf16.hip"]
+SOURCES = ["coords.hip", "spconv.hip", "spconv_dense.hip", "spconv_rows.hip", "spconv_bf16.hip", "norm.hip"]
 HEADERS = ["common.h", "spconv.h", os.path.join("..", "..", "include", "lidiff_amd.h")]
 LIB = os.path.join(HERE, "liblidiff_amd.so")
 ARCH = "gfx950"

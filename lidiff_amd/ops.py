@@ -459,6 +459,65 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     return out
 
 
+# training-mode BatchNorm through the HIP kernels of norm.hip (False: torch's batch_norm kernels)
+FUSED_BN_TRAIN = os.environ.get("LIDIFF_FUSED_BN", "1") != "0"
+
+
+def bn_train_applies(x: torch.Tensor) -> bool:
+    return (FUSED_BN_TRAIN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 2
+            and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """Training-mode nn.BatchNorm1d on a feature matrix [M, C] (MinkowskiBatchNorm, minkunet.py:23) through lidiff_bn_stats /
+    lidiff_bn_apply / lidiff_bn_bwd: batch statistics with double accumulators in a fixed order (deterministic), running
+    estimates updated as torch does (momentum, unbiased variance).  relu: the MinkowskiReLU that follows, fused."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        x = x.contiguous()
+        m, c = x.shape
+        dev = x.device
+        stats = torch.empty((3, c), dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().lidiff_bn_workspace_bytes(c), dtype=torch.uint8, device=dev)
+        call("lidiff_bn_stats", ptr(x), m, c, float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(ws), stream_ptr())
+        y = torch.empty_like(x)
+        w = None if weight is None else weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        call("lidiff_bn_apply", ptr(x), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(b), int(bool(relu)), ptr(y), stream_ptr())
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1.0 - momentum).add_(stats[0], alpha=momentum)
+                running_var.mul_(1.0 - momentum).add_(stats[1], alpha=momentum * m / (m - 1))
+        ctx.save_for_backward(x, w, stats, y if relu else None)
+        ctx.relu = bool(relu)
+        ctx.has_affine = (weight is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, stats, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        m, c = x.shape
+        sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(_lib.load().lidiff_bn_workspace_bytes(c), dtype=torch.uint8, device=x.device)
+        call("lidiff_bn_bwd", ptr(dy), ptr(x), ptr(y), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(sums[0]), ptr(sums[1]),
+             ptr(dx), ptr(ws), stream_ptr())
+        dw = sums[1] * stats[2] if ctx.has_affine[0] and ctx.needs_input_grad[1] else None
+        db = sums[0].clone() if ctx.has_affine[1] and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None, None, None, None
+
+
+def batch_norm_train(x, bn: torch.nn.BatchNorm1d, relu: bool = False):
+    """bn(x) in training mode (optionally followed by ReLU) through _BatchNormTrain; counts the batch like torch does."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu)
+
+
 def pairs_kernel_applies(c_a: int, c_b: int, c_out: int) -> bool:
     """Shapes lidiff_spconv_fwd_pairs takes (input widths multiples of 16 summing to 32 / 64 / 96 / 128, C_out % 32 == 0)."""
     return bool(_lib.load().lidiff_spconv_fwd_pairs_supported(c_a, c_b, c_out)) and not (CONV_FLAGS & 8)

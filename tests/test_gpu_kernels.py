@@ -686,6 +686,57 @@ def test_spconv_256_row_tiles_vs_128_row_tiles_and_oracle(device, cin, split, co
         assert torch.allclose(got[:m][rows].cpu().double(), want, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("m,c", [(2, 32), (37, 96), (5000, 256), (120001, 64), (70000, 128), (9, 4)])
+def test_batch_norm_train_kernels_vs_torch_float64(device, m, c):
+    """lidiff_bn_stats / lidiff_bn_apply / lidiff_bn_bwd (ops._BatchNormTrain: the training-mode MinkowskiBatchNorm) against
+    nn.BatchNorm1d in float64 on the CPU: output, input / weight / bias gradients, running estimates and the batch counter;
+    with a large common offset on the inputs (the variance must not cancel), with and without the fused ReLU, run-to-run
+    identical."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(m + c)
+    x = torch.randn(m, c, generator=g) * (torch.rand(c, generator=g) * 3 + 0.1) + torch.randn(c, generator=g) * 20
+    r = torch.randn(m, c, generator=g)
+    for relu in (False, True):
+        ref = torch.nn.BatchNorm1d(c).double()
+        with torch.no_grad():
+            ref.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            ref.bias.copy_(torch.randn(c, generator=g))
+        bn = torch.nn.BatchNorm1d(c).to(device)
+        bn.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+        ref.train(); bn.train()
+        xr = x.double().requires_grad_(True)
+        pre = ref(xr)
+        yr = torch.relu(pre) if relu else pre
+        (yr * r.double()).sum().backward()
+        xd = x.to(device).requires_grad_(True)
+        y = ops.batch_norm_train(xd, bn, relu=relu)
+        (y * r.to(device)).sum().backward()
+        scale = float(yr.abs().max())
+        assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=1e-5, atol=2e-6 * max(1.0, scale)), (m, c, relu)
+        gs = float(xr.grad.abs().max())
+        # (a handful of rows: nearly equal samples give a tiny variance, and dx is a difference of terms 1 / sqrt(var + eps)
+        # times larger than itself -- float32 cancellation, not an error of the kernel: looser bar)
+        g_rtol, g_atol = (1e-4, 2e-6 * max(1.0, gs)) if m >= 1000 else (2e-2, 2e-3 * max(1.0, gs))
+        got_g, want_g = xd.grad.cpu().double(), xr.grad
+        if relu:            # an output within rounding of the kink may fall on the other side of it: such elements carry a full dy
+            flip = (pre.detach().abs() < 1e-5 * max(1.0, scale))
+            assert flip.float().mean() < 1e-3
+            far = ~flip.any(1)                           # (a flipped element changes its whole row's dx through the sums only weakly)
+            assert torch.allclose(got_g[far], want_g[far], rtol=max(g_rtol, 1e-3), atol=max(g_atol, 1e-4 * gs)), (m, c, relu)
+        else:
+            assert torch.allclose(got_g, want_g, rtol=g_rtol, atol=g_atol), (m, c, relu)
+        p_tol = 1e-4 if not relu else 1e-2          # (with ReLU a few outputs at the kink change side: whole dy terms in the sums)
+        assert torch.allclose(bn.weight.grad.cpu().double(), ref.weight.grad, rtol=p_tol, atol=p_tol * float(ref.weight.grad.abs().max()))
+        assert torch.allclose(bn.bias.grad.cpu().double(), ref.bias.grad, rtol=p_tol, atol=p_tol * float(ref.bias.grad.abs().max()))
+        assert torch.allclose(bn.running_mean.cpu().double(), ref.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn.running_var.cpu().double(), ref.running_var, rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
+        bn2 = torch.nn.BatchNorm1d(c).to(device)
+        bn2.load_state_dict({k: v.float() for k, v in ref.state_dict().items() if "running" not in k and "num" not in k}, strict=False)
+        y2 = ops.batch_norm_train(x.to(device), bn2, relu=relu)
+        assert torch.equal(y2, y.detach())
+
+
 ROW_KERNEL_SHAPES = [(32, 0, 32), (32, 0, 64), (64, 0, 64), (64, 0, 128), (96, 0, 96), (96, 64, 96), (128, 96, 96),
                      (128, 0, 128), (128, 0, 256), (192, 128, 128), (64, 32, 32), (192, 0, 96)]
 

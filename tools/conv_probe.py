@@ -53,7 +53,7 @@ def main():
                                                                  ("spconv.hip", "spconv_dense.hip", "spconv_bf16.hip", "coords.hip", "spconv.h")):
             subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-DLIDIFF_CONV_PROBE",
                             "-shared", os.path.join(csrc, "spconv.hip"), os.path.join(csrc, "spconv_dense.hip"), os.path.join(csrc, "spconv_rows.hip"),
-                            os.path.join(csrc, "spconv_bf16.hip"), os.path.join(csrc, "coords.hip"), "-o", lib], check=True)
+                            os.path.join(csrc, "spconv_bf16.hip"), os.path.join(csrc, "coords.hip"), os.path.join(csrc, "norm.hip"), "-o", lib], check=True)
         _lib.LIB_PATH = lib
         _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))
     from lidiff_amd import ops

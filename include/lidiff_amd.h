@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 21
+#define LIDIFF_ABI_VERSION 22
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -318,18 +318,20 @@ int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m,
  * partial sums combined in a fixed order: deterministic.  c a multiple of 4, pointers 16-byte aligned.
  *   lidiff_bn_stats : mean[c], var[c] (BIASED: the normaliser; the running estimate takes var * m / (m - 1)),
  *                     invstd[c] = 1 / sqrt(var + eps).  workspace: lidiff_bn_workspace_bytes(c).
- *   lidiff_bn_apply : y = (x - mean) * invstd * gamma + beta (gamma / beta nullable), ReLU on request (relu != 0).
+ *   lidiff_bn_apply : y = (x - mean) * invstd * gamma + beta (gamma / beta nullable) [+ residual, nullable: the ResidualBlock's
+ *                     shortcut, minkunet.py:79], ReLU on request (relu != 0).
  *   lidiff_bn_bwd   : sum_dy[c] = sum dy, sum_dy_xmu[c] = sum dy * (x - mean) (d beta and, times invstd, d gamma), and -- unless
  *                     dx == NULL -- dx = (dy - sum_dy / m - (x - mean) * invstd^2 * sum_dy_xmu / m) * invstd * gamma.
- *                     y_relu != NULL: the forward applied ReLU and y_relu is its output -- dy counts only where y_relu > 0. */
+ *                     y_relu != NULL: the forward applied ReLU and y_relu is its output -- dy counts only where y_relu > 0.
+ *                     d_residual != NULL: receives that (masked) dy, the gradient of the forward's residual operand. */
 int64_t lidiff_bn_workspace_bytes(int32_t c);
 int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, float* mean, float* var, float* invstd, void* workspace,
                     void* stream);
 int lidiff_bn_apply(const float* x, int64_t m, int32_t c, const float* mean, const float* invstd, const float* gamma,
-                    const float* beta, int32_t relu, float* y, void* stream);
+                    const float* beta, const float* residual, int32_t relu, float* y, void* stream);
 int lidiff_bn_bwd(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
-                  const float* invstd, const float* gamma, float* sum_dy, float* sum_dy_xmu, float* dx, void* workspace,
-                  void* stream);
+                  const float* invstd, const float* gamma, float* sum_dy, float* sum_dy_xmu, float* dx, float* d_residual,
+                  void* workspace, void* stream);
 
 /* Farthest-point sampling -- DiffCompletion.preprocess_scan, pipeline:92-105 (open3d farthest_point_down_sample):
  * points [n,3] float64; selected[0] = 0, selected[i+1] = the point farthest (squared distance, first maximum) from

@@ -54,8 +54,8 @@ SIGNATURES = {
     "lidiff_spconv_bwd_w_bf16": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p]),
     "lidiff_bn_workspace_bytes": (_i64, [_i32]),
     "lidiff_bn_stats": (_i32, [_p, _i64, _i32, C.c_float, _p, _p, _p, _p, _p]),
-    "lidiff_bn_apply": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
-    "lidiff_bn_bwd": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "lidiff_bn_apply": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),
+    "lidiff_bn_bwd": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
@@ -72,7 +72,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 

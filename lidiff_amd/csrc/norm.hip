@@ -102,8 +102,8 @@ __global__ __launch_bounds__(kWave) void bn_finish_bwd_kernel(const double* __re
 
 template <bool RELU>
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, int64_t total4, int cq,
-                                float* __restrict__ y) {
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ residual, int64_t total4, int cq, float* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     const int q = (int)(i % cq);
@@ -115,6 +115,10 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     float4 o;
     o.x = (xv.x - mu.x) * is.x * g.x + bb.x; o.y = (xv.y - mu.y) * is.y * g.y + bb.y;
     o.z = (xv.z - mu.z) * is.z * g.z + bb.z; o.w = (xv.w - mu.w) * is.w * g.w + bb.w;
+    if (residual) {
+        const float4 r = reinterpret_cast<const float4*>(residual)[i];
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
     if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     reinterpret_cast<float4*>(y)[i] = o;
 }
@@ -124,7 +128,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ sum_dy,
                                     const float* __restrict__ sum_dy_xmu, int64_t total4, int cq, float inv_m,
-                                    float* __restrict__ dx) {
+                                    float* __restrict__ dx, float* __restrict__ d_residual) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     const int q = (int)(i % cq);
@@ -133,6 +137,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         const float4 yv = reinterpret_cast<const float4*>(y)[i];
         g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     }
+    if (d_residual) reinterpret_cast<float4*>(d_residual)[i] = g;          // the residual branch's gradient: dy behind the ReLU
+    if (dx == nullptr) return;
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     const float4 mu = reinterpret_cast<const float4*>(mean)[q], is = reinterpret_cast<const float4*>(invstd)[q];
     const float4 sd = reinterpret_cast<const float4*>(sum_dy)[q], sx = reinterpret_cast<const float4*>(sum_dy_xmu)[q];
@@ -181,21 +187,22 @@ extern "C" int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, 
 }
 
 extern "C" int lidiff_bn_apply(const float* x, int64_t m, int32_t c, const float* mean, const float* invstd,
-                               const float* gamma, const float* beta, int32_t relu, float* y, void* stream) {
+                               const float* gamma, const float* beta, const float* residual, int32_t relu, float* y,
+                               void* stream) {
     LIDIFF_CHECK_ARG(x && mean && invstd && y, "null pointer");
     LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
     hipStream_t st = (hipStream_t)stream;
     const int64_t total4 = m * (c / 4);
     const unsigned grid = (unsigned)ceil_div(total4, 256);
-    if (relu) bn_apply_kernel<true><<<grid, 256, 0, st>>>(x, mean, invstd, gamma, beta, total4, c / 4, y);
-    else bn_apply_kernel<false><<<grid, 256, 0, st>>>(x, mean, invstd, gamma, beta, total4, c / 4, y);
+    if (relu) bn_apply_kernel<true><<<grid, 256, 0, st>>>(x, mean, invstd, gamma, beta, residual, total4, c / 4, y);
+    else bn_apply_kernel<false><<<grid, 256, 0, st>>>(x, mean, invstd, gamma, beta, residual, total4, c / 4, y);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int lidiff_bn_bwd(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                              const float* invstd, const float* gamma, float* sum_dy, float* sum_dy_xmu, float* dx,
-                             void* workspace, void* stream) {
+                             float* d_residual, void* workspace, void* stream) {
     LIDIFF_CHECK_ARG(dy && x && mean && invstd && sum_dy && sum_dy_xmu && workspace, "null pointer");
     LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
     hipStream_t st = (hipStream_t)stream;
@@ -205,12 +212,12 @@ extern "C" int lidiff_bn_bwd(const float* dy, const float* x, const float* y_rel
     if (y_relu) bn_reduce_kernel<true, true><<<nblk, kBnBlock, lds, st>>>(x, dy, y_relu, mean, m, c, per, (double*)workspace);
     else bn_reduce_kernel<true, false><<<nblk, kBnBlock, lds, st>>>(x, dy, nullptr, mean, m, c, per, (double*)workspace);
     bn_finish_bwd_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, sum_dy, sum_dy_xmu);
-    if (dx != nullptr) {
+    if (dx != nullptr || d_residual != nullptr) {
         const int64_t total4 = m * (c / 4);
         const unsigned grid = (unsigned)ceil_div(total4, 256);
         const float inv_m = 1.0f / (float)m;
-        if (y_relu) bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(dy, x, y_relu, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, inv_m, dx);
-        else bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(dy, x, nullptr, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, inv_m, dx);
+        if (y_relu) bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(dy, x, y_relu, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, inv_m, dx, d_residual);
+        else bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(dy, x, nullptr, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, inv_m, dx, d_residual);
     }
     LIDIFF_CHECK_LAUNCH();
     return 0;

@@ -95,6 +95,25 @@ _CENTRE_TAIL = True
 _UP_ORDERED = os.environ.get("LIDIFF_UP_ORDERED", "1") != "0"
 
 
+def _run_seq(seq, x: ME.SparseTensor) -> ME.SparseTensor:
+    """seq(x) for a Sequential of ME modules -- module by module, as nn.Sequential does, except that in training a
+    MinkowskiBatchNorm directly followed by a MinkowskiReLU runs as ONE normalise + ReLU pass (ops._BatchNormTrain(relu=True):
+    no separate ReLU pass forward, its mask folded into the BatchNorm backward; same values)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if (i + 1 < len(mods) and type(m) is ME.MinkowskiBatchNorm and isinstance(mods[i + 1], ME.MinkowskiReLU)
+                and type(m.bn) is nn.BatchNorm1d and m.bn.training and m.bn.momentum is not None and torch.is_grad_enabled()
+                and ops.bn_train_applies(x.F)):
+            x = x._like(ops.batch_norm_train(x.F, m.bn, relu=True))
+            i += 2
+            continue
+        x = m(x)
+        i += 1
+    return x
+
+
 def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=None) -> ME.SparseTensor:
     """relu?( bn(conv([x | extra])) + residual ) as ONE kernel launch (eval mode only)."""
     nbr, _, ts_out, _ = conv.maps(x)
@@ -144,7 +163,7 @@ class BasicConvolutionBlock(nn.Module):
     def forward(self, x):
         if _fusable(self):
             return conv_bn_act(self.net[0], self.net[1], x, relu=True)
-        return self.net(x)
+        return _run_seq(self.net, x)
 
 
 class BasicDeconvolutionBlock(nn.Module):
@@ -157,7 +176,7 @@ class BasicDeconvolutionBlock(nn.Module):
     def forward(self, x):
         if _fusable(self):
             return conv_bn_act(self.net[0], self.net[1], x, relu=True)
-        return self.net(x)
+        return _run_seq(self.net, x)
 
 
 class ResidualBlock(nn.Module):
@@ -184,7 +203,14 @@ class ResidualBlock(nn.Module):
             return conv_bn_act(self.net[3], self.net[4], y, relu=True, residual=short)
         if extra is not None:
             x = x._like(torch.cat([x.F, extra], dim=1))
-        return self.relu(self.net(x) + self.downsample(x))
+        last = self.net[-1]
+        if (type(last) is ME.MinkowskiBatchNorm and type(last.bn) is nn.BatchNorm1d and last.bn.training
+                and last.bn.momentum is not None and torch.is_grad_enabled() and ops.bn_train_applies(x.F)):
+            # training: the block's last BatchNorm, the shortcut add and the ReLU as one pass (ops._BatchNormTrain)
+            h = _run_seq(self.net[:-1], x)
+            r = self.downsample(x)
+            return h._like(ops.batch_norm_train(h.F, last.bn, relu=True, residual=r.F))
+        return self.relu(_run_seq(self.net, x) + self.downsample(x))
 
 
 def _stem(cin, c, D):
@@ -198,7 +224,7 @@ def _stem(cin, c, D):
 def _run_stem(stem, x):
     if _fusable(stem):
         return conv_bn_act(stem[3], stem[4], conv_bn_act(stem[0], stem[1], x, relu=True), relu=True)
-    return stem(x)
+    return _run_seq(stem, x)
 
 
 def _stage(cin, cout, D):

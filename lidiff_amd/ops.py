@@ -471,11 +471,13 @@ def bn_train_applies(x: torch.Tensor) -> bool:
 class _BatchNormTrain(torch.autograd.Function):
     """Training-mode nn.BatchNorm1d on a feature matrix [M, C] (MinkowskiBatchNorm, minkunet.py:23) through lidiff_bn_stats /
     lidiff_bn_apply / lidiff_bn_bwd: batch statistics with double accumulators in a fixed order (deterministic), running
-    estimates updated as torch does (momentum, unbiased variance).  relu: the MinkowskiReLU that follows, fused."""
+    estimates updated as torch does (momentum, unbiased variance).  relu: the MinkowskiReLU that follows, fused; residual: the
+    ResidualBlock's shortcut added in front of that ReLU (minkunet.py:79: relu(net(x) + downsample(x))), fused as well."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual=None):
         x = x.contiguous()
+        residual = None if residual is None else residual.contiguous()
         m, c = x.shape
         dev = x.device
         stats = torch.empty((3, c), dtype=torch.float32, device=dev)
@@ -484,7 +486,8 @@ class _BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
-        call("lidiff_bn_apply", ptr(x), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(b), int(bool(relu)), ptr(y), stream_ptr())
+        call("lidiff_bn_apply", ptr(x), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(b), ptr(residual), int(bool(relu)), ptr(y),
+             stream_ptr())
         if running_mean is not None:
             with torch.no_grad():
                 running_mean.mul_(1.0 - momentum).add_(stats[0], alpha=momentum)
@@ -492,6 +495,7 @@ class _BatchNormTrain(torch.autograd.Function):
         ctx.save_for_backward(x, w, stats, y if relu else None)
         ctx.relu = bool(relu)
         ctx.has_affine = (weight is not None, bias is not None)
+        ctx.has_residual = residual is not None
         return y
 
     @staticmethod
@@ -501,21 +505,24 @@ class _BatchNormTrain(torch.autograd.Function):
         m, c = x.shape
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dres = None
+        if ctx.has_residual and ctx.needs_input_grad[8]:
+            dres = torch.empty_like(x) if ctx.relu else dy      # without ReLU the residual's gradient is dy itself
         ws = torch.empty(_lib.load().lidiff_bn_workspace_bytes(c), dtype=torch.uint8, device=x.device)
         call("lidiff_bn_bwd", ptr(dy), ptr(x), ptr(y), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(sums[0]), ptr(sums[1]),
-             ptr(dx), ptr(ws), stream_ptr())
+             ptr(dx), ptr(dres) if ctx.relu else None, ptr(ws), stream_ptr())
         dw = sums[1] * stats[2] if ctx.has_affine[0] and ctx.needs_input_grad[1] else None
         db = sums[0].clone() if ctx.has_affine[1] and ctx.needs_input_grad[2] else None
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, dres
 
 
-def batch_norm_train(x, bn: torch.nn.BatchNorm1d, relu: bool = False):
+def batch_norm_train(x, bn: torch.nn.BatchNorm1d, relu: bool = False, residual=None):
     """bn(x) in training mode (optionally followed by ReLU) through _BatchNormTrain; counts the batch like torch does."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu)
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu, residual)
 
 
 def pairs_kernel_applies(c_a: int, c_b: int, c_out: int) -> bool:

@@ -7,6 +7,8 @@ gradient all-reduce through lidiff_amd.dist.GradAllReducer, SyncBatchNorm via
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -89,6 +91,30 @@ class DiffusionPoints(nn.Module):
         out = self.model(x_full, x_full_sparse, part_feat, t)
         return out.reshape(t.shape[0], -1, 3)
 
+    # The part -> full matches of the five levels (minkunet.py:403-416: exhaustive arg-min, 0.8 ms each at B = 2 x 180 000 points)
+    # need only coordinates: queued on a side stream as soon as both pyramids exist, they run under the condition encoder;
+    # MinkUNetDiff.match_index makes the consuming stream wait for its level's event.  LIDIFF_MATCHES_AHEAD=0: inline.
+    matches_ahead = os.environ.get("LIDIFF_MATCHES_AHEAD", "1") != "0"
+
+    def _matches_ahead(self, x_full, x_part):
+        if not self.matches_ahead or x_full.F.device.type != "cuda" or x_part.coordinate_manager.maps[1].coords.shape[0] <= 1:
+            return
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main, side = torch.cuda.current_stream(self.device), self._side
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side.wait_event(ready)
+        empty = torch.empty((0, 0), device=self.device)
+        mgr_f, mgr_p = x_full.coordinate_manager, x_part.coordinate_manager
+        top = max(mgr_p.maps)                                  # the encoder's output lives on the part's coarsest map
+        with torch.cuda.stream(side), torch.no_grad():
+            part = ME.SparseTensor(empty, tensor_stride=top, coordinate_manager=mgr_p)
+            for ts in sorted(mgr_f.maps):
+                self.model.match_index(ME.SparseTensor(empty, tensor_stride=ts, coordinate_manager=mgr_f), part, ahead=True)
+            self._matches_done = torch.cuda.Event()
+            self._matches_done.record(side)
+
     # models.py:153-154
     @staticmethod
     def p_losses(y, noise):
@@ -115,8 +141,12 @@ class DiffusionPoints(nn.Module):
             x_part = self.points_to_tensor(torch.zeros_like(pcd_part))
         prebuild_maps(x_full)
         prebuild_maps(x_part)
+        self._matches_ahead(x_full, x_part)
         with ops.train_operands("bf16" if self.precision == "bf16" else "f32"):
             denoise_t = self.forward(x_full, x_full.sparse(), x_part, t)
+        if getattr(self, "_matches_done", None) is not None:      # (every level's match is consumed by the forward; belt and braces
+            torch.cuda.current_stream(self.device).wait_event(self._matches_done)      # for the coordinates' lifetime)
+            self._matches_done = None
         loss_mse = self.p_losses(denoise_t, noise)
         loss_mean = denoise_t.mean() ** 2
         loss_std = (denoise_t.std() - 1.0) ** 2

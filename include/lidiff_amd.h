@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 22
+#define LIDIFF_ABI_VERSION 23
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -275,6 +275,11 @@ int lidiff_spconv_bwd_w_bf16(const float* in_a, int32_t c_in_a, const float* in_
  * x_part.F[idx] of match_part_to_full minkunet.py:418; scatter-add is their backward. */
 int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
                        float* dst, void* stream);
+/* The same sum without atomics: dst[o, :] = sum of src[order[q], :] over q in [ptr[o], ptr[o + 1]), in list order -- `order` the
+ * sources sorted by destination row (stable: source order inside a destination), `ptr` [m + 1] the CSR over the m destination
+ * rows.  Deterministic: the backward of SparseTensor.slice and of the conditioning gathers in training (models.py:180-217). */
+int lidiff_segment_sum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t m, int32_t c, float* dst,
+                            void* stream);
 int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
                             float* dst, void* stream);
 

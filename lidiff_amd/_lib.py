@@ -60,6 +60,7 @@ SIGNATURES = {
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
     "lidiff_scatter_add_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "lidiff_segment_sum_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_mul_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     "lidiff_nn_match": (_i32, [_p, _i64, _p, _i64, _p, _p, _p]),
     "lidiff_argmin_rows_f32": (_i32, [_p, _i64, _p, _i64, _p, _p]),
@@ -72,7 +73,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 

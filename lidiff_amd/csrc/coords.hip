@@ -664,6 +664,31 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int
     atomicAdd(&dst[idx[r] * c + e % c], src[e]);
 }
 
+// dst[o] = sum of src[order[q]] for q in [ptr[o], ptr[o + 1]) -- the scatter-add over a destination-sorted source list: every
+// destination row adds its sources in list order (the stable sort keeps source order), no atomics: deterministic.
+template <bool VEC4>
+__global__ void segment_sum_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ order,
+                                        const int64_t* __restrict__ ptr, int64_t m, int c, float* __restrict__ dst) {
+    const int cw = VEC4 ? c / 4 : c;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * cw) return;
+    const int64_t o = e / cw;
+    const int j = (int)(e % cw);
+    const int64_t lo = ptr[o], hi = ptr[o + 1];
+    if constexpr (VEC4) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t q = lo; q < hi; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(src + order[q] * c)[j];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4*>(dst + o * c)[j] = a;
+    } else {
+        float a = 0.f;
+        for (int64_t q = lo; q < hi; ++q) a += src[order[q] * c + j];
+        dst[o * c + j] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // nearest part voxel: one full row per lane, part rows streamed through LDS tiles; fp32
 // arithmetic as pykeops does (exact on integer coordinates below 2^12), strict '<' while
@@ -1333,6 +1358,19 @@ int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows
     if (n_rows == 0) return 0;
     scatter_add_rows_kernel<<<(unsigned)ceil_div(n_rows * c, kBlock), kBlock, 0, (hipStream_t)stream>>>(
         src, idx, n_rows, c, dst);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_segment_sum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t m, int32_t c, float* dst,
+                            void* stream) {
+    LIDIFF_CHECK_ARG(c > 0 && m >= 0, "bad shape");
+    if (m == 0) return 0;
+    LIDIFF_CHECK_ARG(src && order && ptr && dst, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    if (vec) segment_sum_rows_kernel<true><<<(unsigned)ceil_div(m * (c / 4), kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst);
+    else segment_sum_rows_kernel<false><<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

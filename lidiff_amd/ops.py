@@ -822,9 +822,35 @@ def gather_mul_rows(x: torch.Tensor, table: torch.Tensor, idx: torch.Tensor, out
     return out
 
 
+# scatter-adds (the backward of row gathers) as segment sums over a destination-sorted source list: deterministic, no atomics
+DETERMINISTIC_SCATTER = os.environ.get("LIDIFF_DETERMINISTIC_SCATTER", "1") != "0"
+
+
+def _scatter_csr(idx: torch.Tensor, m: int):
+    """(order, ptr) of a gather index: its sources stably sorted by destination row and the CSR over the m destination rows.
+    Cached on the index tensor (a step's inverse mapping / match index is scattered through once per consumer layer)."""
+    key = (idx.data_ptr(), idx._version, idx.shape[0], m)
+    hit = getattr(idx, "_lidiff_csr", None)
+    if hit is None or hit[0] != key:
+        sorted_idx, order = torch.sort(idx, stable=True)
+        ptr_ = torch.searchsorted(sorted_idx, torch.arange(m + 1, device=idx.device, dtype=idx.dtype))
+        hit = (key, order.contiguous(), ptr_.contiguous())
+        try:
+            idx._lidiff_csr = hit
+        except AttributeError:
+            pass
+    return hit[1], hit[2]
+
+
 def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tensor:
+    """dst[idx[i]] += src[i] over the rows i (dst [m, C]): the backward of gather_rows."""
     src = src.contiguous()
     n, c = src.shape
+    if DETERMINISTIC_SCATTER and n > 0:
+        order, ptr_ = _scatter_csr(idx.contiguous(), m)
+        dst = torch.empty((m, c), dtype=torch.float32, device=src.device)
+        call("lidiff_segment_sum_rows", ptr(src), ptr(order), ptr(ptr_), m, c, ptr(dst), stream_ptr())
+        return dst
     dst = torch.zeros((m, c), dtype=torch.float32, device=src.device)
     call("lidiff_scatter_add_rows", ptr(src), ptr(idx.contiguous()), n, c, ptr(dst), stream_ptr())
     return dst

@@ -756,6 +756,29 @@ def test_batch_norm_train_kernels_vs_torch_float64(device, m, c):
             assert torch.allclose(xd3.grad.cpu().double(), x3.grad, rtol=1e-4, atol=2e-6 * max(1.0, float(x3.grad.abs().max())))
 
 
+def test_scatter_add_as_segment_sum_is_deterministic(device):
+    """ops.scatter_add_rows through lidiff_segment_sum_rows (sources stably sorted by destination, CSR, no atomics): equal to a
+    float64 index_add, identical from run to run, for a many-to-one index (a match index), a near-permutation (an inverse
+    mapping), destinations without sources, and widths that are not multiples of 4."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for n, m, c in ((200000, 6000, 96), (50000, 49000, 3), (1000, 5, 32), (7, 20, 4)):
+        idx = torch.randint(0, m, (n,), generator=g)
+        if m == 20:
+            idx = idx.clamp(max=9)                       # destinations 10 .. 19 stay empty
+        src = torch.randn(n, c, generator=g) * 3
+        want = torch.zeros(m, c, dtype=torch.float64).index_add_(0, idx, src.double())
+        got = ops.scatter_add_rows(src.to(device), idx.to(device), m)
+        assert torch.equal(got, ops.scatter_add_rows(src.to(device), idx.to(device), m))
+        assert torch.allclose(got.cpu().double(), want, rtol=1e-5, atol=1e-4)
+        ops.DETERMINISTIC_SCATTER = False
+        try:
+            atom = ops.scatter_add_rows(src.to(device), idx.to(device), m)
+        finally:
+            ops.DETERMINISTIC_SCATTER = True
+        assert torch.allclose(got, atom, rtol=1e-5, atol=1e-4)
+
+
 ROW_KERNEL_SHAPES = [(32, 0, 32), (32, 0, 64), (64, 0, 64), (64, 0, 128), (96, 0, 96), (96, 64, 96), (128, 96, 96),
                      (128, 0, 128), (128, 0, 256), (192, 128, 128), (64, 32, 32), (192, 0, 96)]
 

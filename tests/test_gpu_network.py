@@ -633,6 +633,28 @@ def _a18_module(seed, dev):
     return mod
 
 
+@pytest.mark.parametrize("precision", ["32", "bf16"])
+def test_training_step_is_bit_reproducible(device, precision):
+    """Two runs of the same DiffusionPoints training step (same weights, batch and draws) give the SAME loss and the same 322
+    parameter gradients bit for bit, in fp32 and with bf16 convolution operands: every kernel of the step is deterministic
+    (fixed-point voxel mean, output-stationary convolutions, slice-ordered dW, double-precision BatchNorm statistics in a fixed
+    order, segment-sum scatter-adds, matches queued ahead on a side stream included)."""
+    from lidiff_amd.diffusion import DiffusionPoints
+    batch = _a18_batches()[1]
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(123)
+        mod = DiffusionPoints(device=device, precision=precision)
+        mod.train()
+        loss = mod.training_step(batch, 0, noise=batch["noise"], t=batch["t"], drop=False)
+        loss.backward()
+        runs.append((loss.detach().cpu(), {k: v.grad.detach().cpu() for k, v in mod.named_parameters() if v.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert runs[0][1].keys() == runs[1][1].keys() and len(runs[0][1]) > 300
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
 def _two_rank_gloo_one_gpu_worker(rank, world, port, q):
     import hashlib
     import torch.distributed as tdist

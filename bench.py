@@ -200,6 +200,7 @@ def coords_roofline(scan_np, device, iters=5):
 
     def build():
         f = ME.TensorField(features=pts, coordinates=coord, device=device)
+        f.coordinate_manager.pyramid = True          # the pipeline's path: device-side row counts, ONE host read (ops.build_pyramid)
         f.sparse()
         mgr = f.coordinate_manager
         ts = 1
@@ -230,13 +231,13 @@ def coords_roofline(scan_np, device, iters=5):
             nbytes += 2 * (16.0 * (m[l] + m[l + 1]) + 8.0 * m[l])        # ks2 table and its transpose (P = M_l)
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"kernel": "coordinate pipeline of one 180000-point x_t (sigma 1): voxel hash + mean, 4 strided maps, 5 ks3 / 4 ks2 / "
-                      "4 transposed kernel maps (coords.hip; includes the host reads of the map sizes)",
+                      "4 transposed kernel maps (coords.hip; the pyramid's row counts stay on the device: one host read of all sizes)",
             "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
             "traffic": coords_traffic_from_profile()[0],
             "traffic_unit": "GB per denoising step moved by the coordinate kernels of ALL three fields of a step (x_t, x_cond, x_uncond: "
                             "hash insert / flag / scan / inverse / mean / kernel maps; rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; static: "
                             + str(coords_traffic_from_profile()[1]) + ") -- `achieved` is one x_t's pyramid alone",
-            "ms": ms, "algorithmic_mbytes": nbytes / 1e6, "voxels_per_level": m}
+            "ms": ms, "algorithmic_mbytes": nbytes / 1e6, "voxels_per_level": m, "host_reads": 1}
 
 
 def train_leg(scan_np, device, steps=3, warmup=1):

@@ -97,7 +97,8 @@ class CoordinateManager:
         st = self._async[1 if second else 0]
         with torch.cuda.stream(st):
             yield
-        _lib.mark_pending(st)
+        if not second:                   # (the second stream's callbacks publish their results with their own events: a
+            _lib.mark_pending(st)        #  consumer of level 0's match must not wait for the matches of all five levels)
 
     def _level_built(self, ts: int):
         if self._async is not None and self._on_level is not None:
@@ -428,14 +429,12 @@ class TensorField:
                 ci = self._C if self._C.dtype == torch.int32 else ops.coords_floor(self._C)
             self.inverse_mapping, _ = mgr.insert(ci)
         if self._sparse is not None:
-            if mgr._async is None:
-                mgr.flush_levels()
+            mgr.flush_levels()
             return self._sparse
         m = mgr.maps[1].coords.shape[0]
         with mgr.building():
             f = _VoxelMean.apply(self._F.float(), self.inverse_mapping, m)
-        if mgr._async is None:          # (on-demand building: the consumer flushes behind its first layers, MinkUNetDiff._forward)
-            mgr.flush_levels()
+        mgr.flush_levels()              # the per-level callbacks (matches), behind the voxel mean
         sp = SparseTensor(f, tensor_stride=1, coordinate_manager=mgr)
         if not (torch.is_grad_enabled() and self._F.requires_grad):
             self._sparse = sp        # same features for every caller of this field (no graph attached)

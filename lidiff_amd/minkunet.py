@@ -567,9 +567,6 @@ class MinkUNetDiff(_Base):
 
     def _forward(self, x, x_sparse, part_feats, t, multi, temp_emb):
         f0 = _run_stem(self.stem, x_sparse)                      # the stem sees no conditioning: shared
-        # on-demand map building (DiffCompletion): the per-level part -> full matches are queued only now, behind the stem's
-        # launches -- their host-side queueing (~50 us a level) is not in front of the first convolution
-        x_sparse.coordinate_manager.flush_levels()
         feats = [f0.replicate(len(part_feats)) if multi else f0]
         for name in _LEVELS[:4]:
             feats.append(getattr(self, name)(self._condition(name, feats[-1], part_feats, temp_emb)))

@@ -159,11 +159,14 @@ class DiffCompletion(nn.Module):
         field._keep = sp
         return field
 
-    def _match_level(self, field, parts, ts):
+    def _match_level(self, field, parts, ts, ahead=False):
+        """ahead: on a stream of its own -- the result carries an event, and whoever uses this level's match waits for that
+        event only (MinkUNetDiff.match_index), not for the matches of the other levels queued behind it."""
         mgr = field.coordinate_manager
         for part in parts:
             if part.C.shape[0] > 1:                  # a one-voxel part (the unconditional branch) needs no match
-                self.model.match_index(ME.SparseTensor(self._empty(), tensor_stride=ts, coordinate_manager=mgr), part)
+                self.model.match_index(ME.SparseTensor(self._empty(), tensor_stride=ts, coordinate_manager=mgr), part,
+                                       ahead=ahead)
 
     def _empty(self):
         if getattr(self, "_empty_t", None) is None:
@@ -375,7 +378,7 @@ class DiffCompletion(nn.Module):
                         x_t.ready.record(main)
                     x_t.F.record_stream(side), x_t.C.record_stream(side)
                     mgr = x_t.coordinate_manager
-                    mgr.set_async(side, self._side2, ready=x_t.ready, on_level=lambda ts: self._match_level(x_t, parts, ts))
+                    mgr.set_async(side, self._side2, ready=x_t.ready, on_level=lambda ts: self._match_level(x_t, parts, ts, ahead=True))
                     try:
                         x_t_sparse = x_t.sparse()
                         self._mark(marks)

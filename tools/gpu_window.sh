@@ -5,7 +5,7 @@ O=$PWD/gpurun_out/window
 mkdir -p $O
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-LIDIFF_MATCH_EARLY=1 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train > $O/bench_prof.json 2> $O/bench_prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train > $O/bench_prof.json 2> $O/bench_prof.err
 cd $R
 DB=$(find $O/prof -name "*results.db" | head -1)
 python tools/rocpd_window.py $DB --nth 3 --ms 5.0 > $O/window.txt 2>&1

@@ -251,8 +251,12 @@ class ConvProfiler:
     Algorithmic work per launch: flops = 2*P*C_in*C_out,
     bytes = 4*(M_in*C_in + M_out*C_out) + 4*K*C_in*C_out + 8*P, P = valid pairs of the map (x replicas)."""
 
-    def __init__(self, variants=None):
+    def __init__(self, variants=None, sample: int = 1):
+        """sample = n: only every n-th launch of a wanted variant carries events (n not a divisor of the launches per step, so
+        that over the steps every layer is sampled): 1 / n of the event records in the timed region, the same average."""
         self.variants = None if variants is None else set(variants)
+        self.sample = max(1, int(sample))
+        self._seen = {}
         self.launches = []          # (variant, start|None, end|None, m_in, m_out, c_in, c_out, k, nbr|None, replicas)
         self.dw = []                # (start, end) of the weight-gradient launches (variant "dw"; bench.py's train leg)
 
@@ -261,12 +265,19 @@ class ConvProfiler:
         return sum(a.elapsed_time(b) for a, b in self.dw)
 
     def wants(self, variant: str) -> bool:
-        return self.variants is None or variant in self.variants
+        if not (self.variants is None or variant in self.variants):
+            return False
+        if self.sample == 1 or variant == "dw":
+            return True
+        n = self._seen.get(variant, 0)
+        self._seen[variant] = n + 1
+        return n % self.sample == 0
 
     def summary(self):
-        """{variant: dict(launches, ms, flops, bytes, timed)} -- synchronises.  EVERY launch is counted (shapes are
-        host data, pair counts are taken after the run from the kept tables); `ms` covers the launches that carried
-        events (`timed` of them) -- all launches of the variants asked for."""
+        """{variant: dict(launches, ms, flops, bytes, timed, flops_timed, bytes_timed)} -- synchronises.  EVERY launch is
+        counted in flops / bytes (shapes are host data, pair counts are taken after the run from the kept tables); `ms`,
+        `flops_timed` and `bytes_timed` cover the launches that carried events (`timed` of them: all launches of the variants
+        asked for, or every `sample`-th of them)."""
         torch.cuda.synchronize()
         counts = {}
         out = {}
@@ -279,13 +290,17 @@ class ConvProfiler:
                     counts[key] = int((nbr >= 0).sum().item())
                 p = counts[key]
             p, m_in, m_out = reps * p, reps * m_in, reps * m_out
-            d = out.setdefault(variant, {"launches": 0, "timed": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d = out.setdefault(variant, {"launches": 0, "timed": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0,
+                                         "flops_timed": 0.0, "bytes_timed": 0.0})
+            fl, by = 2.0 * p * c_in * c_out, 4.0 * (m_in * c_in + m_out * c_out) + 4.0 * k * c_in * c_out + 8.0 * p
             d["launches"] += 1
             if start is not None:
                 d["timed"] += 1
                 d["ms"] += start.elapsed_time(end)
-            d["flops"] += 2.0 * p * c_in * c_out
-            d["bytes"] += 4.0 * (m_in * c_in + m_out * c_out) + 4.0 * k * c_in * c_out + 8.0 * p
+                d["flops_timed"] += fl
+                d["bytes_timed"] += by
+            d["flops"] += fl
+            d["bytes"] += by
         return out
 
 

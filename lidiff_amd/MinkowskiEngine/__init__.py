@@ -44,6 +44,9 @@ class MinkowskiAlgorithm(enum.Enum):
 # ----------------------------------------------------------------------------------------
 # coordinate manager
 # ----------------------------------------------------------------------------------------
+_SPLIT_PYRAMID = __import__("os").environ.get("LIDIFF_SPLIT_PYRAMID", "1") != "0"
+
+
 class CoordinateMap:
     __slots__ = ("coords", "table", "ts")
 
@@ -121,7 +124,8 @@ class CoordinateManager:
     def _insert_pyramid(self, coords_i32: torch.Tensor):
         levels = int(math.log2(self.MAX_STRIDE))
         with self.building():
-            pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2)
+            pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2,
+                                    second_stream=self._async[1] if self._async is not None and _SPLIT_PYRAMID else None)
         for lv in range(levels + 1):
             ts = 1 << lv
             self.maps[ts] = CoordinateMap(pyr.coords[lv], pyr.tables[lv], ts)

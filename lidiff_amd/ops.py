@@ -6,6 +6,7 @@ relative to /root/reference/lidiff).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -95,12 +96,16 @@ class Pyramid:
     __slots__ = ("coords", "tables", "parents", "inverse", "first_idx", "nbr3", "tails")
 
 
-def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, tail_levels: int = 2) -> Pyramid:
+def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, tail_levels: int = 2,
+                  second_stream=None) -> Pyramid:
     """Voxelise int32 coords [N, 4] (vox_unique), the `strides` strided maps below it (map_stride, tensor strides 2, 4, ...),
     and for the first `tail_levels` levels the kernel_size-3 map onto itself plus the COUNT phase of its tail map -- all queued
     back to back on the current stream with every row count staying on the device (the *_dev entry points), followed by
     ONE host read of all sizes.  Same maps, bit for bit, as the call-by-call path (which reads each size as it is made:
-    1 + strides + tail_levels reads); buffers are sized for the point count, which bounds every level."""
+    1 + strides + tail_levels reads); buffers are sized for the point count, which bounds every level.
+    second_stream: the kernel maps and tail counts of the first levels run there, next to the strided maps of the deeper levels
+    on the current stream (a level's kernel map needs only that level): the chain is all small latency-bound kernels, so the
+    two halves overlap almost completely; the current stream joins before the read."""
     require_device(coords, status)
     assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
     coords = coords.contiguous()
@@ -118,6 +123,11 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     call("lidiff_vox_unique", ptr(coords), n, ptr(tables[0].keys), ptr(tables[0].vals), tables[0].cap, ptr(rows[0]),
          ptr(first_idx), ptr(inverse), cptr(0), ptr(status), ptr(keep[0]), st)
     _trace("level 0 queued")
+    cur = torch.cuda.current_stream(dev)
+    level_ev = []
+    if second_stream is not None:
+        level_ev.append(torch.cuda.Event())
+        level_ev[0].record(cur)
     parents = [None]
     for lv in range(1, strides + 1):
         _trace(f"level {lv}: alloc")
@@ -127,18 +137,35 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
         keep.append(_workspace(n, dev))
         call("lidiff_map_stride_dev", ptr(rows[lv - 1]), n, cptr(lv - 1), 1 << lv, ptr(tables[lv].keys), ptr(tables[lv].vals),
              tables[lv].cap, ptr(rows[lv]), ptr(parents[lv]), cptr(lv), ptr(status), ptr(keep[lv]), st)
+        if second_stream is not None and lv < tail_levels:
+            level_ev.append(torch.cuda.Event())
+            level_ev[lv].record(cur)
     _trace("strides queued")
     tails = []
-    for lv in range(min(tail_levels, strides + 1)):
-        nbr = torch.empty((27, n), dtype=torch.int32, device=dev)
-        call("lidiff_kernel_map_self_dev", ptr(rows[lv]), n, cptr(lv), ptr(tables[lv].keys), ptr(tables[lv].vals),
-             tables[lv].cap, 1 << lv, ptr(nbr), st)
-        ws = torch.empty(lib.lidiff_tail_map_workspace_bytes(27, n), dtype=torch.uint8, device=dev)
-        off = torch.empty(28, dtype=torch.int32, device=dev)
-        row_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        call("lidiff_tail_map_dev", ptr(nbr), 27, n, cptr(lv), 13, ptr(off), ptr(row_ptr), 0, None, None, ptr(ws), st)
-        counts[strides + 1 + lv:strides + 2 + lv].copy_(off[27:28])
-        tails.append((nbr, ws, off, row_ptr))
+    tail_ctx = torch.cuda.stream(second_stream) if second_stream is not None else contextlib.nullcontext()
+    with tail_ctx:
+        st2 = stream_ptr()
+        for lv in range(min(tail_levels, strides + 1)):
+            if second_stream is not None:
+                second_stream.wait_event(level_ev[lv])
+            nbr = torch.empty((27, n), dtype=torch.int32, device=dev)
+            call("lidiff_kernel_map_self_dev", ptr(rows[lv]), n, cptr(lv), ptr(tables[lv].keys), ptr(tables[lv].vals),
+                 tables[lv].cap, 1 << lv, ptr(nbr), st2)
+            ws = torch.empty(lib.lidiff_tail_map_workspace_bytes(27, n), dtype=torch.uint8, device=dev)
+            off = torch.empty(28, dtype=torch.int32, device=dev)
+            row_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            call("lidiff_tail_map_dev", ptr(nbr), 27, n, cptr(lv), 13, ptr(off), ptr(row_ptr), 0, None, None, ptr(ws), st2)
+            counts[strides + 1 + lv:strides + 2 + lv].copy_(off[27:28])
+            tails.append((nbr, ws, off, row_ptr))
+        if second_stream is not None:
+            joined = torch.cuda.Event()
+            joined.record(second_stream)
+            counts.record_stream(second_stream)         # (allocated on the current stream, read / written on the second)
+            for lv in range(min(tail_levels, strides + 1)):
+                for t in (rows[lv], tables[lv].keys, tables[lv].vals):
+                    t.record_stream(second_stream)
+    if second_stream is not None:
+        cur.wait_event(joined)
     _trace("tails queued")
     host = counts.tolist()                                     # THE host read of this pyramid
     _trace("sizes read")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 23
+#define LIDIFF_ABI_VERSION 24
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -337,6 +337,27 @@ int lidiff_bn_apply(const float* x, int64_t m, int32_t c, const float* mean, con
 int lidiff_bn_bwd(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                   const float* invstd, const float* gamma, float* sum_dy, float* sum_dy_xmu, float* dx, float* d_residual,
                   void* workspace, void* stream);
+
+/* The same normalisation with the statistics shared over a process group -- ME.MinkowskiSyncBatchNorm, which
+ * train.py:90 / train_refine.py:58 (convert_sync_batchnorm) put in place of every MinkowskiBatchNorm under DDP.  The library never
+ * communicates: it hands the caller the LOCAL per-channel sums as fp64, the caller all-reduces them (RCCL; SUM is exact enough in
+ * fp64 to make every rank derive bit-identical statistics) and hands them back.
+ *   lidiff_bn_sums            : sums[0..c) = sum x, sums[c..2c) = sum x^2 over this rank's m rows.  The caller stores its row
+ *                               count in sums[2c] and all-reduces all 2c + 1 doubles in ONE collective.
+ *   lidiff_bn_stats_from_sums : mean / biased var / invstd of lidiff_bn_stats from such (all-reduced) sums, count = sums[2c]
+ *                               read on the device (no host round trip).  lidiff_bn_apply then runs unchanged.
+ *   lidiff_bn_bwd_sums        : sums[0..c) = sum dy, sums[c..2c) = sum dy * (x - mean) over this rank's rows (mean = the GLOBAL
+ *                               mean; dy masked by y_relu > 0 as in lidiff_bn_bwd): d beta and, times invstd, d gamma of this
+ *                               rank -- and, all-reduced, the two projections dx needs.
+ *   lidiff_bn_bwd_apply       : dx (and d_residual) of lidiff_bn_bwd from the all-reduced sums and the device-resident global row
+ *                               count; sum_dy / sum_dy_xmu receive the fp32 copies the kernel reads. */
+int lidiff_bn_sums(const float* x, int64_t m, int32_t c, double* sums, void* workspace, void* stream);
+int lidiff_bn_stats_from_sums(const double* sums, int32_t c, float eps, float* mean, float* var, float* invstd, void* stream);
+int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
+                       double* sums, void* workspace, void* stream);
+int lidiff_bn_bwd_apply(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
+                        const float* invstd, const float* gamma, const double* sums, const double* count, float* sum_dy,
+                        float* sum_dy_xmu, float* dx, float* d_residual, void* stream);
 
 /* Farthest-point sampling -- DiffCompletion.preprocess_scan, pipeline:92-105 (open3d farthest_point_down_sample):
  * points [n,3] float64; selected[0] = 0, selected[i+1] = the point farthest (squared distance, first maximum) from

@@ -615,22 +615,24 @@ class MinkowskiBatchNorm(nn.Module):
     def forward(self, x: SparseTensor) -> SparseTensor:
         bn = self.bn
         # training: batch statistics and the normalisation through the HIP kernels of norm.hip (one pass each, deterministic;
-        # torch's channels-last batch-norm kernels run at a tenth of the HBM rate on these shapes); momentum = None (cumulative
-        # average) and the sync variant stay on torch
-        if (type(bn) is nn.BatchNorm1d and bn.training and bn.momentum is not None and torch.is_grad_enabled()
-                and ops.bn_train_applies(x.F)):
+        # torch's channels-last batch-norm kernels run at a tenth of the HBM rate on these shapes); the sync variant
+        # (ops.SyncBatchNorm1d) takes the same kernels around one all-reduce of the per-channel sums; momentum = None
+        # (cumulative average) stays on torch
+        if ops.bn_module_fused(bn) and ops.bn_train_applies(x.F):
             return x._like(ops.batch_norm_train(x.F, bn))
         return x._like(bn(x.F))
 
 
 class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
-    """ME.MinkowskiSyncBatchNorm: statistics all-reduced over the process group (RCCL)."""
+    """ME.MinkowskiSyncBatchNorm: statistics all-reduced over the process group (RCCL).  The child `.bn` is
+    ops.SyncBatchNorm1d -- an nn.BatchNorm1d subclass (same state-dict keys) on the norm.hip kernels, so the fused BN + ReLU and
+    BN + shortcut + ReLU forms of the training path (minkunet.py) stay in place under data parallelism."""
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True,
                  process_group=None):
         nn.Module.__init__(self)
-        self.bn = nn.SyncBatchNorm(num_features, eps=eps, momentum=momentum, affine=affine,
-                                   track_running_stats=track_running_stats, process_group=process_group)
+        self.bn = ops.SyncBatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                      track_running_stats=track_running_stats, process_group=process_group)
 
     @classmethod
     def convert_sync_batchnorm(cls, module, process_group=None):

@@ -56,6 +56,10 @@ SIGNATURES = {
     "lidiff_bn_stats": (_i32, [_p, _i64, _i32, C.c_float, _p, _p, _p, _p, _p]),
     "lidiff_bn_apply": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),
     "lidiff_bn_bwd": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "lidiff_bn_sums": (_i32, [_p, _i64, _i32, _p, _p, _p]),
+    "lidiff_bn_stats_from_sums": (_i32, [_p, _i32, C.c_float, _p, _p, _p, _p]),
+    "lidiff_bn_bwd_sums": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "lidiff_bn_bwd_apply": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
@@ -73,7 +77,7 @@ SIGNATURES = {
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 

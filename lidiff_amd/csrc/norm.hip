@@ -100,6 +100,39 @@ __global__ __launch_bounds__(kWave) void bn_finish_bwd_kernel(const double* __re
     sum_dy_xmu[ch] = (float)s2;
 }
 
+// SyncBatchNorm (train.py:90): the per-channel raw sums leave the device-side reduction as fp64 [2][c] so that the host side can
+// all-reduce them over the process group (together with the row count) before anything is derived from them
+__global__ __launch_bounds__(kWave) void bn_finish_sums_kernel(const double* __restrict__ part, int nblk, int c,
+                                                                double* __restrict__ sums) {
+    const int ch = blockIdx.x;
+    double s, s2;
+    bn_channel_sums(part, nblk, ch, s, s2);
+    if (threadIdx.x != 0) return;
+    sums[ch] = s;
+    sums[c + ch] = s2;
+}
+
+__global__ void bn_stats_from_sums_kernel(const double* __restrict__ sums, int c, float eps, float* __restrict__ mean,
+                                          float* __restrict__ var, float* __restrict__ invstd) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double m = sums[2 * c];                        // the (all-reduced) row count travels behind the sums
+    const double mu = sums[ch] / m;
+    double v = sums[c + ch] / m - mu * mu;
+    if (v < 0) v = 0;
+    mean[ch] = (float)mu;
+    var[ch] = (float)v;
+    invstd[ch] = (float)(1.0 / sqrt(v + (double)eps));
+}
+
+__global__ void bn_bwd_from_sums_kernel(const double* __restrict__ sums, int c, float* __restrict__ sum_dy,
+                                        float* __restrict__ sum_dy_xmu) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    sum_dy[ch] = (float)sums[ch];
+    sum_dy_xmu[ch] = (float)sums[c + ch];
+}
+
 template <bool RELU>
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -128,9 +161,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ sum_dy,
                                     const float* __restrict__ sum_dy_xmu, int64_t total4, int cq, float inv_m,
-                                    float* __restrict__ dx, float* __restrict__ d_residual) {
+                                    float* __restrict__ dx, float* __restrict__ d_residual,
+                                    const double* __restrict__ d_count = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
+    if (d_count) inv_m = (float)(1.0 / *d_count);         // SyncBatchNorm: the all-reduced row count stays on the device
     const int q = (int)(i % cq);
     float4 g = reinterpret_cast<const float4*>(dy)[i];
     if (RELU) {
@@ -182,6 +217,62 @@ extern "C" int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, 
     const size_t lds = (size_t)bn_rows_per_block(c) * c * 2 * sizeof(double);
     bn_reduce_kernel<false, false><<<nblk, kBnBlock, lds, st>>>(x, nullptr, nullptr, nullptr, m, c, per, (double*)workspace);
     bn_finish_stats_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, m, eps, mean, var, invstd);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+// -- SyncBatchNorm pieces: local sums -> [all-reduce by the caller] -> statistics -------------------------------------------------
+extern "C" int lidiff_bn_sums(const float* x, int64_t m, int32_t c, double* sums, void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(x && sums && workspace, "null pointer");
+    LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
+    LIDIFF_CHECK_ARG(((uintptr_t)x & 15) == 0, "x must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t per;
+    const int nblk = bn_blocks(m, c, &per);
+    const size_t lds = (size_t)bn_rows_per_block(c) * c * 2 * sizeof(double);
+    bn_reduce_kernel<false, false><<<nblk, kBnBlock, lds, st>>>(x, nullptr, nullptr, nullptr, m, c, per, (double*)workspace);
+    bn_finish_sums_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, sums);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lidiff_bn_stats_from_sums(const double* sums, int32_t c, float eps, float* mean, float* var, float* invstd,
+                                         void* stream) {
+    LIDIFF_CHECK_ARG(sums && mean && var && invstd, "null pointer");
+    LIDIFF_CHECK_ARG(c >= 1, "need c >= 1");
+    bn_stats_from_sums_kernel<<<(unsigned)ceil_div(c, 256), 256, 0, (hipStream_t)stream>>>(sums, c, eps, mean, var, invstd);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
+                                  double* sums, void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(dy && x && mean && sums && workspace, "null pointer");
+    LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t per;
+    const int nblk = bn_blocks(m, c, &per);
+    const size_t lds = (size_t)bn_rows_per_block(c) * c * 2 * sizeof(double);
+    if (y_relu) bn_reduce_kernel<true, true><<<nblk, kBnBlock, lds, st>>>(x, dy, y_relu, mean, m, c, per, (double*)workspace);
+    else bn_reduce_kernel<true, false><<<nblk, kBnBlock, lds, st>>>(x, dy, nullptr, mean, m, c, per, (double*)workspace);
+    bn_finish_sums_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, sums);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lidiff_bn_bwd_apply(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
+                                   const float* invstd, const float* gamma, const double* sums, const double* count,
+                                   float* sum_dy, float* sum_dy_xmu, float* dx, float* d_residual, void* stream) {
+    LIDIFF_CHECK_ARG(dy && x && mean && invstd && sums && count && sum_dy && sum_dy_xmu, "null pointer");
+    LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
+    hipStream_t st = (hipStream_t)stream;
+    bn_bwd_from_sums_kernel<<<(unsigned)ceil_div(c, 256), 256, 0, st>>>(sums, c, sum_dy, sum_dy_xmu);
+    if (dx != nullptr || d_residual != nullptr) {
+        const int64_t total4 = m * (c / 4);
+        const unsigned grid = (unsigned)ceil_div(total4, 256);
+        if (y_relu) bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(dy, x, y_relu, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, 0.f, dx, d_residual, count);
+        else bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(dy, x, nullptr, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, 0.f, dx, d_residual, count);
+    }
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

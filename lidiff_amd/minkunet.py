@@ -95,6 +95,9 @@ _CENTRE_TAIL = True
 _UP_ORDERED = os.environ.get("LIDIFF_UP_ORDERED", "1") != "0"
 
 
+_ME_BN = (ME.MinkowskiBatchNorm, ME.MinkowskiSyncBatchNorm)     # exact types whose .bn batch_norm_train() may stand in for
+
+
 def _run_seq(seq, x: ME.SparseTensor) -> ME.SparseTensor:
     """seq(x) for a Sequential of ME modules -- module by module, as nn.Sequential does, except that in training a
     MinkowskiBatchNorm directly followed by a MinkowskiReLU runs as ONE normalise + ReLU pass (ops._BatchNormTrain(relu=True):
@@ -103,9 +106,8 @@ def _run_seq(seq, x: ME.SparseTensor) -> ME.SparseTensor:
     i = 0
     while i < len(mods):
         m = mods[i]
-        if (i + 1 < len(mods) and type(m) is ME.MinkowskiBatchNorm and isinstance(mods[i + 1], ME.MinkowskiReLU)
-                and type(m.bn) is nn.BatchNorm1d and m.bn.training and m.bn.momentum is not None and torch.is_grad_enabled()
-                and ops.bn_train_applies(x.F)):
+        if (i + 1 < len(mods) and type(m) in _ME_BN and isinstance(mods[i + 1], ME.MinkowskiReLU)
+                and ops.bn_module_fused(m.bn) and ops.bn_train_applies(x.F)):
             x = x._like(ops.batch_norm_train(x.F, m.bn, relu=True))
             i += 2
             continue
@@ -204,12 +206,14 @@ class ResidualBlock(nn.Module):
         if extra is not None:
             x = x._like(torch.cat([x.F, extra], dim=1))
         last = self.net[-1]
-        if (type(last) is ME.MinkowskiBatchNorm and type(last.bn) is nn.BatchNorm1d and last.bn.training
-                and last.bn.momentum is not None and torch.is_grad_enabled() and ops.bn_train_applies(x.F)):
-            # training: the block's last BatchNorm, the shortcut add and the ReLU as one pass (ops._BatchNormTrain)
+        if type(last) in _ME_BN and ops.bn_module_fused(last.bn):
+            # training: the block's last BatchNorm, the shortcut add and the ReLU as one pass (ops._BatchNormTrain) -- decided
+            # on the tensor that IS normalised (net[:-1]'s output) and only when the shortcut has its shape and dtype
             h = _run_seq(self.net[:-1], x)
             r = self.downsample(x)
-            return h._like(ops.batch_norm_train(h.F, last.bn, relu=True, residual=r.F))
+            if ops.bn_train_applies(h.F) and r.F.shape == h.F.shape and r.F.dtype == h.F.dtype:
+                return h._like(ops.batch_norm_train(h.F, last.bn, relu=True, residual=r.F))
+            return self.relu(last(h) + r)
         return self.relu(_run_seq(self.net, x) + self.downsample(x))
 
 

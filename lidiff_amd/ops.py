@@ -510,21 +510,74 @@ def bn_train_applies(x: torch.Tensor) -> bool:
             and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024)
 
 
+class SyncBatchNorm1d(torch.nn.BatchNorm1d):
+    """The `.bn` child of ME.MinkowskiSyncBatchNorm (train.py:90 ``convert_sync_batchnorm``): an nn.BatchNorm1d -- same
+    parameters, buffers and state-dict keys -- whose TRAINING statistics are taken over every rank of `process_group`.  The
+    normalisation itself stays on the kernels of norm.hip (_BatchNormTrain with group=...): per-channel (sum x, sum x^2, rows)
+    leave the device reduction as fp64, ONE all-reduce of 2C + 1 doubles per layer shares them (RCCL under "nccl"; an fp64 SUM
+    gives every rank the same bits), backward shares (sum dy, sum dy (x - mean)) the same way.  Eval mode, CPU tensors and
+    widths the kernels do not take fall back to the local nn.BatchNorm1d arithmetic / torch's SyncBatchNorm function."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats)
+        self.process_group = process_group
+
+    def group(self):
+        """The process group to share statistics over, or None when there is nobody to share with."""
+        import torch.distributed as tdist
+        if not (tdist.is_available() and tdist.is_initialized()):
+            return None
+        g = self.process_group if self.process_group is not None else tdist.group.WORLD
+        return g if tdist.get_world_size(g) > 1 else None
+
+    def forward(self, x):
+        g = self.group() if self.training else None
+        if g is None:
+            return super().forward(x)
+        if bn_train_applies(x) and self.momentum is not None and torch.is_grad_enabled():
+            return batch_norm_train(x, self)
+        # shapes norm.hip does not take: torch's own synchronised function (same statistics, its kernels)
+        from torch.nn.modules._functions import SyncBatchNorm as _TorchSync
+        import torch.distributed as tdist
+        if self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return _TorchSync.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                0.1 if self.momentum is None else self.momentum, g, tdist.get_world_size(g))
+
+
+def bn_module_fused(bn) -> bool:
+    """Is `bn` a BatchNorm1d whose training pass batch_norm_train() implements (plain, or the synchronised subclass)?"""
+    return (type(bn) in (torch.nn.BatchNorm1d, SyncBatchNorm1d) and bn.training and bn.momentum is not None
+            and torch.is_grad_enabled())
+
+
 class _BatchNormTrain(torch.autograd.Function):
     """Training-mode nn.BatchNorm1d on a feature matrix [M, C] (MinkowskiBatchNorm, minkunet.py:23) through lidiff_bn_stats /
     lidiff_bn_apply / lidiff_bn_bwd: batch statistics with double accumulators in a fixed order (deterministic), running
     estimates updated as torch does (momentum, unbiased variance).  relu: the MinkowskiReLU that follows, fused; residual: the
-    ResidualBlock's shortcut added in front of that ReLU (minkunet.py:79: relu(net(x) + downsample(x))), fused as well."""
+    ResidualBlock's shortcut added in front of that ReLU (minkunet.py:79: relu(net(x) + downsample(x))), fused as well.
+    group: a torch.distributed process group -- SyncBatchNorm (train.py:90): the statistics of forward and backward are summed
+    over its ranks (lidiff_bn_sums / _stats_from_sums / _bwd_sums / _bwd_apply around one all-reduce each)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual=None, group=None):
         x = x.contiguous()
         residual = None if residual is None else residual.contiguous()
         m, c = x.shape
         dev = x.device
         stats = torch.empty((3, c), dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.load().lidiff_bn_workspace_bytes(c), dtype=torch.uint8, device=dev)
-        call("lidiff_bn_stats", ptr(x), m, c, float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(ws), stream_ptr())
+        count = None
+        if group is None:
+            call("lidiff_bn_stats", ptr(x), m, c, float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(ws), stream_ptr())
+        else:
+            import torch.distributed as tdist
+            sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+            call("lidiff_bn_sums", ptr(x), m, c, ptr(sums), ptr(ws), stream_ptr())
+            sums[2 * c] = float(m)
+            tdist.all_reduce(sums, op=tdist.ReduceOp.SUM, group=group)
+            call("lidiff_bn_stats_from_sums", ptr(sums), c, float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), stream_ptr())
+            count = sums[2 * c:]                                 # [1] fp64, stays on the device
         y = torch.empty_like(x)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
@@ -533,16 +586,21 @@ class _BatchNormTrain(torch.autograd.Function):
         if running_mean is not None:
             with torch.no_grad():
                 running_mean.mul_(1.0 - momentum).add_(stats[0], alpha=momentum)
-                running_var.mul_(1.0 - momentum).add_(stats[1], alpha=momentum * m / (m - 1))
-        ctx.save_for_backward(x, w, stats, y if relu else None)
+                if count is None:
+                    running_var.mul_(1.0 - momentum).add_(stats[1], alpha=momentum * m / (m - 1))
+                else:
+                    unbias = (count / (count - 1.0)).float() * momentum
+                    running_var.mul_(1.0 - momentum).add_(stats[1] * unbias)
+        ctx.save_for_backward(x, w, stats, y if relu else None, count)
         ctx.relu = bool(relu)
         ctx.has_affine = (weight is not None, bias is not None)
         ctx.has_residual = residual is not None
+        ctx.group = group
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, stats, y = ctx.saved_tensors
+        x, w, stats, y, count = ctx.saved_tensors
         dy = dy.contiguous()
         m, c = x.shape
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
@@ -551,20 +609,32 @@ class _BatchNormTrain(torch.autograd.Function):
         if ctx.has_residual and ctx.needs_input_grad[8]:
             dres = torch.empty_like(x) if ctx.relu else dy      # without ReLU the residual's gradient is dy itself
         ws = torch.empty(_lib.load().lidiff_bn_workspace_bytes(c), dtype=torch.uint8, device=x.device)
-        call("lidiff_bn_bwd", ptr(dy), ptr(x), ptr(y), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(sums[0]), ptr(sums[1]),
-             ptr(dx), ptr(dres) if ctx.relu else None, ptr(ws), stream_ptr())
-        dw = sums[1] * stats[2] if ctx.has_affine[0] and ctx.needs_input_grad[1] else None
-        db = sums[0].clone() if ctx.has_affine[1] and ctx.needs_input_grad[2] else None
-        return dx, dw, db, None, None, None, None, None, dres
+        if ctx.group is None:
+            call("lidiff_bn_bwd", ptr(dy), ptr(x), ptr(y), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(sums[0]), ptr(sums[1]),
+                 ptr(dx), ptr(dres) if ctx.relu else None, ptr(ws), stream_ptr())
+            local = sums
+        else:
+            import torch.distributed as tdist
+            dsums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+            call("lidiff_bn_bwd_sums", ptr(dy), ptr(x), ptr(y), m, c, ptr(stats[0]), ptr(dsums), ptr(ws), stream_ptr())
+            local = dsums.float().view(2, c)                     # THIS rank's sums: d beta / d gamma (the gradient all-reduce averages them)
+            tdist.all_reduce(dsums, op=tdist.ReduceOp.SUM, group=ctx.group)
+            call("lidiff_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(dsums), ptr(count),
+                 ptr(sums[0]), ptr(sums[1]), ptr(dx), ptr(dres) if ctx.relu else None, stream_ptr())
+        dw = local[1] * stats[2] if ctx.has_affine[0] and ctx.needs_input_grad[1] else None
+        db = local[0].clone() if ctx.has_affine[1] and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None, None, None, None, dres, None
 
 
 def batch_norm_train(x, bn: torch.nn.BatchNorm1d, relu: bool = False, residual=None):
-    """bn(x) in training mode (optionally followed by ReLU) through _BatchNormTrain; counts the batch like torch does."""
+    """bn(x) in training mode (optionally followed by ReLU) through _BatchNormTrain; counts the batch like torch does.
+    A SyncBatchNorm1d shares its statistics over its process group."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu, residual)
+    group = bn.group() if isinstance(bn, SyncBatchNorm1d) else None
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu, residual, group)
 
 
 def pairs_kernel_applies(c_a: int, c_b: int, c_out: int) -> bool:

@@ -142,3 +142,81 @@ def t50_oracle():
     ts = [int(t) for t in o.set_timesteps(50)]
     traj, src = golden_or_compute("t50_small", t50_key(sd), lambda: t50_compute(sd))
     return scan_np, zs, ts, traj, src
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# closed_c2: BASELINE configs[1] END TO END on the oracle -- the 180 000-point bench scan, seeded weights, the closed loop over
+# all T = 50 DPM-Solver++ steps with the scheduler's noise draws shared (pipeline:155-169), then postprocess_scan + the MinkUNet
+# refinement forward (pipeline:117-132).  tests/test_gpu_baseline.py runs DiffCompletion.completion_loop + refine_forward on
+# the same inputs and noise and compares the two completions by the reference's own metric (utils/metrics.py:124-141,
+# ChamferDistance) -- the one the BASELINE metric names ("Chamfer vs ref", north_star: within 1e-3).
+# ----------------------------------------------------------------------------------------------------------------------------
+CLOSED_STEPS = 50
+CLOSED_KEEP = (1, 5, 10, 25, 40, 50)      # trajectory positions whose points are kept (float32) to locate any divergence
+CLOSED_NOISE_SEED = 11
+
+
+def closed_noise(i: int, n_points: int) -> np.ndarray:
+    """The scheduler's N(0, I) draw of step i, float64 [1, n, 3] -- one generator per step, so that either side can make step
+    i's draw without holding all 50 (216 MB)."""
+    return np.random.default_rng([CLOSED_NOISE_SEED, i]).standard_normal((1, n_points, 3))
+
+
+def seeded_refine_state_dict():
+    _, _, refine = build_seeded_models(42)
+    return {k: v for k, v in refine.state_dict().items()}
+
+
+def closed_inputs(fps_scan):
+    """(condition scan [180000, 3] float32, x_T [180000, 3] float32): what complete_scan builds at pipeline:118-119 --
+    the FPS scan tiled x10 plus N(0, I) (seed 0; the same x_T as the c1_t999 fixture)."""
+    return c1_inputs(fps_scan, 999)
+
+
+def closed_key(fps_scan, sd, sd_refine):
+    scan, noisy = closed_inputs(fps_scan)
+    return ([noisy, scan, closed_noise(0, 4), np.array([CLOSED_STEPS, CLOSED_NOISE_SEED])] + state_dict_arrays(sd)
+            + state_dict_arrays(sd_refine))
+
+
+def postprocess_scan(completed, input_scan, max_range=50.0):
+    """DiffCompletion.postprocess_scan pipeline:107-115 (numpy; torch's std is the unbiased one)."""
+    dist = np.sqrt(np.sum(completed ** 2, -1))
+    post = completed[dist < max_range]
+    z = torch.from_numpy(np.ascontiguousarray(input_scan[..., 2]))
+    max_z, min_z = z.max().item(), (z.mean() - 2 * z.std()).item()
+    return post[(post[:, 2] < max_z) & (post[:, 2] > min_z)]
+
+
+def closed_compute(fps_scan, sd, sd_refine, steps=CLOSED_STEPS, log=None):
+    scan_np, noisy_np = closed_inputs(fps_scan)
+    n = scan_np.shape[0]
+    o = DpmSolverSdeOracle()
+    ts = o.set_timesteps(CLOSED_STEPS)
+    x_init = scan_np.astype(np.float64)[None]
+    cond_o = net.points_to_field(torch.from_numpy(scan_np)[None])
+    zero_o = net.points_to_field(torch.zeros(1, n, 3))
+    xo = noisy_np.astype(np.float64)[None]
+    out = {}
+    with torch.no_grad():
+        for i, t in enumerate(ts[:steps]):
+            xf = net.points_to_field(torch.from_numpy(xo).float())
+            eps = net.classfree_forward(sd, xf, cond_o, zero_o, torch.tensor([int(t)]), w=6.0)
+            xo = x_init + o.step(eps.numpy(), int(t), xf.F.numpy().reshape(1, -1, 3) - x_init, closed_noise(i, n))
+            if i + 1 in CLOSED_KEEP:
+                out[f"x{i + 1}"] = xo[0].astype(np.float32)
+            if log is not None:
+                log(i, int(t), eps.numpy(), xo)
+        # complete_scan pipeline:123-130: x_t.F of the LAST field (float32 features), post-filter, refinement forward
+        completed = net.points_to_field(torch.from_numpy(xo).float()).F.numpy()
+        post = postprocess_scan(completed, x_init)
+        offset = net.unet_refine_forward(sd_refine, net.points_to_field(torch.from_numpy(post)[None])).numpy()
+    out["completed"] = completed.astype(np.float32)
+    out["post_rows"] = np.array([post.shape[0]])
+    out["refine_offset"] = offset.astype(np.float32)            # [P, 18]; the refined cloud is post[:, None] + offset.reshape(-1, 6, 3)
+    return out
+
+
+def closed_oracle(fps_scan):
+    sd, sd_refine = seeded_state_dict(), seeded_refine_state_dict()
+    return golden_or_compute("closed_c2", closed_key(fps_scan, sd, sd_refine), lambda: closed_compute(fps_scan, sd, sd_refine))

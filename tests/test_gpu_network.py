@@ -685,7 +685,7 @@ def test_two_rank_train_loop_on_one_gpu_over_gloo(device):
     and every kernel of the step deterministic).  (Until the scatter-adds of the backward -- slice, conditioning gathers -- became segment sums in a fixed order, Adam's
     sign-like first steps amplified their fp32-atomic noise: 0 .. 5.5 % of the elements flipped, cosines 0.9983 .. 0.99999; with
     every kernel of the step deterministic the two runs agree exactly.)
-    BatchNorm statistics are per process here (sync_bn = False: SyncBatchNorm needs RCCL; that form is the >= 2-GPU test below)."""
+    BatchNorm statistics are per process here (sync_bn = False); the synchronised form is the next test."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sk:
@@ -734,6 +734,121 @@ def test_two_rank_train_loop_on_one_gpu_over_gloo(device):
         assert np.linalg.norm(d_ref) > 0 and worst == 0.0, (k, cos, off, worst)        # bit for bit
 
 
+def _syncbn_forward_backward(mod, batches, n_total):
+    """DiffusionPoints.forward on the concatenation of `batches` in TRAINING mode and the gradient of a loss that is a plain sum
+    over points (sum |eps - noise|^2 / (3 n_total)): separable over ranks, so the SUM of the ranks' gradients is the gradient of
+    the one-process run on the concatenated batch (the training step's own loss has batch-level mean / std terms and is not)."""
+    from lidiff_amd.diffusion import prebuild_maps
+    full = torch.cat([b["pcd_full"] for b in batches]).to(mod.device)
+    part = torch.cat([b["pcd_part"] for b in batches]).to(mod.device)
+    noise = torch.cat([b["noise"] for b in batches]).to(mod.device)
+    t = torch.cat([b["t"] for b in batches]).to(mod.device)
+    x_full = prebuild_maps(mod.points_to_tensor(full + mod.q_sample(torch.zeros_like(full), t, noise)))
+    x_part = prebuild_maps(mod.points_to_tensor(part))
+    mod.train()
+    mod.zero_grad(set_to_none=True)
+    eps = mod.forward(x_full, x_full.sparse(), x_part, t)
+    ((eps - noise) ** 2).sum().div(3.0 * n_total).backward()
+    return eps.detach()
+
+
+_SYNCBN_STATS = ["model.stem.1.bn", "model.stage2.1.net.1.bn", "model.stage4.2.net.4.bn", "model.up1.0.net.1.bn", "model.up4.1.1.net.4.bn",
+                 "partial_enc.stage3.1.downsample.1.bn"]
+
+
+def _two_rank_syncbn_one_gpu_worker(rank, world, port, q):
+    import hashlib
+    import torch.distributed as tdist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import lidiff_amd.MinkowskiEngine as ME
+    from lidiff_amd import dist as ldist
+    from lidiff_amd import ops
+    from lidiff_amd.diffusion import train_loop
+    ldist.init_from_env("gloo")
+    dev = torch.device("cuda", 0)
+    batches = _a18_batches()
+    n_total = sum(b["pcd_full"].shape[0] * b["pcd_full"].shape[1] for b in batches[:2])
+    # (1) one forward + backward with synchronised statistics: rank r holds batch r of the pair
+    mod = _a18_module(100, dev)                                   # same weights on both ranks
+    ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(mod)
+    n_sync = sum(type(m) is ops.SyncBatchNorm1d for m in mod.modules())
+    eps = _syncbn_forward_backward(mod, [batches[rank]], n_total)
+    grads = {}
+    for k, p in mod.named_parameters():
+        if k in _A18_TENSORS or k.endswith("stem.1.bn.weight") or k.endswith("stem.1.bn.bias"):
+            g = p.grad.detach().clone()
+            tdist.all_reduce(g)                                   # SUM over ranks = the gradient of the concatenated batch
+            grads[k] = g.cpu().numpy()
+    named = dict(mod.named_modules())
+    stats = {k: (named[k].running_mean.cpu().numpy(), named[k].running_var.cpu().numpy()) for k in _SYNCBN_STATS}
+    # (2) the real train_loop with sync_bn=True: conversion, broadcast, rank-sharded batches, HIP SyncBatchNorm, all-reduce, Adam
+    mod2 = _a18_module(100 + rank, dev)
+    losses = train_loop(mod2, batches, steps=2, sync_bn=True)
+    h = hashlib.sha1()
+    for k, v in sorted(mod2.state_dict().items()):                # parameters AND BatchNorm running statistics
+        h.update(v.detach().cpu().numpy().tobytes())
+    n_sync2 = sum(type(m) is ops.SyncBatchNorm1d for m in mod2.modules())
+    q.put((rank, n_sync, eps.cpu().numpy(), grads, stats, losses, h.hexdigest(), n_sync2))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_on_one_gpu_over_gloo(device):
+    """SURVEY.md 8 row a18, the SyncBatchNorm half (train.py:90 convert_sync_batchnorm): TWO processes sharing cuda:0, statistics
+    exchanged over gloo, the normalisation on the norm.hip kernels (ops.SyncBatchNorm1d / _BatchNormTrain(group=...): fp64
+    per-channel sums, one all-reduce per layer forward and backward, fused ReLU / shortcut forms kept).
+    (1) Each rank runs DiffusionPoints.forward (training mode) on ITS batch of two scans; one process runs it with plain
+    BatchNorm on the CONCATENATED batch of four.  Outputs (each rank's rows), BatchNorm running statistics and the summed
+    gradients of a point-separable loss agree -- synchronised statistics ARE the statistics of the concatenated batch.
+    (2) train_loop(sync_bn=True) for two steps: every tensor of the state dict -- weights and running statistics --
+    bit-identical on the two ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_syncbn_one_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=900) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == res[0][6] == res[1][6] and res[0][0] > 70        # all 74 BatchNorms are the sync kind
+    # (2) the ranks of the real loop agree bit for bit, running statistics included
+    assert np.isfinite(res[0][4]).all() and len(res[0][4]) == 2
+    assert res[0][5] == res[1][5], "ranks hold different weights / running statistics after 2 sync-BN steps"
+    # (1) against one process on the concatenated batch
+    batches = _a18_batches()
+    n_total = sum(b["pcd_full"].shape[0] * b["pcd_full"].shape[1] for b in batches[:2])
+    mod = _a18_module(100, device)
+    eps = _syncbn_forward_backward(mod, batches[:2], n_total).cpu().numpy()
+    two = np.concatenate([res[0][1], res[1][1]])
+    scale = float(np.abs(eps).max())
+    err_out = float(np.abs(two - eps).max()) / scale
+    named = dict(mod.named_modules())
+    err_stat = 0.0
+    for k in _SYNCBN_STATS:
+        for r in (0, 1):
+            assert np.array_equal(res[0][3][k][0], res[1][3][k][0]) and np.array_equal(res[0][3][k][1], res[1][3][k][1]), k
+        for got, want in zip(res[0][3][k], (named[k].running_mean.cpu().numpy(), named[k].running_var.cpu().numpy())):
+            err_stat = max(err_stat, float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30)))
+    err_grad, cos_min = 0.0, 1.0
+    for k, p in mod.named_parameters():
+        if k not in res[0][2]:
+            continue
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k
+        want, got = p.grad.detach().cpu().numpy(), res[0][2][k]
+        err_grad = max(err_grad, float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30)))
+        cos_min = min(cos_min, float((got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30)))
+    record_parity("syncbn_two_ranks_vs_concatenated_batch", out_rel_err=err_out, running_stat_rel_err=err_stat,
+                  grad_rel_err=err_grad, grad_cos_min=cos_min, n_sync_bn=res[0][0])
+    assert err_stat <= 1e-6, err_stat
+    assert err_out <= 1e-5 and err_grad <= 1e-4 and cos_min >= 0.99999, (err_out, err_grad, cos_min)
+
+
 def _two_rank_train_worker(rank, world, port, q):
     import torch.distributed as tdist
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -748,7 +863,8 @@ def _two_rank_train_worker(rank, world, port, q):
     full = torch.from_numpy(np.stack([scan, scan[::-1].copy()]))
     batches = [{"pcd_full": full + 0.01 * i, "pcd_part": full[:, :60].contiguous() + 0.01 * i} for i in range(4)]
     losses = train_loop(mod, batches, steps=3)
-    sync_bn = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in mod.modules())
+    from lidiff_amd.ops import SyncBatchNorm1d
+    sync_bn = sum(type(m) is SyncBatchNorm1d for m in mod.modules())
     w = mod.model.stage3[1].net[0].kernel.detach().float().cpu()
     rm = mod.model.stem[1].bn.running_mean.detach().cpu()
     q.put((rank, losses, sync_bn, w.sum().item(), w.abs().sum().item(), rm.tolist()))

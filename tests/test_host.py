@@ -34,7 +34,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
             assert (a is want) if want is not None else a in (C.c_int32, C.c_int64), (name, q, a)
             if want is None:
                 assert a is (C.c_int64 if q.startswith("int64_t") else C.c_int32), (name, q, a)
-    assert lib.lidiff_abi_version() == _lib.ABI_VERSION == 23
+    assert lib.lidiff_abi_version() == _lib.ABI_VERSION == 24
     assert lib.lidiff_hash_capacity(180000) == 524288 and lib.lidiff_hash_capacity(1) == 1024
     assert lib.lidiff_unique_workspace_bytes(1000) >= 1000 * 4
     # host-side argument validation reaches the error string without touching a device
@@ -131,7 +131,11 @@ def test_sync_batchnorm_conversion():
     net.stem[1].bn.running_mean.fill_(0.25)
     net = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(net)
     bns = [m for m in net.modules() if isinstance(m, ME.MinkowskiBatchNorm)]
-    assert bns and all(isinstance(m, ME.MinkowskiSyncBatchNorm) and isinstance(m.bn, torch.nn.SyncBatchNorm) for m in bns)
+    from lidiff_amd.ops import SyncBatchNorm1d
+    # the sync variant's child is an nn.BatchNorm1d subclass on the norm.hip kernels (not torch's SyncBatchNorm): same keys,
+    # LiDiff's weight_initialization (minkunet.py:128-132, isinstance(m, nn.BatchNorm1d)) still finds it
+    assert bns and all(isinstance(m, ME.MinkowskiSyncBatchNorm) and type(m.bn) is SyncBatchNorm1d
+                       and isinstance(m.bn, torch.nn.BatchNorm1d) for m in bns)
     assert torch.all(net.stem[1].bn.running_mean == 0.25)
     assert "stem.1.bn.weight" in net.state_dict()
 

@@ -85,11 +85,13 @@ def run_steps(pipe, x_init, xs, tvals, first, count, cache_condition=False):
     parts = pipe.encode_conditions(x_cond, x_uncond) if cache_condition else None
     for j in range(first, first + count):
         t = torch.full((1,), tvals[j], dtype=torch.int64, device=x_init.device)
-        noise_t = pipe.classfree_forward(x_t, x_cond, x_uncond, t, parts, t_host=tvals[j])
-        input_noise = x_t.F.reshape(1, -1, 3) - x_init
+        e_cond, e_uncond = pipe.classfree_pair(x_t, x_cond, x_uncond, t, parts, t_host=tvals[j])
         if j == first or tvals[j] >= tvals[j - 1]:
             pipe.new_scheduler()                       # a new scan's trajectory starts
-        _ = x_init + pipe.dpm_scheduler.step(noise_t, tvals[j], input_noise)["prev_sample"]
+        # the step's own boundary exactly as completion_loop runs it (guidance, DPM-Solver++ update with a fresh draw, the new
+        # points' field) -- computed and dropped, because the open loop prescribes the next points: one MORE field construction
+        # per step than the closed loop has, never less
+        _ = pipe.step_boundary(x_init, x_t, e_cond, e_uncond, tvals[j])
         nxt = xs[j + 1] if j + 1 < len(xs) else xs[j]
         x_t = pipe.points_to_tensor(nxt)               # open loop: next sigma's points (see docstring)
         if parts is None:
@@ -523,24 +525,40 @@ def main():
                              "alg_gbs": v["bytes_timed"] / (v["ms"] * 1e-3) / 1e9} for k, v in summ.items() if v["timed"]},
         }
     if vprof is not None or (prof is not None and args.all_variants):
-        vs = (vprof or prof).summary()
-        narrow = {k: v for k, v in vs.items() if k in ("bn96", "bn64", "bn32", "bn16", "rows", "thin") and v["timed"]}
-        if narrow:
-            nb, nms = sum(v["bytes"] for v in narrow.values()), sum(v["ms"] for v in narrow.values())
-            out["roofline_narrow"] = {
-                "kernel": "spconv_fwd_kernel, output-channel tiles below 128 (bn96 / bn64 / bn32: the stride-1/2 layers, tail "
-                          "passes included) + spconv_rows_kernel (rows: kernel_size-1 convolutions and centre passes of every width)", "bound": "hbm", "achieved": nb / (nms * 1e-3) / 1e9,
-                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nb / (nms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "traffic": traffic_from_profile(sorted(narrow))[0],
-                "traffic_unit": "GB per launch, averaged over these variants' launches (HBM-side, rocprofv3 PMC FETCH_SIZE x2 + "
-                                "WRITE_SIZE; static: " + str(traffic_from_profile(sorted(narrow))[1]) + ")",
-                "algorithmic_gbytes_per_launch": nb / sum(v["launches"] for v in narrow.values()) / 1e9,
-                "ms_per_step": nms / args.steps, "launches_per_step": sum(v["launches"] for v in narrow.values()) / args.steps,
-                "note": "algorithmic bytes 4 (M_in C_in + M_out C_out) + 4 K C_in C_out + 8 P per launch / HIP-event time, "
-                        "from a second pass of the same steps with every conv launch timed (not the pass behind `value`)",
-                "variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                 "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
-                                 "alg_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in vs.items() if v["timed"]}}
+        # every launch that is NOT the dominant 128-column tile kernel, split by what bounds it: arithmetic
+        # intensity of the launch (algorithmic flops / algorithmic bytes) against the ridge point 157.3 TFLOP/s / 8 TB/s = 19.7
+        # FLOP/B -- the 64 / 96-column kernel_size-3 layers and the wide row-kernel launches are MFMA-bound, the 32-channel
+        # layers, the stems and the narrow row-kernel launches are HBM-bound; each class against ITS peak
+        narrow_variants = ("bn96", "bn64", "bn32", "bn16", "rows", "thin")
+        split = ops.launches_by_bound(vprof or prof, PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9), narrow_variants)
+        for bound, d in split.items():
+            if not d["launches"]:
+                continue
+            mfma = bound == "mfma"
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if mfma else d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            peak = PEAK_F32_MFMA_TFLOPS if mfma else PEAK_HBM_GBS
+            vs = sorted({k[0] for k in d["shapes"]})
+            layers = []
+            for (variant, kk, c_in, c_out), r in sorted(d["shapes"].items(), key=lambda kv: -kv[1]["ms"]):
+                a_ = r["flops"] / (r["ms"] * 1e-3) / 1e12 if mfma else r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                layers.append({"kernel": variant, "k": kk, "c_in": c_in, "c_out": c_out, "launches_per_step": r["launches"] / args.steps,
+                               "ms_per_step": round(r["ms"] / args.steps, 4), "achieved": round(a_, 2), "frac": round(a_ / peak, 4),
+                               "flop_per_byte": round(r["flops"] / r["bytes"], 1)})
+            out["roofline_narrow_" + bound] = {
+                "kernel": ("launches outside the 128-column tile kernel with arithmetic intensity >= 19.7 FLOP/B (bn64 / bn96 kernel_size-3 "
+                           "tiles at stride 2-4, wide spconv_rows_kernel launches)" if mfma else
+                           "launches outside the 128-column tile kernel with arithmetic intensity < 19.7 FLOP/B (32-channel layers, stems, "
+                           "low-density stride-1/2 tail passes, narrow spconv_rows_kernel launches)"),
+                "bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s", "frac": ach / peak,
+                "ms_per_step": d["ms"] / args.steps, "launches_per_step": d["launches"] / args.steps,
+                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                "algorithmic_gbytes_per_launch": d["bytes"] / d["launches"] / 1e9,
+                "traffic": traffic_from_profile(vs)[0],
+                "traffic_unit": "GB per launch averaged over ALL launches of the kernel variants " + "/".join(vs) + " (a variant serves "
+                                "both classes; HBM-side, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; static: " + str(traffic_from_profile(vs)[1]) + ")",
+                "note": "algorithmic flops 2 P C_in C_out and bytes 4 (M_in C_in + M_out C_out) + 4 K C_in C_out + 8 P per launch / "
+                        "HIP-event time, from a second pass of the same steps with every conv launch timed (not the pass behind `value`)",
+                "layers": layers}
     if alt is not None:
         a_elapsed, aprof = alt
         out["alt"] = {

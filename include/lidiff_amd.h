@@ -303,6 +303,12 @@ int lidiff_gather_bias_leaky(const float* src, const int64_t* idx, const float* 
  * the max over ALL columns of full). */
 int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
                     const int32_t* d_max_coord, int64_t* idx, void* stream);
+/* The same search for a map whose row count is still on the device (a coordinate pyramid before its one host read,
+ * lidiff_map_stride_dev): full has room for m_full_bound rows, the first *d_m_full are valid; d_max_coord [1] is computed here
+ * (max over all columns of the valid rows) and idx [m_full_bound] written for the valid rows only.  Lets the five part -> full
+ * matches of a step run beside the pyramid's own kernels instead of behind its host read. */
+int lidiff_nn_match_dev(const int32_t* full, int64_t m_full_bound, const int32_t* d_m_full, const int32_t* part, int64_t m_part,
+                        int32_t* d_max_coord, int64_t* idx, void* stream);
 
 /* The same arg-min when the part rows are a coordinate map of tensor stride `part_stride` with hash table
  * (hkeys_part, hvals_part, cap_part): searches the lattice cells around every full row in growing shells instead
@@ -358,6 +364,26 @@ int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* y_relu, int
 int lidiff_bn_bwd_apply(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                         const float* invstd, const float* gamma, const double* sums, const double* count, float* sum_dy,
                         float* sum_dy_xmu, float* dx, float* d_residual, void* stream);
+
+/* The boundary between two denoising steps as one launch -- DiffCompletion.completion_loop, pipeline:148-153 (classifier-free
+ * guidance), :161-163 (offsets, dpm_scheduler.step: sde-dpmsolver++) and :164 with :68-84 (points_to_tensor of the
+ * new points): per point and axis, every operation rounded on its own in the precision torch-on-the-GPU gives it,
+ *   eps  = e_u + w (e_c - e_u)                         (fp32)
+ *   off  = (double) x_t - x_init ;  x0 = (off - (double)(sigma_t eps)) * inv_alpha_t                     (fp64; sigma_t eps in fp32)
+ *   prev = c_sample off + c_m0 x0 [+ c_d1 (inv_r0 (x0 - m_prev))] [+ c_noise noise]                      (fp64, left to right)
+ *   feats = (float)(x_init + prev) ;  coords = (b', rint(feats * inv_resolution)) as int32
+ * m_prev NULL: first-order update; noise NULL: no noise term.  b' = the batch index i / n_per_batch, passed through
+ * rint(b * inv_resolution) when scale_batch_column != 0 (pipeline:72 divides the batch column too).
+ * x0_out [n,3] fp64 (the solver's next m_prev), feats_out [n,3] fp32, coords_out [n,4] int32: what
+ * TensorField(features, coordinates) of the next step takes.  The coefficients are host doubles (the scheduler's tables). */
+int lidiff_cfg_dpm_step(const float* eps_cond, const float* eps_uncond, float w, const float* x_t, const double* x_init,
+                        const double* m_prev, const double* noise, float sigma_t, double inv_alpha_t, double c_sample, double c_m0,
+                        double c_d1, double inv_r0, double c_noise, float inv_resolution, int64_t n_points, int64_t n_per_batch,
+                        int32_t scale_batch_column, double* x0_out, float* feats_out, int32_t* coords_out, void* stream);
+/* points_to_tensor alone (pipeline:68-84; models.py:162-178 with scale_batch_column = 0): [B, n, 3] points, fp64 (is_f64 != 0)
+ * or fp32 -> fp32 features [B n, 3] and int32 voxel coordinates [B n, 4], one launch. */
+int lidiff_points_to_field(const void* points, int32_t is_f64, float inv_resolution, int64_t n_points, int64_t n_per_batch,
+                           int32_t scale_batch_column, float* feats_out, int32_t* coords_out, void* stream);
 
 /* Farthest-point sampling -- DiffCompletion.preprocess_scan, pipeline:92-105 (open3d farthest_point_down_sample):
  * points [n,3] float64; selected[0] = 0, selected[i+1] = the point farthest (squared distance, first maximum) from

@@ -70,25 +70,27 @@ class CoordinateManager:
         self._async = None                              # (build stream, second build stream) -- set_async()
         self._ready = None                              # event: the field's points exist (recorded on the consumer's stream)
         self._on_level = None                           # callable(ts): queued on the second stream when level ts exists
+        self._on_level_dev = None                       # callable(ts, rows_bound, d_count) -> [(aux key, owner, tensor, event)]:
+        #                                                 the same, but inside the pyramid chain, before its sizes reach the host
         # True: insert() builds the whole pyramid (ops.build_pyramid: voxel map, the four strided maps, the kernel_size-3
         # maps and tail-map counts of the first two levels) with ONE host read instead of one per map.  Same maps.
         self.pyramid = False
 
     # -- asynchronous, on-demand building (DiffCompletion, round 3) ------------------------------------------------------
-    def set_async(self, side, side2, ready=None, on_level=None):
+    def set_async(self, side, side2, ready=None, on_level=None, on_level_dev=None):
         """Build every map of this manager ON DEMAND on `side` (the map-size reads synchronise that stream only) while the
         consumer's stream keeps running what is already queued; consumers join through lidiff_amd._lib.call().  on_level(ts)
         runs on `side2` as soon as the coordinate map of stride ts exists (the part -> full match of that level)."""
         from .. import _lib
         _lib.register_build_stream(side)
         _lib.register_build_stream(side2)
-        self._async, self._ready, self._on_level = (side, side2), ready, on_level
+        self._async, self._ready, self._on_level, self._on_level_dev = (side, side2), ready, on_level, on_level_dev
         if ready is not None:
             side.wait_event(ready)
             side2.wait_event(ready)
 
     def clear_async(self):
-        self._async = self._on_level = None
+        self._async = self._on_level = self._on_level_dev = None
 
     @contextlib.contextmanager
     def building(self, second: bool = False):
@@ -123,9 +125,18 @@ class CoordinateManager:
 
     def _insert_pyramid(self, coords_i32: torch.Tensor):
         levels = int(math.log2(self.MAX_STRIDE))
+        second = self._async[1] if self._async is not None and _SPLIT_PYRAMID else None
+        hook, early = None, []
+        if second is not None and self._on_level_dev is not None:
+            # per-level work that needs coordinates but no host-side size (the part -> full matches): queued INSIDE the chain,
+            # with the row counts on the device, instead of behind the pyramid's host read
+            def hook(lv, rows, d_count):
+                early.append((lv, self._on_level_dev(1 << lv, rows, d_count)))
         with self.building():
-            pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2,
-                                    second_stream=self._async[1] if self._async is not None and _SPLIT_PYRAMID else None)
+            pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2, second_stream=second, on_level_dev=hook)
+        for lv, results in early:
+            for key, owner, bound_tensor, event in results:
+                self.aux[key] = (owner, bound_tensor[:pyr.coords[lv].shape[0]], event)
         for lv in range(levels + 1):
             ts = 1 << lv
             self.maps[ts] = CoordinateMap(pyr.coords[lv], pyr.tables[lv], ts)
@@ -137,7 +148,7 @@ class CoordinateManager:
         # the per-level callbacks (DiffCompletion: the part -> full matches, 50-250 us kernels that fill the chip) are queued by
         # flush_levels() -- TensorField.sparse() calls it behind the voxel mean, so that the first convolution's inputs are
         # not stuck behind them
-        self._deferred_levels = [1 << lv for lv in range(levels + 1)]
+        self._deferred_levels = [] if hook is not None else [1 << lv for lv in range(levels + 1)]
         return pyr.inverse, pyr.first_idx
 
     def flush_levels(self):

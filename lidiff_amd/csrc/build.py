@@ -12,7 +12,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["coords.hip", "spconv.hip", "spconv_dense.hip", "spconv_rows.hip", "spconv_bf16.hip", "norm.hip"]
+SOURCES = ["coords.hip", "spconv.hip", "spconv_dense.hip", "spconv_rows.hip", "spconv_bf16.hip", "norm.hip", "step.hip"]
+# step.hip restates a sequence of separately rounded torch launches: no fused multiply-adds there
+EXTRA_FLAGS = {"step.hip": ["-ffp-contract=off"]}
 HEADERS = ["common.h", "spconv.h", os.path.join("..", "..", "include", "lidiff_amd.h")]
 LIB = os.path.join(HERE, "liblidiff_amd.so")
 ARCH = "gfx950"
@@ -40,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(HERE, src.replace(".hip", ".o"))
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
-               "-c", os.path.join(HERE, src), "-o", obj]
+               "-c", os.path.join(HERE, src), "-o", obj] + EXTRA_FLAGS.get(src, [])
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.run(cmd, check=True)

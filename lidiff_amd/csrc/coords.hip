@@ -702,8 +702,13 @@ constexpr int kMatchPt = 2;                               // full rows per lane:
 template <bool SPLIT, bool F32IN = false>
 __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full,
                                 const int32_t* __restrict__ part, int64_t m_part, int64_t part_per_split,
-                                const int32_t* __restrict__ d_max_coord, int64_t* __restrict__ idx) {
+                                const int32_t* __restrict__ d_max_coord, int64_t* __restrict__ idx,
+                                const int32_t* __restrict__ d_m_full = nullptr) {
     __shared__ float4 tile[kMatchTile];
+    if (d_m_full != nullptr) {                            // row count still on the device (a pyramid before its host read):
+        m_full = *d_m_full;                               // the grid covers the bound, workgroups beyond the count leave at once
+        if ((int64_t)blockIdx.x * blockDim.x * kMatchPt >= m_full) return;
+    }
     const float scale = F32IN ? 1.0f : 2.0f * (float)(*d_max_coord);
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x * kMatchPt + threadIdx.x;   // rows i0, i0 + blockDim.x
     static_assert(kMatchPt == 2, "the two rows of a lane ride in the halves of packed-fp32 registers");
@@ -760,9 +765,23 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
     }
 }
 
-__global__ void nn_match_finish_kernel(int64_t* __restrict__ idx, int64_t m_full) {
+__global__ void nn_match_finish_kernel(int64_t* __restrict__ idx, int64_t m_full, const int32_t* __restrict__ d_m_full = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_m_full != nullptr) m_full = *d_m_full;
     if (i < m_full) idx[i] &= 0xffffffffll;
+}
+
+// max over ALL columns of the first *d_m rows (torch's full.max() of minkunet.py:410, with the row count on the device);
+// *d_max starts at a value below every coordinate
+__global__ void coord_max_dev_kernel(const int32_t* __restrict__ coords, const int32_t* __restrict__ d_m, int32_t* __restrict__ d_max) {
+    const int64_t m = *d_m;
+    int best = INT32_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        best = max(best, max(max(c.x, c.y), max(c.z, c.w)));
+    }
+    for (int off = kWave / 2; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
+    if (lane_id() == 0 && best != INT32_MIN) atomicMax(d_max, best);
 }
 
 // Same arg-min through the part map's hash table: part voxels sit on a lattice of pitch `ps` (their tensor
@@ -1068,17 +1087,18 @@ static void nn_dist_launch(const void* a, int64_t n, const void* b, int64_t m, v
 
 template <bool F32IN>
 static int nn_match_launch(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
-                           const int32_t* d_max_coord, int64_t* idx, hipStream_t st) {
+                           const int32_t* d_max_coord, int64_t* idx, hipStream_t st, const int32_t* d_m_full = nullptr) {
+    // (d_m_full: m_full is only a BOUND of the row count, which the kernels read from the device)
     const int64_t blocks = ceil_div(m_full, (int64_t)kBlock * kMatchPt);
     const int64_t splits = min(ceil_div((int64_t)2048, blocks), ceil_div(m_part, (int64_t)kMatchTile));
     if (splits <= 1) {
-        nn_match_kernel<false, F32IN><<<(unsigned)blocks, kBlock, 0, st>>>(full, m_full, part, m_part, 0, d_max_coord, idx);
+        nn_match_kernel<false, F32IN><<<(unsigned)blocks, kBlock, 0, st>>>(full, m_full, part, m_part, 0, d_max_coord, idx, d_m_full);
     } else {
         const int64_t per = ceil_div(ceil_div(m_part, splits), (int64_t)kMatchTile) * kMatchTile;
         LIDIFF_CHECK_HIP(hipMemsetAsync(idx, 0xff, (size_t)m_full * 8, st));
         nn_match_kernel<true, F32IN><<<dim3((unsigned)blocks, (unsigned)splits), kBlock, 0, st>>>(
-            full, m_full, part, m_part, per, d_max_coord, idx);
-        nn_match_finish_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, st>>>(idx, m_full);
+            full, m_full, part, m_part, per, d_max_coord, idx, d_m_full);
+        nn_match_finish_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, st>>>(idx, m_full, d_m_full);
     }
     LIDIFF_CHECK_LAUNCH();
     return 0;
@@ -1381,6 +1401,17 @@ int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, in
     if (m_full == 0) return 0;
     LIDIFF_CHECK_ARG(m_part < (int64_t)1 << 31, "part tensor too large for 32-bit row indices");
     return nn_match_launch<false>(full, m_full, part, m_part, d_max_coord, idx, (hipStream_t)stream);
+}
+
+int lidiff_nn_match_dev(const int32_t* full, int64_t m_full_bound, const int32_t* d_m_full, const int32_t* part, int64_t m_part,
+                        int32_t* d_max_coord, int64_t* idx, void* stream) {
+    LIDIFF_CHECK_ARG(full && d_m_full && part && d_max_coord && idx, "null pointer");
+    LIDIFF_CHECK_ARG(m_part >= 1 && m_part < (int64_t)1 << 31, "the part tensor must have 1 .. 2^31-1 rows");
+    if (m_full_bound == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    LIDIFF_CHECK_HIP(hipMemsetAsync(d_max_coord, 0x80, sizeof(int32_t), st));       // 0x80808080: below every coordinate
+    coord_max_dev_kernel<<<(unsigned)min((int64_t)512, ceil_div(m_full_bound, kBlock)), kBlock, 0, st>>>(full, d_m_full, d_max_coord);
+    return nn_match_launch<false>(full, m_full_bound, part, m_part, d_max_coord, idx, st, d_m_full);
 }
 
 int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m, int64_t* idx, void* stream) {

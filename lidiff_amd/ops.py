@@ -97,7 +97,7 @@ class Pyramid:
 
 
 def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, tail_levels: int = 2,
-                  second_stream=None) -> Pyramid:
+                  second_stream=None, on_level_dev=None) -> Pyramid:
     """Voxelise int32 coords [N, 4] (vox_unique), the `strides` strided maps below it (map_stride, tensor strides 2, 4, ...),
     and for the first `tail_levels` levels the kernel_size-3 map onto itself plus the COUNT phase of its tail map -- all queued
     back to back on the current stream with every row count staying on the device (the *_dev entry points), followed by
@@ -105,7 +105,10 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     1 + strides + tail_levels reads); buffers are sized for the point count, which bounds every level.
     second_stream: the kernel maps and tail counts of the first levels run there, next to the strided maps of the deeper levels
     on the current stream (a level's kernel map needs only that level): the chain is all small latency-bound kernels, so the
-    two halves overlap almost completely; the current stream joins before the read."""
+    two halves overlap almost completely; the current stream joins before the read.
+    on_level_dev(lv, rows_bound, d_count) (only with second_stream): called for every level under second_stream, BEHIND the event
+    the read waits for -- work that needs a level's coordinates but not its size on the host (DiffCompletion: the part -> full
+    matches, lidiff_nn_match_dev) runs there while the host is still blocked in the read."""
     require_device(coords, status)
     assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
     coords = coords.contiguous()
@@ -141,6 +144,9 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
             level_ev.append(torch.cuda.Event())
             level_ev[lv].record(cur)
     _trace("strides queued")
+    if second_stream is not None and on_level_dev is not None:
+        strides_done = torch.cuda.Event()
+        strides_done.record(cur)
     tails = []
     tail_ctx = torch.cuda.stream(second_stream) if second_stream is not None else contextlib.nullcontext()
     with tail_ctx:
@@ -164,6 +170,11 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
             for lv in range(min(tail_levels, strides + 1)):
                 for t in (rows[lv], tables[lv].keys, tables[lv].vals):
                     t.record_stream(second_stream)
+            if on_level_dev is not None:
+                second_stream.wait_event(strides_done)
+                for lv in range(strides + 1):
+                    rows[lv].record_stream(second_stream)
+                    on_level_dev(lv, rows[lv], counts[lv:lv + 1])
     if second_stream is not None:
         cur.wait_event(joined)
     _trace("tails queued")
@@ -329,6 +340,39 @@ class ConvProfiler:
             d["flops"] += fl
             d["bytes"] += by
         return out
+
+
+def launches_by_bound(prof: "ConvProfiler", ridge: float, variants=None):
+    """The timed launches of `variants` (None = all) split by what bounds them: arithmetic intensity = algorithmic flops /
+    algorithmic bytes of the launch against the machine's ridge point (peak FLOP/s / peak B/s) -- "mfma" at or
+    above it, "hbm" below.  Per class: launches, ms, flops, bytes and the per-shape rows (variant, k, c_in, c_out) inside it."""
+    torch.cuda.synchronize()
+    counts = {}
+    out = {b: {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "shapes": {}} for b in ("mfma", "hbm")}
+    for variant, start, end, m_in, m_out, c_in, c_out, k, nbr, reps in prof.launches:
+        if start is None or (variants is not None and variant not in variants):
+            continue
+        if nbr is None:
+            p = m_out
+        else:
+            key = nbr.data_ptr()
+            if key not in counts:
+                counts[key] = int((nbr >= 0).sum().item())
+            p = counts[key]
+        p, m_in, m_out = reps * p, reps * m_in, reps * m_out
+        fl, by = 2.0 * p * c_in * c_out, 4.0 * (m_in * c_in + m_out * c_out) + 4.0 * k * c_in * c_out + 8.0 * p
+        d = out["mfma" if fl / by >= ridge else "hbm"]
+        ms = start.elapsed_time(end)
+        d["launches"] += 1
+        d["ms"] += ms
+        d["flops"] += fl
+        d["bytes"] += by
+        r = d["shapes"].setdefault((variant, k, c_in, c_out), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        r["launches"] += 1
+        r["ms"] += ms
+        r["flops"] += fl
+        r["bytes"] += by
+    return out
 
 
 def layer_table(prof: "ConvProfiler", steps: int = 1):
@@ -971,6 +1015,58 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
 FPS_COOPERATIVE = os.environ.get("LIDIFF_FPS_COOPERATIVE", "1") != "0"
 
 
+def _inv_resolution(resolution: float) -> float:
+    """1 / resolution as torch's GPU kernels form it for ``x / resolution`` with a host scalar: the reciprocal in the opmath
+    type of float32 tensors (0.05 -> exactly 20.0f)."""
+    import numpy as np
+    return float(np.float32(1.0) / np.float32(resolution))
+
+
+def points_to_field(points: torch.Tensor, resolution: float, scale_batch_column: bool = True):
+    """[B, n, 3] device points (float64 or float32) -> (float32 features [B n, 3], int32 voxel coordinates [B n, 4]) in one
+    launch: batched_coordinates + round(x / resolution) + ME's floor (pipeline:68-84; models.py:162-178 with
+    scale_batch_column=False)."""
+    require_device(points)
+    if points.dim() != 3 or points.shape[2] != 3 or points.dtype not in (torch.float32, torch.float64):
+        raise ValueError("points must be [B, n, 3] float32 / float64")
+    points = points.contiguous()
+    n = points.shape[0] * points.shape[1]
+    feats = torch.empty((n, 3), dtype=torch.float32, device=points.device)
+    coords = torch.empty((n, 4), dtype=torch.int32, device=points.device)
+    call("lidiff_points_to_field", ptr(points), int(points.dtype == torch.float64), _inv_resolution(resolution), n,
+         max(1, points.shape[1]), int(bool(scale_batch_column)), ptr(feats), ptr(coords), stream_ptr())
+    return feats, coords
+
+
+def cfg_dpm_step(e_cond, e_uncond, w: float, x_t, x_init, plan: dict, noise, resolution: float, scale_batch_column: bool = True):
+    """Guidance + DPM-Solver++ update + the next field's points and voxel coordinates as one launch (lidiff_cfg_dpm_step;
+    pipeline:148-153,161-164).  plan: DPMSolverMultistepScheduler.step_plan(t).  Returns (x0 [B, n, 3] float64, features
+    [B n, 3] float32, coordinates [B n, 4] int32)."""
+    import numpy as np
+    require_device(e_cond, e_uncond, x_t, x_init)
+    b, n_per = x_init.shape[0], x_init.shape[1]
+    n = b * n_per
+    e_cond, e_uncond, x_t, x_init = (v.contiguous() for v in (e_cond, e_uncond, x_t, x_init))
+    if not (e_cond.dtype == e_uncond.dtype == x_t.dtype == torch.float32 and x_init.dtype == torch.float64
+            and e_cond.numel() == e_uncond.numel() == x_t.numel() == x_init.numel() == 3 * n):
+        raise ValueError("cfg_dpm_step: float32 eps / points [B, n, 3] and float64 x_init [B, n, 3] expected")
+    m_prev = plan["m_prev"]
+    if m_prev is not None:
+        m_prev = m_prev.contiguous()
+        assert m_prev.dtype == torch.float64 and m_prev.numel() == 3 * n
+    if noise is not None:
+        noise = noise.contiguous()
+        assert noise.dtype == torch.float64 and noise.numel() == 3 * n
+    x0 = torch.empty((b, n_per, 3), dtype=torch.float64, device=x_init.device)
+    feats = torch.empty((n, 3), dtype=torch.float32, device=x_init.device)
+    coords = torch.empty((n, 4), dtype=torch.int32, device=x_init.device)
+    call("lidiff_cfg_dpm_step", ptr(e_cond), ptr(e_uncond), float(w), ptr(x_t), ptr(x_init), ptr(m_prev), ptr(noise),
+         float(np.float32(plan["sigma_t"])), 1.0 / plan["alpha_t"], plan["c_sample"], plan["c_m0"], plan["c_d1"], plan["inv_r0"],
+         plan["c_noise"], _inv_resolution(resolution), n, max(1, n_per), int(bool(scale_batch_column)), ptr(x0), ptr(feats),
+         ptr(coords), stream_ptr())
+    return x0, feats, coords
+
+
 def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
     """open3d farthest_point_down_sample stand-in of preprocess_scan (pipeline:97-99): indices of n_samples
     points, greedy from index 0, float64 squared distances, first maximum wins."""
@@ -1030,6 +1126,19 @@ def nn_match(full_c: torch.Tensor, part_c: torch.Tensor, part_table: HashTable |
     else:
         call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord),
              ptr(idx), stream_ptr())
+    return idx
+
+
+def nn_match_dev(full_bound: torch.Tensor, d_count: torch.Tensor, part_c: torch.Tensor) -> torch.Tensor:
+    """nn_match for a map whose row count still lives on the device (build_pyramid before its host read): full_bound
+    [n_bound, 4] int32 of which the first d_count[0] rows are valid.  Returns idx [n_bound] int64 (valid rows written)."""
+    require_device(full_bound, d_count, part_c)
+    part_c = part_c.contiguous()
+    assert full_bound.dtype == torch.int32 and part_c.dtype == torch.int32 and d_count.dtype == torch.int32 and full_bound.is_contiguous()
+    max_coord = torch.empty(1, dtype=torch.int32, device=full_bound.device)
+    idx = torch.empty(full_bound.shape[0], dtype=torch.int64, device=full_bound.device)
+    call("lidiff_nn_match_dev", ptr(full_bound), full_bound.shape[0], ptr(d_count), ptr(part_c), part_c.shape[0], ptr(max_coord),
+         ptr(idx), stream_ptr())
     return idx
 
 

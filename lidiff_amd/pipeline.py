@@ -71,11 +71,25 @@ class DiffCompletion(nn.Module):
         self.dpm_scheduler.set_timesteps(d["s_steps"])
         self.dpm_scheduler.to(self.device)
 
+    # The boundary between two steps -- guidance, DPM-Solver++ update, the next field's points and voxel coordinates -- as ONE
+    # launch (ops.cfg_dpm_step / step.hip) instead of ~25 elementwise torch launches, and points_to_tensor as one launch
+    # (ops.points_to_field) instead of six; same values bit for bit (test_fused_step_boundary_equals_the_torch_sequence).
+    # LIDIFF_FUSED_STEP=0: the torch sequence.
+    fused_step = os.environ.get("LIDIFF_FUSED_STEP", "1") != "0"
+
     # pipeline:68-84
     def points_to_tensor(self, points):
+        if (self.fused_step and isinstance(points, torch.Tensor) and points.is_cuda and points.dim() == 3
+                and points.shape[2] == 3 and points.dtype in (torch.float32, torch.float64)):
+            from . import ops
+            feats, coords = ops.points_to_field(points.detach(), self.hparams["data"]["resolution"], scale_batch_column=True)
+            return self._make_field(feats, coords)
         x_feats = ME.utils.batched_coordinates(list(points[:]), dtype=torch.float32, device=self.device)
         x_coord = torch.round(x_feats / self.hparams["data"]["resolution"])
-        field = ME.TensorField(features=x_feats[:, 1:], coordinates=x_coord,
+        return self._make_field(x_feats[:, 1:], x_coord)
+
+    def _make_field(self, feats, coords):
+        field = ME.TensorField(features=feats, coordinates=coords,
                                quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
                                minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
         field.coordinate_manager.pyramid = self.single_read and field.F.device.type == "cuda"
@@ -167,6 +181,22 @@ class DiffCompletion(nn.Module):
             if part.C.shape[0] > 1:                  # a one-voxel part (the unconditional branch) needs no match
                 self.model.match_index(ME.SparseTensor(self._empty(), tensor_stride=ts, coordinate_manager=mgr), part,
                                        ahead=ahead)
+
+    # x_t's part -> full matches queued INSIDE its pyramid chain, reading the row counts from the device (lidiff_nn_match_dev):
+    # they run while the host is still blocked in the pyramid's size read, and the host goes from that read straight to the first
+    # convolutions instead of first queuing five searches (profiles/r04_step_boundary.txt).  LIDIFF_MATCH_IN_CHAIN=0: behind the read.
+    match_in_chain = os.environ.get("LIDIFF_MATCH_IN_CHAIN", "1") != "0"
+
+    def _match_level_dev(self, parts, ts, rows_bound, d_count):
+        from . import ops
+        out = []
+        for part in parts:
+            if part.C.shape[0] > 1:
+                idx = ops.nn_match_dev(rows_bound, d_count, part.C)
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+                out.append((("match", ts, id(part.coordinate_manager), part.tensor_stride), part.coordinate_manager, idx, done))
+        return out
 
     def _empty(self):
         if getattr(self, "_empty_t", None) is None:
@@ -346,6 +376,11 @@ class DiffCompletion(nn.Module):
     def classfree_forward(self, x_t, x_cond, x_uncond, t, parts=None, t_host=None):
         """t_host: the timestep as a host integer when the caller has it (saves nothing but lets the tables that were computed
         one step ahead be matched to this step without reading t back from the device)."""
+        e_cond, e_uncond = self.classfree_pair(x_t, x_cond, x_uncond, t, parts, t_host)
+        return e_uncond + self.w_uncond * (e_cond - e_uncond)
+
+    def classfree_pair(self, x_t, x_cond, x_uncond, t, parts=None, t_host=None):
+        """The two network outputs (conditional, unconditional) [B, N, 3] of classfree_forward, before the guidance mix."""
         marks = [] if self.timeline is not None else None
         self._stamp("step: enter")
         self._mark(marks)
@@ -378,7 +413,9 @@ class DiffCompletion(nn.Module):
                         x_t.ready.record(main)
                     x_t.F.record_stream(side), x_t.C.record_stream(side)
                     mgr = x_t.coordinate_manager
-                    mgr.set_async(side, self._side2, ready=x_t.ready, on_level=lambda ts: self._match_level(x_t, parts, ts, ahead=True))
+                    mgr.set_async(side, self._side2, ready=x_t.ready, on_level=lambda ts: self._match_level(x_t, parts, ts, ahead=True),
+                                  on_level_dev=(lambda ts, rows, cnt: self._match_level_dev(parts, ts, rows, cnt))
+                                  if self.match_in_chain else None)
                     try:
                         x_t_sparse = x_t.sparse()
                         self._mark(marks)
@@ -401,26 +438,42 @@ class DiffCompletion(nn.Module):
                 self._stamp("step: network queued")
                 if marks is not None:
                     self.timeline.append(marks)
-                e_cond, e_uncond = e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
-                return e_uncond + self.w_uncond * (e_cond - e_uncond)
+                return e_cond.reshape(t.shape[0], -1, 3), e_uncond.reshape(t.shape[0], -1, 3)
         # two forwards, as the reference runs them (pair_cfg = False); forward() joins the side stream for the conditions
         x_t_sparse = self._adopt(x_t).sparse()
         e_cond = self.forward(x_t, x_t_sparse, x_cond, t)
         e_uncond = self.forward(x_t, x_t_sparse, x_uncond, t)
-        return e_uncond + self.w_uncond * (e_cond - e_uncond)
+        return e_cond, e_uncond
 
     def denoise_step(self, x_init, x_t, x_cond, x_uncond, t_int: int, noise=None, parts=None, next_t=None):
         """One iteration of completion_loop (pipeline:158-167): CFG network pair, DPM-Solver++
         update on the per-point offsets, re-voxelisation of x_t and the two conditions (`parts`: the
         encoded conditions of a cache_condition run, which then skips their re-voxelisation too)."""
         t = torch.full((1,), t_int, dtype=torch.int64, device=self.device)
-        noise_t = self.classfree_forward(x_t, x_cond, x_uncond, t, parts, t_host=t_int)
-        input_noise = x_t.F.reshape(t.shape[0], -1, 3) - x_init
-        x_new = x_init + self.dpm_scheduler.step(noise_t, t_int, input_noise, noise=noise)["prev_sample"]
-        x_t = self.points_to_tensor(x_new)
+        e_cond, e_uncond = self.classfree_pair(x_t, x_cond, x_uncond, t, parts, t_host=t_int)
+        x_t = self.step_boundary(x_init, x_t, e_cond, e_uncond, t_int, noise)
         if parts is None:
             x_cond, x_uncond = self.reset_partial_pcd(x_cond, x_uncond, next_t=next_t)
         return x_t, x_cond, x_uncond
+
+    def step_boundary(self, x_init, x_t, e_cond, e_uncond, t_int: int, noise=None):
+        """pipeline:153 + 161-164: guidance mix, offsets, dpm_scheduler.step, x_init + prev_sample, points_to_tensor -> the next
+        step's field.  One launch (ops.cfg_dpm_step) when the inputs allow it, the torch sequence otherwise."""
+        sch = self.dpm_scheduler
+        if (self.fused_step and x_init.is_cuda and x_init.dtype == torch.float64 and x_init.dim() == 3
+                and sch.algorithm_type == "sde-dpmsolver++" and x_t.F.dtype == torch.float32 and e_cond.dtype == torch.float32
+                and (noise is None or (noise.dtype == torch.float64 and noise.is_cuda))):
+            from . import ops
+            if noise is None:                       # the draw dpm_scheduler.step makes (same generator state, same values)
+                noise = torch.randn(x_init.shape, device=x_init.device, dtype=torch.float64)
+            x0, feats, coords = ops.cfg_dpm_step(e_cond, e_uncond, self.w_uncond, x_t.F, x_init, sch.step_plan(t_int), noise,
+                                                 self.hparams["data"]["resolution"], scale_batch_column=True)
+            sch.commit(x0)
+            return self._make_field(feats, coords)
+        noise_t = e_uncond + self.w_uncond * (e_cond - e_uncond)
+        input_noise = x_t.F.reshape(x_init.shape[0], -1, 3) - x_init
+        x_new = x_init + sch.step(noise_t, t_int, input_noise, noise=noise)["prev_sample"]
+        return self.points_to_tensor(x_new)
 
     # pipeline:155-169
     def completion_loop(self, x_init, x_t, x_cond, x_uncond, noises=None):

@@ -129,6 +129,38 @@ class DPMSolverMultistepScheduler:
             self.lower_order_nums += 1
         return SchedulerOutput(prev_sample=prev) if return_dict else (prev,)
 
+    def step_plan(self, timestep):
+        """The host half of step() for a caller that evaluates the update in its own kernel (ops.cfg_dpm_step, the fused step
+        boundary of DiffCompletion.denoise_step): advances the multistep bookkeeping exactly as step() does and returns the
+        update's scalars -- the same Python floats, from the same expressions, that _first_order / _second_order multiply the
+        tensors with -- plus the previous data prediction.  The caller stores the new data prediction with commit()."""
+        if self.num_inference_steps is None:
+            raise ValueError("call set_timesteps first")
+        if self.algorithm_type != "sde-dpmsolver++":
+            raise NotImplementedError("step_plan covers sde-dpmsolver++ (the sampler LiDiff constructs)")
+        t = int(timestep) if not isinstance(timestep, torch.Tensor) else self._host_value(timestep)
+        n = len(self._host_timesteps)
+        step_index = self._host_timesteps.index(t) if t in self._host_timesteps else n - 1
+        t_prev = 0 if step_index == n - 1 else self._host_timesteps[step_index + 1]
+        lower_final = step_index == n - 1 and self.lower_order_final and n < 15
+        lam, alpha, sigma = self._host_tables()
+        for i in range(self.solver_order - 1):
+            self.model_outputs[i] = self.model_outputs[i + 1]
+        self.model_outputs[-1] = None                       # commit() fills it
+        h, a_p, s_p, s_t = self._coeffs(t, t_prev)
+        g = a_p * -math.expm1(-2.0 * h)
+        plan = {"t": t, "sigma_t": sigma[t], "alpha_t": alpha[t], "c_sample": s_p / s_t * math.exp(-h), "c_m0": g,
+                "c_noise": s_p * math.sqrt(-math.expm1(-2.0 * h)), "m_prev": None, "c_d1": 0.0, "inv_r0": 0.0}
+        if not (self.solver_order == 1 or self.lower_order_nums < 1 or lower_final):
+            r0 = (lam[t] - lam[self._host_timesteps[step_index - 1]]) / h
+            plan.update(m_prev=self.model_outputs[-2], c_d1=0.5 * g, inv_r0=1.0 / r0)
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        return plan
+
+    def commit(self, x0):
+        self.model_outputs[-1] = x0
+
     @staticmethod
     def _host_value(timestep: torch.Tensor) -> int:
         """A tensor timestep is accepted as upstream does (one device read if it lives on the

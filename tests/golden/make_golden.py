@@ -186,7 +186,31 @@ def make_heavy():
     print(f"t50_small: {time.time() - t0:.0f} s", flush=True)
 
 
+def make_closed():
+    """python tests/golden/make_golden.py --closed: the oracle's END-TO-END run of BASELINE configs[1] -- closed loop over all
+    T = 50 steps on the 180 000-point bench scan with seeded weights and shared scheduler noise, postprocess_scan, MinkUNet
+    refinement (tests/heavy_oracle.closed_compute; ~2 min of CPU per step on 8 cores) -> tests/golden/closed_c2.npz, the truth of
+    tests/test_gpu_baseline.py::test_closed_loop_c2_chamfer_vs_oracle."""
+    import time
+    import heavy_oracle as heavy
+    fps = np.load(os.path.join(HERE, "scan_000123_fps18000.npy"))
+    sd, sdr = heavy.seeded_state_dict(), heavy.seeded_refine_state_dict()
+    t0 = time.time()
+    scan = np.tile(fps.astype(np.float64), (10, 1))
+
+    def log(i, t, eps, xo):
+        off = xo[0] - scan
+        print(f"step {i} t={t} max |eps| {np.abs(eps).max():.4f} offsets std {off.std():.4f} max {np.abs(off).max():.2f} "
+              f"elapsed {time.time() - t0:.0f} s", flush=True)
+    out = heavy.closed_compute(fps, sd, sdr, log=log)
+    heavy.save_golden("closed_c2", heavy.closed_key(fps, sd, sdr), out)
+    print("closed_c2:", {k: v.shape for k, v in out.items()}, f"{time.time() - t0:.0f} s", flush=True)
+
+
 if __name__ == "__main__":
+    if "--closed" in sys.argv:
+        make_closed()
+        sys.exit(0)
     if "--heavy" in sys.argv:
         make_heavy()
         sys.exit(0)

@@ -230,3 +230,76 @@ def test_t50_trajectory_teacher_forced_every_point(device):
             assert dx < X_ATOL, (i, dx)                                          # every point, metres
     record_parity("t50_teacher_forced_2000pts", worst_abs_eps_err=worst_eps, worst_abs_x_err_m=worst_x, truth=src)
     print(f"T=50 teacher-forced: worst |eps| error {worst_eps:.2e}, worst |x| error {worst_x:.2e} m ({src})")
+
+
+# ---------------------------------------------------------------------------------------- (e)
+def _chamfer(a, b, device):
+    """utils/metrics.py:124-141 (ChamferDistance.update): (mean NN distance a -> b + mean NN distance b -> a) / 2, metres."""
+    from lidiff_amd.evaluation import ChamferDistance
+    cd = ChamferDistance(device=device)
+    cd.update(a, b)
+    return cd.compute()[0]
+
+
+def test_closed_loop_c2_chamfer_vs_oracle(device, fps_scan):
+    """BASELINE configs[1] END TO END, the metric's own acceptance quantity ("Chamfer vs ref", north_star: within 1e-3): the
+    180 000-point bench scan, seeded weights, the CLOSED loop over all T = 50 sde-dpmsolver++ steps (every step voxelises the
+    points the previous one produced: pipeline:155-169), postprocess_scan and the MinkUNet refinement forward
+    (pipeline:117-132) -- DiffCompletion on the device against the oracle's run of the same loop with the same scheduler noise
+    (tests/golden/closed_c2.npz, made by tests/golden/make_golden.py --closed from tests/heavy_oracle.closed_compute).
+    Compared with the reference's metric, utils/metrics.py:124-141: Chamfer(product, oracle) <= 1e-3 m for the diffused cloud
+    and for the refined cloud.  Unlike the teacher-forced tests nothing is re-synchronised here: a point within fp32 noise of a
+    voxel boundary may be voxelised differently by the two sides (torch's GPU kernels evaluate x / 0.05 as
+    x * 20.0f, the CPU divides -- ~5 ppm of the coordinates per step), which changes that point's -- and through the
+    convolutions its neighbours' -- trajectory; the per-point shares and the positions kept along the trajectory are recorded."""
+    from lidiff_amd.pipeline import DiffCompletion
+    sd, sd_refine = heavy.seeded_state_dict(), heavy.seeded_refine_state_dict()
+    key = heavy.closed_key(fps_scan, sd, sd_refine)
+    assert heavy.golden_status("closed_c2", key) == (True, True, True), \
+        "tests/golden/closed_c2.npz is absent or stale: python tests/golden/make_golden.py --closed (~100 min of CPU)"
+    with np.load(heavy.golden_path("closed_c2")) as z:
+        want = {k: z[k] for k in z.files if not k.endswith("_sha1")}
+    enc, unet, refine = build_seeded_models(42)
+    pipe = DiffCompletion(denoising_steps=heavy.CLOSED_STEPS, cond_weight=6.0, device=device)
+    pipe.partial_enc, pipe.model, pipe.model_refine = enc.to(device), unet.to(device), refine.to(device)
+    scan_np, noisy_np = heavy.closed_inputs(fps_scan)
+    n = scan_np.shape[0]
+    scan = torch.from_numpy(scan_np).double()[None].to(device)
+    x_t = pipe.points_to_tensor(torch.from_numpy(noisy_np).double()[None].to(device))
+    x_cond, x_uncond = pipe.points_to_tensor(scan), pipe.points_to_tensor(torch.zeros_like(scan))
+    pipe.new_scheduler()
+    ts = pipe.dpm_scheduler.host_timesteps
+    assert len(ts) == heavy.CLOSED_STEPS
+    along = {}
+    for i, t_int in enumerate(ts):
+        x_t, x_cond, x_uncond = pipe.denoise_step(scan, x_t, x_cond, x_uncond, t_int, torch.from_numpy(heavy.closed_noise(i, n)).to(device),
+                                                  next_t=ts[i + 1] if i + 1 < len(ts) else None)
+        if i + 1 in heavy.CLOSED_KEEP:
+            got = x_t.F.contiguous().cpu().numpy()
+            err = np.abs(got - want[f"x{i + 1}"]).max(axis=1)
+            along[i + 1] = (float(np.mean(err <= 1e-4)), float(np.mean(err <= 1e-3)), float(np.median(err)), float(err.max()))
+    x_t.coordinate_manager.check()
+    completed = x_t.F.contiguous().cpu().numpy()
+    assert completed.shape == want["completed"].shape == (n, 3) and np.isfinite(completed).all()
+    err = np.abs(completed - want["completed"]).max(axis=1)
+    cd_diff = _chamfer(completed, want["completed"], device)
+    # post-filter + refinement (pipeline:123-130), both sides from their OWN diffused cloud
+    post = pipe.postprocess_scan(completed, scan_np[None].astype(np.float64))
+    post_o = heavy.postprocess_scan(want["completed"], scan_np[None].astype(np.float64))
+    assert post_o.shape[0] == int(want["post_rows"][0]) == want["refine_offset"].shape[0]
+    offset = pipe.refine_forward(pipe.points_to_tensor(torch.as_tensor(post[None, :, :]))).reshape(-1, 6, 3).cpu().numpy()
+    refined = (post[:, None, :] + offset).reshape(-1, 3)
+    refined_o = (post_o[:, None, :] + want["refine_offset"].reshape(-1, 6, 3)).reshape(-1, 3)
+    cd_ref = _chamfer(refined, refined_o, device)
+    scale = float(np.abs(want["completed"] - scan_np).max())
+    record_parity("closed_loop_c2_180k_T50", chamfer_diffused_m=cd_diff, chamfer_refined_m=cd_ref,
+                  share_within_0p1mm=float(np.mean(err <= 1e-4)), share_within_1mm=float(np.mean(err <= 1e-3)),
+                  share_within_5mm=float(np.mean(err <= 5e-3)), points_beyond_0p1mm=int(np.sum(err > 1e-4)),
+                  median_err_m=float(np.median(err)), max_err_m=float(err.max()), max_offset_m=scale,
+                  post_rows=int(post.shape[0]), post_rows_oracle=int(post_o.shape[0]),
+                  **{f"step{k}_share_0p1mm": v[0] for k, v in along.items()}, **{f"step{k}_max_err_m": v[3] for k, v in along.items()})
+    print(f"closed loop C2: Chamfer diffused {cd_diff:.3e} m, refined {cd_ref:.3e} m; points within 0.1 mm {np.mean(err <= 1e-4):.6f}, "
+          f"1 mm {np.mean(err <= 1e-3):.6f}; median {np.median(err):.2e} m, max {err.max():.2e} m; along the trajectory "
+          f"(step: share <= 0.1 mm, share <= 1 mm, median, max) {along}; post-filter rows {post.shape[0]} vs {post_o.shape[0]}")
+    assert cd_diff <= 1e-3, cd_diff
+    assert cd_ref <= 1e-3, cd_ref

@@ -484,6 +484,16 @@ def test_nn_match(device):
     f = np.array([[0, 0, 0, 0]], np.int32)                             # exact tie -> lowest index
     p = np.array([[0, 2, 0, 0], [0, -2, 0, 0], [0, 0, 2, 0]], np.int32)
     assert ops.nn_match(dev_i32(f, device), dev_i32(p, device)).item() == 0
+    # row count on the device (the matches queued inside a pyramid chain, lidiff_nn_match_dev): a buffer sized for a BOUND whose
+    # rows beyond the count hold garbage (larger coordinates than any valid row: they must not enter max_coord) -- same winners
+    for n_full, n_bound in ((300, 5000), (5000, 5000), (70000, 180000), (1, 64)):
+        fc = random_cloud(n_full, 60, 20 + n_full, batch=2)
+        buf = np.full((n_bound, 4), 30000, np.int32)
+        buf[:n_full] = fc
+        cnt = torch.tensor([n_full], dtype=torch.int32, device=device)
+        for pc in (part, part_dup, one):
+            got = ops.nn_match_dev(dev_i32(buf, device), cnt, dev_i32(pc, device))[:n_full].cpu().numpy()
+            assert np.array_equal(got, me.argmin_match(fc, pc)), (n_full, n_bound, pc.shape)
 
 
 def test_fps_reproduces_the_committed_scan_from_the_range_filtered_input(device, fps_scan):

@@ -239,6 +239,48 @@ def test_completion_loop_vs_oracle(device, models):
     assert np.array_equal(cached, out), (np.count_nonzero(dd), dd.size, dd.max())
 
 
+def test_fused_step_boundary_equals_the_torch_sequence(device, models, fps_scan):
+    """SURVEY.md 8(f) row 1 / pipeline:148-167: the boundary between two steps as ONE launch (lidiff_cfg_dpm_step: guidance,
+    DPM-Solver++ update, the next field's points and voxel coordinates) and points_to_tensor as one launch
+    (lidiff_points_to_field) give the SAME BITS as the ~25 torch launches they stand for -- every product and sum rounded where
+    torch rounds it, x / 0.05 as the reciprocal multiplication torch's GPU kernels perform: (a) points_to_tensor on fp64 / fp32
+    points with two batches, (b) a T = 6 closed loop (first-order first step, second-order afterwards) with injected noise and
+    with the scheduler's own draws from the same generator state."""
+    from lidiff_amd.pipeline import DiffCompletion
+    enc, unet, refine, sd = models
+    pipe = DiffCompletion(denoising_steps=6, cond_weight=6.0, device=device)
+    pipe.partial_enc, pipe.model, pipe.model_refine = enc, unet, refine
+    rng = np.random.default_rng(5)
+    for dt in (torch.float64, torch.float32):
+        pts = torch.from_numpy(rng.standard_normal((2, 5000, 3)) * 30.0).to(dt).to(device)
+        got = {}
+        for fused in (True, False):
+            pipe.fused_step = fused
+            f = pipe.points_to_tensor(pts)
+            ci = f.C if f.C.dtype == torch.int32 else torch.floor(f.C).to(torch.int32)
+            got[fused] = (f.F.contiguous().cpu(), ci.cpu())
+        assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1]), dt
+        assert got[True][1][:, 0].unique().tolist() == [0, 20]          # the batch column is divided by the resolution too
+    scan_np = np.tile(fps_scan[:600].astype(np.float32), (10, 1))
+    noisy_np = noisy_scan_points(fps_scan[:600], 1.0, 3)
+    scan = torch.from_numpy(scan_np).double()[None].to(device)
+    x_feats = torch.from_numpy(noisy_np).double()[None].to(device)
+    z = [torch.from_numpy(rng.standard_normal((1, scan_np.shape[0], 3))).to(device) for _ in range(6)]
+    outs = {}
+    for mode in ("injected", "drawn"):
+        for fused in (True, False):
+            pipe.fused_step = fused
+            pipe.new_scheduler()
+            torch.manual_seed(77)
+            outs[(mode, fused)] = pipe.completion_loop(scan, pipe.points_to_tensor(x_feats), pipe.points_to_tensor(scan),
+                                                       pipe.points_to_tensor(torch.zeros_like(scan)),
+                                                       noises=z if mode == "injected" else None)
+        d = np.abs(outs[(mode, True)] - outs[(mode, False)])
+        assert np.array_equal(outs[(mode, True)], outs[(mode, False)]), (mode, np.count_nonzero(d), float(d.max()))
+    assert not np.array_equal(outs[("injected", True)], outs[("drawn", True)])
+    pipe.fused_step = True
+
+
 def test_overlapped_coordinate_pipeline_equals_the_serial_one(device, models, fps_scan):
     """DiffCompletion.overlap_maps: the coordinate pipeline of a field on a side stream, under another tensor's convolutions
     (the next step's conditions under the UNet, x_t's maps under the condition encoders).  Scheduling only: four closed-loop

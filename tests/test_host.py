@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         argtypes = _lib.SIGNATURES[name][1]
         assert len(params) == len(argtypes), (name, params, argtypes)
         for q, a in zip(params, argtypes):
-            want = C.c_void_p if "*" in q else C.c_float if q.startswith("float") else None
+            want = C.c_void_p if "*" in q else C.c_float if q.startswith("float") else C.c_double if q.startswith("double") else None
             assert (a is want) if want is not None else a in (C.c_int32, C.c_int64), (name, q, a)
             if want is None:
                 assert a is (C.c_int64 if q.startswith("int64_t") else C.c_int32), (name, q, a)

@@ -145,6 +145,15 @@ def cpu_baseline(scan_np, seed=42, threads=0):
                       f"{cores} OpenMP threads / {torch.get_num_threads()} torch threads on {model}"}
 
 
+_STDOUT = None            # the real stdout once main() has pointed fd 1 at stderr
+
+
+def emit(line: str):
+    out = _STDOUT or sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 VARIANT_KERNELS = {"bn128": ("<128, 8, 1",), "bn96": ("<128, 6, 1", "<128, 3, 2"), "bn64": ("<128, 4, 2",),
                    "bn32": ("<128, 2, 4",), "bn16": ("<128, 1, 8",), "rows": ("spconv_rows_kernel",), "thin": ("spconv_thin_kernel",)}
 COORD_KERNELS = ("insert_kernel", "flag_count_kernel", "scan_write_kernel", "inverse_kernel", "mean_", "kernel_map_",
@@ -260,9 +269,28 @@ def train_leg(scan_np, device, steps=3, warmup=1):
     ev = lambda: torch.cuda.Event(enable_timing=True)
     out = {"workload": "configs[4] per-GPU shape: B = 2 x 180000 points, 18000-point partial scans, forward + loss + backward "
                        "+ Adam, random-init weights (tools/train_probe.py is the same step)", "steps": steps, "warmup": warmup}
-    for precision in ("32", "bf16"):
+    import torch.distributed as tdist
+    import lidiff_amd.MinkowskiEngine as ME
+    own_group = False
+    for precision in ("32", "bf16", "bf16_syncbn"):
+        sync = precision.endswith("_syncbn")
+        precision = precision.split("_")[0]
         torch.manual_seed(0)
         module = DiffusionPoints(device=device, precision=precision)
+        if sync:
+            # configs[4] runs under convert_sync_batchnorm (train.py:90): the same step with every BatchNorm on the synchronised
+            # path of norm.hip -- per-channel fp64 sums, ONE all-reduce per layer forward and backward over RCCL -- in a process
+            # group of this one rank (the 1-GPU box): all the launches and collectives of the multi-rank step, minus the wire
+            if not tdist.is_initialized():
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                         device_id=device)
+                own_group = True
+            ops.SyncBatchNorm1d.sync_single_rank = True
+            ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(module)
         module.train()
         opt, _ = module.configure_optimizers()
         gen = torch.Generator(device=device).manual_seed(1)
@@ -292,16 +320,84 @@ def train_leg(scan_np, device, steps=3, warmup=1):
                 dw_ms += prof.dw_ms()
         ms = {k: v / steps for k, v in tot.items()}
         total = sum(ms.values())
-        out["f32" if precision == "32" else "bf16"] = {
+        out[("f32" if precision == "32" else "bf16") + ("_syncbn" if sync else "")] = {
             "ms_per_step": total, "steps_per_s": 1e3 / total, "scans_per_s": 2e3 / total, **ms,
             "conv_fwd_dx_kernels_ms": conv_ms / steps, "conv_dw_kernels_ms": dw_ms / steps,
             "other_ms": total - (conv_ms + dw_ms) / steps,
             "peak_memory_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "final_loss": float(loss.detach())}
+        if sync:
+            out["bf16_syncbn"]["sync_batchnorm_layers"] = sum(type(m) is ops.SyncBatchNorm1d for m in module.modules())
+            out["bf16_syncbn"]["collectives_per_step"] = 2 * out["bf16_syncbn"]["sync_batchnorm_layers"]
+            out["bf16_syncbn"]["backend"] = tdist.get_backend()
+            ops.SyncBatchNorm1d.sync_single_rank = False
         del module, opt, loss
         torch.cuda.empty_cache()
-    out["note"] = ("other_ms = BatchNorm (torch), conditioning / head MLP GEMMs (hipBLASLt), coordinate maps, loss, Adam and "
+    if own_group:
+        tdist.destroy_process_group()
+    out["note"] = ("other_ms = BatchNorm (norm.hip), conditioning / head MLP GEMMs (hipBLASLt), coordinate maps, loss, Adam and "
                    "launch gaps; data-parallel training adds one bucketed gradient all-reduce per step (lidiff_amd/dist.py)")
     return out
+
+
+def load_raw_scan():
+    """The reference's bundled scan after its range filter (119 035 points): what preprocess_scan's FPS takes in."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_range_filtered.npy")).astype(np.float64)
+
+
+def pipeline_leg(pipe, device, seeds, warm=True):
+    """DiffCompletion.complete_scan (pipeline:117-132, timed per scan as pipeline:198-203 does): range filter + farthest-point
+    sampling to 18 000 points, x10 + N(0, I), the CLOSED T = 50 CFG denoising loop, post-filter, refinement forward -- seeded
+    random-init weights, one scan per seed.  Returns the per-scan seconds and the phase sums."""
+    raw = load_raw_scan()
+    if warm:                                                   # kernels / allocator / packed weights: one short scan, untimed
+        saved = pipe.hparams["diff"]["s_steps"]
+        pipe.hparams["diff"]["s_steps"] = 2
+        pipe.complete_scan(raw, generator=torch.Generator(device=device).manual_seed(1))
+        pipe.hparams["diff"]["s_steps"] = saved
+        torch.cuda.synchronize()
+    per_scan, phases, rows = [], {}, []
+    for seed in seeds:
+        gen = torch.Generator(device=device).manual_seed(int(seed))
+        torch.manual_seed(int(seed))                           # the scheduler's draws (torch.randn without a generator, as upstream)
+        t0 = time.perf_counter()
+        refined, diffused = pipe.complete_scan(raw, generator=gen, timings=phases)
+        torch.cuda.synchronize()
+        per_scan.append(time.perf_counter() - t0)
+        rows.append((int(diffused.shape[0]), int(refined.shape[0]), bool(np.isfinite(refined).all())))
+    return per_scan, phases, rows
+
+
+def pipeline_main(args, rank, world, device):
+    """`bench.py --gpus N --pipeline [--scans S]`: BASELINE configs[2] / [3]'s unit of work -- whole scans (FPS + T = 50 +
+    refinement), scans sharded round-robin over the ranks (dist.shard_items: scan i -> rank i mod N), no collective on the data
+    path; barrier + synchronize on both sides, MAX over ranks, ONE line from rank 0: scans/s of the whole job and s/scan."""
+    from lidiff_amd import dist as ldist
+    ranks_seen = int(ldist.sum_over_ranks(1.0, device=device))
+    pipe = build_pipeline(device)
+    total = world * args.scans
+    mine = ldist.shard_items(total, rank, world)
+    with torch.no_grad():
+        pipeline_leg(pipe, device, [], warm=True)
+        ldist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        per_scan, phases, rows = pipeline_leg(pipe, device, [5000 + i for i in mine], warm=False)
+        torch.cuda.synchronize()
+        ldist.barrier()
+        elapsed = ldist.max_over_ranks(time.perf_counter() - t0, device=device)
+    if rank != 0:
+        return
+    emit(json.dumps({
+        "metric": "completed scans/sec (FPS + T=50 CFG denoising + refinement) on 180k-pt scans", "value": total / elapsed,
+        "unit": "scans/s", "n_gpus": world, "rccl_ranks_seen": ranks_seen, "visible_devices": torch.cuda.device_count(),
+        "scans": total, "scans_per_gpu": args.scans, "s_per_scan": elapsed / args.scans, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "denoising_steps_per_s": total * T_STEPS / elapsed,
+        "config": {"workload": "configs[2]: independent 180000-point scans (bundled scan, own noise seed each) sharded one per GPU, "
+                               "DiffCompletion.complete_scan = range filter + FPS 18000 + T=50 sde-dpmsolver++ CFG loop (closed) + "
+                               "post-filter + MinkUNet refinement, fp32, seeded random-init weights",
+                   "parallelism": f"scan-sharded x{world}, no data-path collective", "shard_of_rank0": mine},
+        "rank0": {"s_per_scan": per_scan, "phases_s": phases, "rows_diffused_refined_finite": rows}}))
 
 
 def spawn_ranks(args, argv):
@@ -338,8 +434,8 @@ def dry_run(args, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "denoising steps/sec on 180k-pt scan", "dry_run": True, "n_gpus": world,
                           "rccl_ranks_seen": seen, "backend": tdist.get_backend() if world > 1 else None,
-                          "steps": args.steps, "warmup": args.warmup, "elapsed_s": elapsed,
-                          "shards": [ldist.shard_items(world, r, world) for r in range(world)]}))
+                          "steps": args.steps, "warmup": args.warmup, "elapsed_s": elapsed, "pipeline": bool(args.pipeline),
+                          "shards": [ldist.shard_items(world * (args.scans if args.pipeline else 1), r, world) for r in range(world)]}))
     if world > 1:
         tdist.destroy_process_group()
 
@@ -366,6 +462,12 @@ def main():
                     help="skip the 'train' leg (configs[4]'s per-GPU training step, fp32 and bf16: 4 steps each)")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the 'alt' leg (the same steps with the dense layers from two bf16 pieces per operand)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="time whole scans instead of denoising steps: DiffCompletion.complete_scan (FPS + T = 50 + refinement) on "
+                         "--scans scans per rank, sharded over the ranks (BASELINE configs[2] / [3]); prints scans/s and s/scan")
+    ap.add_argument("--scans", type=int, default=1, help="--pipeline: scans per rank")
+    ap.add_argument("--no-closed-loop", action="store_true",
+                    help="skip the 'closed_loop' leg (one complete_scan with seeded weights: s per scan, beside the metric)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / timing plumbing only, on the CPU over gloo (no kernels): CI of the N > 1 path")
     args = ap.parse_args()
@@ -373,6 +475,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args, sys.argv[1:]))
     from lidiff_amd import dist as ldist
+    if not args.dry_run:
+        # ONE line on stdout: native libraries write there too (RCCL prints its version banner when a communicator is created), so the
+        # process's fd 1 points at stderr for the whole run and the JSON line goes to the saved descriptor at the end
+        global _STDOUT
+        sys.stdout.flush()
+        _STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     rank, world, local = ldist.init_from_env("gloo" if args.dry_run else "nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
@@ -387,6 +496,8 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:       # N ranks share the host: each keeps to its share of the cores (the step's host side is one Python thread)
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    if args.pipeline:
+        return pipeline_main(args, rank, world, device)
     # one tiny collective over RCCL before anything is timed: every rank must be seen (the data path itself has none)
     ranks_seen = int(ldist.sum_over_ranks(1.0, device=device))
 
@@ -580,13 +691,27 @@ def main():
     if world == 1 and not args.no_coords_roofline:
         with torch.no_grad():
             out["roofline_hbm"] = coords_roofline(scan_np, device)
+    if world == 1 and not args.no_closed_loop:
+        # beside the metric, never `value` (SURVEY.md 8d "also report the closed-loop run with seeded random weights"): one whole
+        # scan through DiffCompletion.complete_scan -- the number the reference itself prints per scan (pipeline:198-203)
+        with torch.no_grad():
+            per_scan, phases, rows = pipeline_leg(pipe, device, [5000])
+        out["closed_loop"] = {
+            "s_per_scan": per_scan[0], "scans_per_s": 1.0 / per_scan[0], "denoising_steps_per_s": T_STEPS / phases["denoise_s"],
+            "ms_per_denoising_step": 1e3 * phases["denoise_s"] / T_STEPS, "phases_s": phases,
+            "points_diffused": rows[0][0], "points_refined": rows[0][1], "finite": rows[0][2],
+            "workload": "complete_scan (pipeline:117-132) on the bundled scan: range filter + FPS 119035 -> 18000, x10 + N(0, I), CLOSED "
+                        "T=50 CFG loop (each step voxelises the points the previous one produced), post-filter, MinkUNet refinement; "
+                        "seeded random-init weights -- the offsets do not contract as with trained weights (they grow to ~1 / alpha_T), "
+                        "so the maps are sparser than on the metric's sigma_t trajectory; parity of this loop against the oracle: "
+                        "tests/test_gpu_baseline.py::test_closed_loop_c2_chamfer_vs_oracle"}
     if world == 1 and not args.no_train:
         del pipe
         torch.cuda.empty_cache()
         out["train"] = train_leg(scan_np, device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scan_np, threads=args.cpu_threads)
-    print(json.dumps(out))
+    emit(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -277,9 +277,13 @@ int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int
                        float* dst, void* stream);
 /* The same sum without atomics: dst[o, :] = sum of src[order[q], :] over q in [ptr[o], ptr[o + 1]), in list order -- `order` the
  * sources sorted by destination row (stable: source order inside a destination), `ptr` [m + 1] the CSR over the m destination
- * rows.  Deterministic: the backward of SparseTensor.slice and of the conditioning gathers in training (models.py:180-217). */
+ * rows.  Deterministic: the backward of SparseTensor.slice and of the conditioning gathers in training (models.py:180-217).
+ * worklist (nullable; worklist_ints >= 2 int32, e.g. n_sources / 64 + 2): destinations with more than 64 sources -- the
+ * unconditional branch of a training step, models.py:192-195, gathers ~180 000 rows from each of 2 part voxels -- are summed by
+ * one workgroup per (destination, 32 channels) in a fixed lane order instead of by one thread walking the whole segment; without
+ * it every segment takes the one-thread path. */
 int lidiff_segment_sum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t m, int32_t c, float* dst,
-                            void* stream);
+                            int32_t* worklist, int64_t worklist_ints, void* stream);
 int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
                             float* dst, void* stream);
 
@@ -327,8 +331,9 @@ int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m,
 /* Training-mode batch normalisation over the rows of a feature matrix [m, c] -- MinkowskiBatchNorm = nn.BatchNorm1d on F
  * (minkunet.py:23,59,79; the training step of models.py:180-217).  One pass over [m, c] per kernel, double accumulators,
  * partial sums combined in a fixed order: deterministic.  c a multiple of 4, pointers 16-byte aligned.
- *   lidiff_bn_stats : mean[c], var[c] (BIASED: the normaliser; the running estimate takes var * m / (m - 1)),
- *                     invstd[c] = 1 / sqrt(var + eps).  workspace: lidiff_bn_workspace_bytes(c).
+ *   lidiff_bn_stats : mean[c], var[c] (BIASED: the normaliser), invstd[c] = 1 / sqrt(var + eps); running_mean / running_var
+ *                     (nullable) are updated in the same launch as nn.BatchNorm1d updates them: r = (1 - momentum) r + momentum x
+ *                     with the UNBIASED variance var * m / (m - 1).  workspace: lidiff_bn_workspace_bytes(c).
  *   lidiff_bn_apply : y = (x - mean) * invstd * gamma + beta (gamma / beta nullable) [+ residual, nullable: the ResidualBlock's
  *                     shortcut, minkunet.py:79], ReLU on request (relu != 0).
  *   lidiff_bn_bwd   : sum_dy[c] = sum dy, sum_dy_xmu[c] = sum dy * (x - mean) (d beta and, times invstd, d gamma), and -- unless
@@ -336,8 +341,8 @@ int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m,
  *                     y_relu != NULL: the forward applied ReLU and y_relu is its output -- dy counts only where y_relu > 0.
  *                     d_residual != NULL: receives that (masked) dy, the gradient of the forward's residual operand. */
 int64_t lidiff_bn_workspace_bytes(int32_t c);
-int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, float* mean, float* var, float* invstd, void* workspace,
-                    void* stream);
+int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, float* mean, float* var, float* invstd,
+                    float* running_mean, float* running_var, float momentum, void* workspace, void* stream);
 int lidiff_bn_apply(const float* x, int64_t m, int32_t c, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, const float* residual, int32_t relu, float* y, void* stream);
 int lidiff_bn_bwd(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
@@ -348,17 +353,19 @@ int lidiff_bn_bwd(const float* dy, const float* x, const float* y_relu, int64_t 
  * train.py:90 / train_refine.py:58 (convert_sync_batchnorm) put in place of every MinkowskiBatchNorm under DDP.  The library never
  * communicates: it hands the caller the LOCAL per-channel sums as fp64, the caller all-reduces them (RCCL; SUM is exact enough in
  * fp64 to make every rank derive bit-identical statistics) and hands them back.
- *   lidiff_bn_sums            : sums[0..c) = sum x, sums[c..2c) = sum x^2 over this rank's m rows.  The caller stores its row
- *                               count in sums[2c] and all-reduces all 2c + 1 doubles in ONE collective.
+ *   lidiff_bn_sums            : sums[0..c) = sum x, sums[c..2c) = sum x^2 over this rank's m rows, sums[2c] = m.  The caller
+ *                               all-reduces all 2c + 1 doubles in ONE collective.
  *   lidiff_bn_stats_from_sums : mean / biased var / invstd of lidiff_bn_stats from such (all-reduced) sums, count = sums[2c]
- *                               read on the device (no host round trip).  lidiff_bn_apply then runs unchanged.
+ *                               read on the device (no host round trip); running estimates updated as lidiff_bn_stats does,
+ *                               with the GLOBAL count.  lidiff_bn_apply then runs unchanged.
  *   lidiff_bn_bwd_sums        : sums[0..c) = sum dy, sums[c..2c) = sum dy * (x - mean) over this rank's rows (mean = the GLOBAL
  *                               mean; dy masked by y_relu > 0 as in lidiff_bn_bwd): d beta and, times invstd, d gamma of this
  *                               rank -- and, all-reduced, the two projections dx needs.
  *   lidiff_bn_bwd_apply       : dx (and d_residual) of lidiff_bn_bwd from the all-reduced sums and the device-resident global row
  *                               count; sum_dy / sum_dy_xmu receive the fp32 copies the kernel reads. */
 int lidiff_bn_sums(const float* x, int64_t m, int32_t c, double* sums, void* workspace, void* stream);
-int lidiff_bn_stats_from_sums(const double* sums, int32_t c, float eps, float* mean, float* var, float* invstd, void* stream);
+int lidiff_bn_stats_from_sums(const double* sums, int32_t c, float eps, float* mean, float* var, float* invstd,
+                              float* running_mean, float* running_var, float momentum, void* stream);
 int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                        double* sums, void* workspace, void* stream);
 int lidiff_bn_bwd_apply(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,

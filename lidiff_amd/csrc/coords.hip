@@ -241,7 +241,10 @@ __global__ void mean_div_kernel(const unsigned long long* __restrict__ acc, cons
     if (e >= total) return;
     const double inv_scale = ldexp(1.0, -mean_shift(*amax, n_bits));
     const float n = (float)cnt[e / c];
-    const float sum = (float)((double)(long long)acc[e] * inv_scale);  // the exact sum, rounded to fp32 once
+    float sum = (float)((double)(long long)acc[e] * inv_scale);        // the exact sum, rounded to fp32 once
+    // an Inf / NaN feature anywhere makes the common scale meaningless for every voxel: the whole batch reads NaN (a diverged
+    // training run must not be masked by finite garbage; the fp32-atomic form propagated NaN to the affected voxel only)
+    if (*amax >= 0x7f800000u) sum = __uint_as_float(0x7fc00000u);
     out[e] = sum / n;
     if (e % c == 0) counts[e / c] = n;
 }
@@ -666,15 +669,28 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int
 
 // dst[o] = sum of src[order[q]] for q in [ptr[o], ptr[o + 1]) -- the scatter-add over a destination-sorted source list: every
 // destination row adds its sources in list order (the stable sort keeps source order), no atomics: deterministic.
+// One thread per (destination, float4) walks its segment; a segment longer than kSegShort sources is NOT summed here: the thread
+// of its first float4 appends the destination to `worklist` (worklist[0] = count) and segment_sum_long_kernel sums it
+// cooperatively.  (The unconditional branch of a training step -- models.py:192-195, a part of all zeros -- puts ~180 000
+// sources on each of 2 destinations at every conditioning level: one thread per float4 would walk them one by one.)
+constexpr int kSegShort = 64;
 template <bool VEC4>
 __global__ void segment_sum_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ order,
-                                        const int64_t* __restrict__ ptr, int64_t m, int c, float* __restrict__ dst) {
+                                        const int64_t* __restrict__ ptr, int64_t m, int c, float* __restrict__ dst,
+                                        int32_t* __restrict__ worklist, int64_t worklist_cap) {
     const int cw = VEC4 ? c / 4 : c;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m * cw) return;
     const int64_t o = e / cw;
     const int j = (int)(e % cw);
     const int64_t lo = ptr[o], hi = ptr[o + 1];
+    if (worklist != nullptr && hi - lo > kSegShort) {
+        if (j == 0) {
+            const int slot = atomicAdd(worklist, 1);         // (the order of the list does not enter any sum)
+            if (slot < worklist_cap) worklist[1 + slot] = (int32_t)o;
+        }
+        return;
+    }
     if constexpr (VEC4) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int64_t q = lo; q < hi; ++q) {
@@ -686,6 +702,39 @@ __global__ void segment_sum_rows_kernel(const float* __restrict__ src, const int
         float a = 0.f;
         for (int64_t q = lo; q < hi; ++q) a += src[order[q] * c + j];
         dst[o * c + j] = a;
+    }
+}
+
+// The long segments: workgroup (x, g) takes the destinations worklist[1 + x], worklist[1 + x + gridDim.x], ... and of each the
+// channels [32 g, 32 g + 32).  Its 256 threads are 32 source lanes x 8 channel quads (128 contiguous bytes per source row):
+// lane r adds the sources lo + r, lo + r + 32, ... in order, the 32 partials are then added in lane order -- fixed order:
+// deterministic (and independent of the order in which the worklist was filled).
+__global__ __launch_bounds__(256) void segment_sum_long_kernel(const float* __restrict__ src, const int64_t* __restrict__ order,
+                                                               const int64_t* __restrict__ ptr, int c, float* __restrict__ dst,
+                                                               const int32_t* __restrict__ worklist, int64_t worklist_cap) {
+    __shared__ float sm[32][33];
+    const int count = (int)min((int64_t)worklist[0], worklist_cap);
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const int ch0 = 32 * blockIdx.y + 4 * q;                  // first of this thread's (up to) 4 channels
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const int64_t o = worklist[1 + i];
+        const int64_t lo = ptr[o], hi = ptr[o + 1];
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t s = lo + r; s < hi; s += 32) {
+            const float* row = src + order[s] * c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ch0 + e < c) a[e] += row[ch0 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm[r][4 * q + e] = a[e];
+        __syncthreads();
+        if (threadIdx.x < 32 && 32 * blockIdx.y + threadIdx.x < c) {
+            float t = 0.f;
+            for (int rr = 0; rr < 32; ++rr) t += sm[rr][threadIdx.x];
+            dst[o * c + 32 * blockIdx.y + threadIdx.x] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -1383,14 +1432,20 @@ int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows
 }
 
 int lidiff_segment_sum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t m, int32_t c, float* dst,
-                            void* stream) {
+                            int32_t* worklist, int64_t worklist_ints, void* stream) {
     LIDIFF_CHECK_ARG(c > 0 && m >= 0, "bad shape");
     if (m == 0) return 0;
     LIDIFF_CHECK_ARG(src && order && ptr && dst, "null pointer");
+    LIDIFF_CHECK_ARG(worklist == nullptr || worklist_ints >= 2, "worklist needs room for its count and one entry");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
-    if (vec) segment_sum_rows_kernel<true><<<(unsigned)ceil_div(m * (c / 4), kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst);
-    else segment_sum_rows_kernel<false><<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst);
+    const int64_t cap = worklist ? worklist_ints - 1 : 0;
+    if (worklist) LIDIFF_CHECK_HIP(hipMemsetAsync(worklist, 0, sizeof(int32_t), st));
+    if (vec) segment_sum_rows_kernel<true><<<(unsigned)ceil_div(m * (c / 4), kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst, worklist, cap);
+    else segment_sum_rows_kernel<false><<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst, worklist, cap);
+    if (worklist)
+        segment_sum_long_kernel<<<dim3((unsigned)min((int64_t)128, cap), (unsigned)ceil_div(c, 32)), 256, 0, st>>>(src, order, ptr, c, dst,
+                                                                                                                 worklist, cap);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

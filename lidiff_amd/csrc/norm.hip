@@ -75,9 +75,22 @@ __device__ __forceinline__ void bn_channel_sums(const double* __restrict__ part,
     }
 }
 
+// running estimates as nn.BatchNorm1d keeps them: r = (1 - momentum) r + momentum x, the variance unbiased (x count / (count - 1));
+// the two roundings of torch's mul_ / add_ pair
+__device__ __forceinline__ void bn_update_running(float* __restrict__ running_mean, float* __restrict__ running_var, int ch,
+                                                  float mean, float var, double count, float momentum) {
+#pragma clang fp contract(off)
+    if (running_mean != nullptr) running_mean[ch] = running_mean[ch] * (1.0f - momentum) + mean * momentum;
+    if (running_var != nullptr) {
+        const float unbias = (float)(count / (count - 1.0)) * momentum;
+        running_var[ch] = running_var[ch] * (1.0f - momentum) + var * unbias;
+    }
+}
+
 __global__ __launch_bounds__(kWave) void bn_finish_stats_kernel(const double* __restrict__ part, int nblk, int c, int64_t m,
                                                                  float eps, float* __restrict__ mean, float* __restrict__ var,
-                                                                 float* __restrict__ invstd) {
+                                                                 float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, float momentum) {
     const int ch = blockIdx.x;
     double s, s2;
     bn_channel_sums(part, nblk, ch, s, s2);
@@ -86,8 +99,9 @@ __global__ __launch_bounds__(kWave) void bn_finish_stats_kernel(const double* __
     double v = s2 / (double)m - mu * mu;
     if (v < 0) v = 0;
     mean[ch] = (float)mu;
-    var[ch] = (float)v;                                  // biased (the normaliser); the caller derives the unbiased running one
+    var[ch] = (float)v;                                  // biased (the normaliser); the running estimate takes the unbiased one
     invstd[ch] = (float)(1.0 / sqrt(v + (double)eps));
+    bn_update_running(running_mean, running_var, ch, (float)mu, (float)v, (double)m, momentum);
 }
 
 __global__ __launch_bounds__(kWave) void bn_finish_bwd_kernel(const double* __restrict__ part, int nblk, int c,
@@ -103,17 +117,19 @@ __global__ __launch_bounds__(kWave) void bn_finish_bwd_kernel(const double* __re
 // SyncBatchNorm (train.py:90): the per-channel raw sums leave the device-side reduction as fp64 [2][c] so that the host side can
 // all-reduce them over the process group (together with the row count) before anything is derived from them
 __global__ __launch_bounds__(kWave) void bn_finish_sums_kernel(const double* __restrict__ part, int nblk, int c,
-                                                                double* __restrict__ sums) {
+                                                                double* __restrict__ sums, double count) {
     const int ch = blockIdx.x;
     double s, s2;
     bn_channel_sums(part, nblk, ch, s, s2);
     if (threadIdx.x != 0) return;
     sums[ch] = s;
     sums[c + ch] = s2;
+    if (ch == 0 && count >= 0) sums[2 * c] = count;      // this rank's row count travels behind the sums (forward only)
 }
 
 __global__ void bn_stats_from_sums_kernel(const double* __restrict__ sums, int c, float eps, float* __restrict__ mean,
-                                          float* __restrict__ var, float* __restrict__ invstd) {
+                                          float* __restrict__ var, float* __restrict__ invstd, float* __restrict__ running_mean,
+                                          float* __restrict__ running_var, float momentum) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     const double m = sums[2 * c];                        // the (all-reduced) row count travels behind the sums
@@ -123,6 +139,7 @@ __global__ void bn_stats_from_sums_kernel(const double* __restrict__ sums, int c
     mean[ch] = (float)mu;
     var[ch] = (float)v;
     invstd[ch] = (float)(1.0 / sqrt(v + (double)eps));
+    bn_update_running(running_mean, running_var, ch, (float)mu, (float)v, m, momentum);
 }
 
 __global__ void bn_bwd_from_sums_kernel(const double* __restrict__ sums, int c, float* __restrict__ sum_dy,
@@ -207,7 +224,7 @@ extern "C" int64_t lidiff_bn_workspace_bytes(int32_t c) { return (int64_t)kBnMax
 static bool bn_shape_ok(int64_t m, int c) { return m >= 1 && c >= 4 && c % 4 == 0 && c <= 1024 && kBnBlock / (c / 4) >= 1; }
 
 extern "C" int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, float* mean, float* var, float* invstd,
-                               void* workspace, void* stream) {
+                               float* running_mean, float* running_var, float momentum, void* workspace, void* stream) {
     LIDIFF_CHECK_ARG(x && mean && var && invstd && workspace, "null pointer");
     LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
     LIDIFF_CHECK_ARG(((uintptr_t)x & 15) == 0, "x must be 16-byte aligned");
@@ -216,7 +233,8 @@ extern "C" int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, 
     const int nblk = bn_blocks(m, c, &per);
     const size_t lds = (size_t)bn_rows_per_block(c) * c * 2 * sizeof(double);
     bn_reduce_kernel<false, false><<<nblk, kBnBlock, lds, st>>>(x, nullptr, nullptr, nullptr, m, c, per, (double*)workspace);
-    bn_finish_stats_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, m, eps, mean, var, invstd);
+    bn_finish_stats_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, m, eps, mean, var, invstd, running_mean,
+                                                          running_var, momentum);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -231,16 +249,17 @@ extern "C" int lidiff_bn_sums(const float* x, int64_t m, int32_t c, double* sums
     const int nblk = bn_blocks(m, c, &per);
     const size_t lds = (size_t)bn_rows_per_block(c) * c * 2 * sizeof(double);
     bn_reduce_kernel<false, false><<<nblk, kBnBlock, lds, st>>>(x, nullptr, nullptr, nullptr, m, c, per, (double*)workspace);
-    bn_finish_sums_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, sums);
+    bn_finish_sums_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, sums, (double)m);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int lidiff_bn_stats_from_sums(const double* sums, int32_t c, float eps, float* mean, float* var, float* invstd,
-                                         void* stream) {
+                                         float* running_mean, float* running_var, float momentum, void* stream) {
     LIDIFF_CHECK_ARG(sums && mean && var && invstd, "null pointer");
     LIDIFF_CHECK_ARG(c >= 1, "need c >= 1");
-    bn_stats_from_sums_kernel<<<(unsigned)ceil_div(c, 256), 256, 0, (hipStream_t)stream>>>(sums, c, eps, mean, var, invstd);
+    bn_stats_from_sums_kernel<<<(unsigned)ceil_div(c, 256), 256, 0, (hipStream_t)stream>>>(sums, c, eps, mean, var, invstd, running_mean,
+                                                                                           running_var, momentum);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -255,7 +274,7 @@ extern "C" int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* 
     const size_t lds = (size_t)bn_rows_per_block(c) * c * 2 * sizeof(double);
     if (y_relu) bn_reduce_kernel<true, true><<<nblk, kBnBlock, lds, st>>>(x, dy, y_relu, mean, m, c, per, (double*)workspace);
     else bn_reduce_kernel<true, false><<<nblk, kBnBlock, lds, st>>>(x, dy, nullptr, mean, m, c, per, (double*)workspace);
-    bn_finish_sums_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, sums);
+    bn_finish_sums_kernel<<<(unsigned)c, kWave, 0, st>>>((const double*)workspace, nblk, c, sums, -1.0);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

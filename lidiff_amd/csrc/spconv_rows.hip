@@ -263,7 +263,10 @@ __global__ __launch_bounds__(256) void spconv_thin_kernel(const ConvParams p) {
     float* tile = o_s + wave * 64 * 33;
 #pragma unroll
     for (int c = 0; c < kThinCo; ++c) tile[lane * 33 + c] = acc[c];
-    // (a wave's accesses to its own LDS tile are in order: no barrier needed between its writes and its reads)
+    // the exchange is between lanes of ONE wave: the hardware executes a wave's LDS accesses in order, but the compiler may only
+    // be told so -- a wavefront-scope release fence plus a wave barrier pins the ds_writes in front of the ds_reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 64;
     for (int e = lane; e < 64 * kThinCo; e += 64) {                   // 64 consecutive floats of the wave's 64 x 32 tile per pass
         const int r = e >> 5, c = e & 31;

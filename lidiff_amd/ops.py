@@ -77,7 +77,7 @@ def map_stride(coords: torch.Tensor, s_out: int, status: torch.Tensor):
     return coarse[:m], parent, table
 
 
-PYRAMID_TRACE = None     # debugging: a list -> build_pyramid appends (label, host time) pairs (tools/debug/step_timeline.py)
+PYRAMID_TRACE = None     # debugging: a list -> build_pyramid appends (label, host time) pairs (tools/step_timeline.py)
 
 
 def _trace(label):
@@ -566,13 +566,17 @@ class SyncBatchNorm1d(torch.nn.BatchNorm1d):
         super().__init__(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats)
         self.process_group = process_group
 
+    # True: take the synchronised path (sums -> all-reduce -> statistics) even in a group of ONE rank -- what bench.py's train leg
+    # times on the 1-GPU box: every launch and collective of the multi-rank step, minus the wire
+    sync_single_rank = False
+
     def group(self):
         """The process group to share statistics over, or None when there is nobody to share with."""
         import torch.distributed as tdist
         if not (tdist.is_available() and tdist.is_initialized()):
             return None
         g = self.process_group if self.process_group is not None else tdist.group.WORLD
-        return g if tdist.get_world_size(g) > 1 else None
+        return g if (tdist.get_world_size(g) > 1 or self.sync_single_rank) else None
 
     def forward(self, x):
         g = self.group() if self.training else None
@@ -612,29 +616,32 @@ class _BatchNormTrain(torch.autograd.Function):
         stats = torch.empty((3, c), dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.load().lidiff_bn_workspace_bytes(c), dtype=torch.uint8, device=dev)
         count = None
+        rm = running_mean if running_mean is not None and running_mean.dtype == torch.float32 else None
+        rv = running_var if rm is not None else None
         if group is None:
-            call("lidiff_bn_stats", ptr(x), m, c, float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(ws), stream_ptr())
+            call("lidiff_bn_stats", ptr(x), m, c, float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(rm), ptr(rv),
+                 float(momentum), ptr(ws), stream_ptr())
         else:
             import torch.distributed as tdist
             sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-            call("lidiff_bn_sums", ptr(x), m, c, ptr(sums), ptr(ws), stream_ptr())
-            sums[2 * c] = float(m)
+            call("lidiff_bn_sums", ptr(x), m, c, ptr(sums), ptr(ws), stream_ptr())         # sums[2c] = m
             tdist.all_reduce(sums, op=tdist.ReduceOp.SUM, group=group)
-            call("lidiff_bn_stats_from_sums", ptr(sums), c, float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), stream_ptr())
+            call("lidiff_bn_stats_from_sums", ptr(sums), c, float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(rm), ptr(rv),
+                 float(momentum), stream_ptr())
             count = sums[2 * c:]                                 # [1] fp64, stays on the device
+        if rm is not None:       # updated inside the statistics launch, behind autograd's back: bump the version counters by hand
+            torch.autograd.graph.increment_version(running_mean)      # (they key the folded eval-mode scale / shift caches)
+            torch.autograd.graph.increment_version(running_var)
         y = torch.empty_like(x)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
         call("lidiff_bn_apply", ptr(x), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(b), ptr(residual), int(bool(relu)), ptr(y),
              stream_ptr())
-        if running_mean is not None:
+        if running_mean is not None and rm is None:              # running estimates of another dtype: torch's own arithmetic
             with torch.no_grad():
+                cnt = float(m) if count is None else count
                 running_mean.mul_(1.0 - momentum).add_(stats[0], alpha=momentum)
-                if count is None:
-                    running_var.mul_(1.0 - momentum).add_(stats[1], alpha=momentum * m / (m - 1))
-                else:
-                    unbias = (count / (count - 1.0)).float() * momentum
-                    running_var.mul_(1.0 - momentum).add_(stats[1] * unbias)
+                running_var.mul_(1.0 - momentum).add_(stats[1] * (cnt / (cnt - 1.0)) * momentum)
         ctx.save_for_backward(x, w, stats, y if relu else None, count)
         ctx.relu = bool(relu)
         ctx.has_affine = (weight is not None, bias is not None)
@@ -1005,7 +1012,10 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
     if DETERMINISTIC_SCATTER and n > 0:
         order, ptr_ = _scatter_csr(idx.contiguous(), m)
         dst = torch.empty((m, c), dtype=torch.float32, device=src.device)
-        call("lidiff_segment_sum_rows", ptr(src), ptr(order), ptr(ptr_), m, c, ptr(dst), stream_ptr())
+        # destinations with > 64 sources (the unconditional training branch: ~180 000 rows gathered from each of 2 part voxels)
+        # go through a worklist to a cooperative kernel instead of one thread walking the segment
+        work = torch.empty(n // 64 + 2, dtype=torch.int32, device=src.device)
+        call("lidiff_segment_sum_rows", ptr(src), ptr(order), ptr(ptr_), m, c, ptr(dst), ptr(work), work.numel(), stream_ptr())
         return dst
     dst = torch.zeros((m, c), dtype=torch.float32, device=src.device)
     call("lidiff_scatter_add_rows", ptr(src), ptr(idx.contiguous()), n, c, ptr(dst), stream_ptr())

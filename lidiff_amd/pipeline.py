@@ -149,7 +149,7 @@ class DiffCompletion(nn.Module):
                 # `also(field, ts)` (the part -> full match of one level: a brute-force search, five of them ~1.1 ms) needs
                 # coordinates only: each level's search is queued on a second side stream as soon as that level's map exists,
                 # NEXT TO the rest of the strided maps, the kernel maps, tail maps and up orders of this stream.  The chain behind
-                # x_t's points is what the network waits for once the condition encoders are through (tools/debug/chain_probe.py:
+                # x_t's points is what the network waits for once the condition encoders are through (measured in round 3:
                 # 2.45 ms in series on an idle GPU, of which the searches are 1.14).
                 mgr, ts = field.coordinate_manager, 1
                 while True:
@@ -278,18 +278,31 @@ class DiffCompletion(nn.Module):
         return post_scan[(post_scan[:, 2] < max_z) & (post_scan[:, 2] > min_z)]
 
     # pipeline:117-132
-    def complete_scan(self, scan, generator=None):
+    def complete_scan(self, scan, generator=None, timings: dict | None = None):
+        """timings: a dict that receives the seconds spent in preprocess (range filter + FPS), the denoising loop, and
+        post-filter + refinement (each ended by a device synchronisation; None = no extra synchronisation)."""
+        import time
+
+        def lap(key, t0):
+            if timings is not None:
+                torch.cuda.synchronize(self.device)
+                timings[key] = timings.get(key, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+        t0 = time.perf_counter()
         scan = self.preprocess_scan(scan)
+        t0 = lap("preprocess_s", t0)
         x_feats = scan + torch.randn(scan.shape, device=self.device, generator=generator, dtype=scan.dtype)
         x_full = self.points_to_tensor(x_feats)
         x_cond = self.points_to_tensor(scan)
         x_uncond = self.points_to_tensor(torch.zeros_like(scan))
         self.new_scheduler()
         completed_scan = self.completion_loop(scan, x_full, x_cond, x_uncond)
+        t0 = lap("denoise_s", t0)
         post_scan = self.postprocess_scan(completed_scan, scan)
         refine_in = self.points_to_tensor(torch.as_tensor(post_scan[None, :, :]))
         offset = self.refine_forward(refine_in).reshape(-1, 6, 3)
         refine_complete_scan = post_scan[:, None, :] + offset.cpu().numpy()
+        lap("refine_s", t0)
         return refine_complete_scan.reshape(-1, 3), post_scan
 
     # pipeline:134-138
@@ -358,9 +371,9 @@ class DiffCompletion(nn.Module):
             self._warm_state = state                 # packed weights / folded BatchNorm now exist, queued on the main stream
             return out
 
-    # tools/debug/step_timeline.py: a list here collects (step start, conditions encoded, x_t adopted, network done) events
+    # tools/step_timeline.py: a list here collects (step start, conditions encoded, x_t adopted, network done) events
     timeline = None
-    host_stamps = None          # tools/debug/step_timeline.py --host: (label, time.perf_counter()) of the host thread
+    host_stamps = None          # tools/step_timeline.py --host: (label, time.perf_counter()) of the host thread
 
     def _stamp(self, label):
         if self.host_stamps is not None:

@@ -431,7 +431,7 @@ def test_training_step_loss_and_gradients_vs_oracle(device, drop, precision):
     norm 4.9e-4).  The scene is sized so that the coarse levels hold a few hundred voxels: on a 600-point scene train-mode
     BatchNorm over the ~20 voxels of stride 16 amplifies last-bit differences (atomic voxel mean / slice / dW sums, as in
     ME's own GPU path) until two runs of the SAME device step differ by 2.6e-2 in a BatchNorm bias gradient
-    (tools/debug/dbg_train_parity.py) -- a property of the step, not of either implementation.
+    (measured in round 2) -- a property of the step, not of either implementation.
     (precision "bf16" is not pinned at this level: rounding to bf16 is discontinuous, a last-bit difference that crosses a
     rounding boundary becomes a 2^-9 one, and within ~3 layers the device and ANY emulation of it differ by the bf16 noise
     floor itself -- measured: device vs me.bf16_operands() emulation, cosine 0.92 on the first kernel's gradient, the same as

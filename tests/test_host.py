@@ -261,6 +261,12 @@ def test_bench_launches_its_own_ranks():
     js = json.loads(lines[0])
     assert js["n_gpus"] == 2 and js["rccl_ranks_seen"] == 2 and js["dry_run"] and js["shards"] == [[0], [1]]
     assert js["elapsed_s"] >= 0.02                                # the max over ranks (rank 1 sleeps 20 ms)
+    # the whole-scan form (configs[2] / [3]): bench.py --gpus N --pipeline --scans S shards N x S scans round-robin
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--pipeline", "--scans", "3", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    js = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert js["pipeline"] and js["n_gpus"] == 2 and js["shards"] == [[0, 2, 4], [1, 3, 5]]
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
                            capture_output=True, text=True, timeout=300)

@@ -49,11 +49,11 @@ def main():
         from lidiff_amd import _lib
         csrc = os.path.join(ROOT, "lidiff_amd", "csrc")
         lib = os.path.join(csrc, "liblidiff_amd_probe.so")
-        if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(csrc, f)) for f in
-                                                                 ("spconv.hip", "spconv_dense.hip", "spconv_bf16.hip", "coords.hip", "spconv.h")):
+        from lidiff_amd.csrc import build as _build
+        srcs = [os.path.join(csrc, f) for f in _build.SOURCES]
+        if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs + [os.path.join(csrc, "spconv.h")]):
             subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-DLIDIFF_CONV_PROBE",
-                            "-shared", os.path.join(csrc, "spconv.hip"), os.path.join(csrc, "spconv_dense.hip"), os.path.join(csrc, "spconv_rows.hip"),
-                            os.path.join(csrc, "spconv_bf16.hip"), os.path.join(csrc, "coords.hip"), os.path.join(csrc, "norm.hip"), "-o", lib], check=True)
+                            "-shared"] + srcs + ["-o", lib], check=True)
         _lib.LIB_PATH = lib
         _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))
     from lidiff_amd import ops

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where a denoising step's wall time goes on the MAIN stream (HIP events inside DiffCompletion.classfree_forward):
 condition encoders | wait for the side stream (x_t's maps and matches) | MinkUNetDiff | rest of the step.
-    python tools/debug/step_timeline.py [--steps 10]"""
+    python tools/step_timeline.py [--steps 10]"""
 import argparse
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 

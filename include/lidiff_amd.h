@@ -278,12 +278,13 @@ int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int
 /* The same sum without atomics: dst[o, :] = sum of src[order[q], :] over q in [ptr[o], ptr[o + 1]), in list order -- `order` the
  * sources sorted by destination row (stable: source order inside a destination), `ptr` [m + 1] the CSR over the m destination
  * rows.  Deterministic: the backward of SparseTensor.slice and of the conditioning gathers in training (models.py:180-217).
- * worklist (nullable; worklist_ints >= 2 int32, e.g. n_sources / 64 + 2): destinations with more than 64 sources -- the
- * unconditional branch of a training step, models.py:192-195, gathers ~180 000 rows from each of 2 part voxels -- are summed by
- * one workgroup per (destination, 32 channels) in a fixed lane order instead of by one thread walking the whole segment; without
- * it every segment takes the one-thread path. */
+ * workspace (nullable; lidiff_segment_sum_workspace_bytes(n_sources, c)): destinations with more than 64 sources -- the
+ * unconditional branch of a training step, models.py:192-195, gathers ~180 000 rows from each of 2 part voxels -- are summed in
+ * chunks of 1024 sources by one workgroup per (chunk, 32 channels), the chunk sums then in chunk order: a fixed order as well;
+ * without it every segment takes the one-thread path.  n_sources = rows of src / entries of order. */
+int64_t lidiff_segment_sum_workspace_bytes(int64_t n_sources, int32_t c);
 int lidiff_segment_sum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t m, int32_t c, float* dst,
-                            int32_t* worklist, int64_t worklist_ints, void* stream);
+                            int64_t n_sources, void* workspace, void* stream);
 int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
                             float* dst, void* stream);
 

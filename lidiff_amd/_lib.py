@@ -67,7 +67,8 @@ SIGNATURES = {
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
     "lidiff_scatter_add_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
-    "lidiff_segment_sum_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _i64, _p]),
+    "lidiff_segment_sum_workspace_bytes": (_i64, [_i64, _i32]),
+    "lidiff_segment_sum_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "lidiff_gather_mul_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     "lidiff_nn_match": (_i32, [_p, _i64, _p, _i64, _p, _p, _p]),
     "lidiff_nn_match_dev": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _p]),

@@ -669,25 +669,46 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int
 
 // dst[o] = sum of src[order[q]] for q in [ptr[o], ptr[o + 1]) -- the scatter-add over a destination-sorted source list: every
 // destination row adds its sources in list order (the stable sort keeps source order), no atomics: deterministic.
-// One thread per (destination, float4) walks its segment; a segment longer than kSegShort sources is NOT summed here: the thread
-// of its first float4 appends the destination to `worklist` (worklist[0] = count) and segment_sum_long_kernel sums it
-// cooperatively.  (The unconditional branch of a training step -- models.py:192-195, a part of all zeros -- puts ~180 000
-// sources on each of 2 destinations at every conditioning level: one thread per float4 would walk them one by one.)
+// One thread per (destination, float4) walks its segment.  A segment longer than kSegShort sources is NOT summed that way (the
+// unconditional branch of a training step -- models.py:192-195, a part of all zeros -- puts ~180 000 sources on each of 2
+// destinations at every conditioning level: 256 threads would walk them one by one): its first thread registers the destination
+// and reserves ceil(len / kSegChunk) chunks; segment_sum_chunk_kernel sums every chunk of kSegChunk sources with one workgroup per
+// (chunk, 32 channels) -- lane r adds sources r, r + 32, ... in order, the 32 lane sums are added in lane order -- and
+// segment_sum_combine_kernel adds a destination's chunk sums in chunk order.  The order in which destinations register decides
+// only WHERE partial sums are stored, never the order of a sum: deterministic.
 constexpr int kSegShort = 64;
+constexpr int kSegChunk = 1024;
+struct SegWork {                     // workspace layout (int32 words): [0] long segments, [1] chunks, then the two lists
+    int32_t* head; int32_t* longs; int32_t* chunks; float* part; int64_t cap_long, cap_chunks;
+};
+__host__ __device__ inline int64_t seg_cap_long(int64_t n) { return n / kSegShort + 1; }
+__host__ __device__ inline int64_t seg_cap_chunks(int64_t n) { return n / kSegChunk + seg_cap_long(n); }
+static SegWork seg_work(void* ws, int64_t n, int c) {
+    SegWork w;
+    w.cap_long = seg_cap_long(n); w.cap_chunks = seg_cap_chunks(n);
+    w.head = (int32_t*)ws;
+    w.longs = w.head + 4;                                   // (destination, first chunk, chunks) per long segment
+    w.chunks = w.longs + 3 * w.cap_long;                    // (long-segment slot, chunk index) per chunk
+    w.part = (float*)(((uintptr_t)(w.chunks + 2 * w.cap_chunks) + 15) & ~(uintptr_t)15);
+    return w;
+}
+
 template <bool VEC4>
 __global__ void segment_sum_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ order,
-                                        const int64_t* __restrict__ ptr, int64_t m, int c, float* __restrict__ dst,
-                                        int32_t* __restrict__ worklist, int64_t worklist_cap) {
+                                        const int64_t* __restrict__ ptr, int64_t m, int c, float* __restrict__ dst, SegWork w) {
     const int cw = VEC4 ? c / 4 : c;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m * cw) return;
     const int64_t o = e / cw;
     const int j = (int)(e % cw);
     const int64_t lo = ptr[o], hi = ptr[o + 1];
-    if (worklist != nullptr && hi - lo > kSegShort) {
+    if (w.head != nullptr && hi - lo > kSegShort) {
         if (j == 0) {
-            const int slot = atomicAdd(worklist, 1);         // (the order of the list does not enter any sum)
-            if (slot < worklist_cap) worklist[1 + slot] = (int32_t)o;
+            const int nch = (int)((hi - lo + kSegChunk - 1) / kSegChunk);
+            const int slot = atomicAdd(&w.head[0], 1);
+            const int base = atomicAdd(&w.head[1], nch);
+            w.longs[3 * slot] = (int32_t)o; w.longs[3 * slot + 1] = base; w.longs[3 * slot + 2] = nch;
+            for (int i = 0; i < nch; ++i) { w.chunks[2 * (base + i)] = slot; w.chunks[2 * (base + i) + 1] = i; }
         }
         return;
     }
@@ -705,20 +726,18 @@ __global__ void segment_sum_rows_kernel(const float* __restrict__ src, const int
     }
 }
 
-// The long segments: workgroup (x, g) takes the destinations worklist[1 + x], worklist[1 + x + gridDim.x], ... and of each the
-// channels [32 g, 32 g + 32).  Its 256 threads are 32 source lanes x 8 channel quads (128 contiguous bytes per source row):
-// lane r adds the sources lo + r, lo + r + 32, ... in order, the 32 partials are then added in lane order -- fixed order:
-// deterministic (and independent of the order in which the worklist was filled).
-__global__ __launch_bounds__(256) void segment_sum_long_kernel(const float* __restrict__ src, const int64_t* __restrict__ order,
-                                                               const int64_t* __restrict__ ptr, int c, float* __restrict__ dst,
-                                                               const int32_t* __restrict__ worklist, int64_t worklist_cap) {
+// workgroup (x, g): chunks x, x + gridDim.x, ... of the registered long segments, channels [32 g, 32 g + 32); 256 threads =
+// 32 source lanes x 8 channel quads (128 contiguous bytes per source row)
+__global__ __launch_bounds__(256) void segment_sum_chunk_kernel(const float* __restrict__ src, const int64_t* __restrict__ order,
+                                                                const int64_t* __restrict__ ptr, int c, SegWork w) {
     __shared__ float sm[32][33];
-    const int count = (int)min((int64_t)worklist[0], worklist_cap);
+    const int nchunks = w.head[1];
     const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
-    const int ch0 = 32 * blockIdx.y + 4 * q;                  // first of this thread's (up to) 4 channels
-    for (int i = blockIdx.x; i < count; i += gridDim.x) {
-        const int64_t o = worklist[1 + i];
-        const int64_t lo = ptr[o], hi = ptr[o + 1];
+    const int ch0 = 32 * blockIdx.y + 4 * q;
+    for (int i = blockIdx.x; i < nchunks; i += gridDim.x) {
+        const int slot = w.chunks[2 * i], ci = w.chunks[2 * i + 1];
+        const int64_t o = w.longs[3 * slot];
+        const int64_t lo = ptr[o] + (int64_t)ci * kSegChunk, hi = min(ptr[o + 1], lo + kSegChunk);
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         for (int64_t s = lo + r; s < hi; s += 32) {
             const float* row = src + order[s] * c;
@@ -732,9 +751,21 @@ __global__ __launch_bounds__(256) void segment_sum_long_kernel(const float* __re
         if (threadIdx.x < 32 && 32 * blockIdx.y + threadIdx.x < c) {
             float t = 0.f;
             for (int rr = 0; rr < 32; ++rr) t += sm[rr][threadIdx.x];
-            dst[o * c + 32 * blockIdx.y + threadIdx.x] = t;
+            w.part[(int64_t)i * c + 32 * blockIdx.y + threadIdx.x] = t;
         }
         __syncthreads();
+    }
+}
+
+// one thread per (long segment, channel): its chunk sums in chunk order
+__global__ void segment_sum_combine_kernel(int c, float* __restrict__ dst, SegWork w) {
+    const int nlong = w.head[0];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)nlong * c; e += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(e / c), ch = (int)(e % c);
+        const int base = w.longs[3 * slot + 1], nch = w.longs[3 * slot + 2];
+        float t = 0.f;
+        for (int i = 0; i < nch; ++i) t += w.part[(int64_t)(base + i) * c + ch];
+        dst[(int64_t)w.longs[3 * slot] * c + ch] = t;
     }
 }
 
@@ -1431,21 +1462,29 @@ int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows
     return 0;
 }
 
+int64_t lidiff_segment_sum_workspace_bytes(int64_t n_sources, int32_t c) {
+    return (4 + 3 * seg_cap_long(n_sources) + 2 * seg_cap_chunks(n_sources) + 8) * (int64_t)sizeof(int32_t)
+           + seg_cap_chunks(n_sources) * (int64_t)c * (int64_t)sizeof(float) + 16;
+}
+
 int lidiff_segment_sum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t m, int32_t c, float* dst,
-                            int32_t* worklist, int64_t worklist_ints, void* stream) {
-    LIDIFF_CHECK_ARG(c > 0 && m >= 0, "bad shape");
+                            int64_t n_sources, void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(c > 0 && m >= 0 && n_sources >= 0, "bad shape");
     if (m == 0) return 0;
     LIDIFF_CHECK_ARG(src && order && ptr && dst, "null pointer");
-    LIDIFF_CHECK_ARG(worklist == nullptr || worklist_ints >= 2, "worklist needs room for its count and one entry");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
-    const int64_t cap = worklist ? worklist_ints - 1 : 0;
-    if (worklist) LIDIFF_CHECK_HIP(hipMemsetAsync(worklist, 0, sizeof(int32_t), st));
-    if (vec) segment_sum_rows_kernel<true><<<(unsigned)ceil_div(m * (c / 4), kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst, worklist, cap);
-    else segment_sum_rows_kernel<false><<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst, worklist, cap);
-    if (worklist)
-        segment_sum_long_kernel<<<dim3((unsigned)min((int64_t)128, cap), (unsigned)ceil_div(c, 32)), 256, 0, st>>>(src, order, ptr, c, dst,
-                                                                                                                 worklist, cap);
+    SegWork w{};
+    if (workspace != nullptr) {
+        w = seg_work(workspace, n_sources, c);
+        LIDIFF_CHECK_HIP(hipMemsetAsync(w.head, 0, 4 * sizeof(int32_t), st));
+    }
+    if (vec) segment_sum_rows_kernel<true><<<(unsigned)ceil_div(m * (c / 4), kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst, w);
+    else segment_sum_rows_kernel<false><<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(src, order, ptr, m, c, dst, w);
+    if (workspace != nullptr) {
+        segment_sum_chunk_kernel<<<dim3((unsigned)min((int64_t)512, w.cap_chunks), (unsigned)ceil_div(c, 32)), 256, 0, st>>>(src, order, ptr, c, w);
+        segment_sum_combine_kernel<<<(unsigned)min((int64_t)256, ceil_div(w.cap_long * c, kBlock)), kBlock, 0, st>>>(c, dst, w);
+    }
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

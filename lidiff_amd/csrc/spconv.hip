@@ -99,6 +99,15 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         }
     };
     constexpr int kDummyRow = BM * BN * 4;
+    // The accumulator tile is addressed in 16-byte chunks (4 consecutive channels of one row -- what a lane holds of a block's
+    // MFMA result, see run_item) and a row's chunks are XOR-permuted by the row's low bits: the 16 lanes of a quarter wave flush
+    // 16 DIFFERENT rows at the same channel offset, and with the plain layout (row pitch = a multiple of all 64 banks) they would
+    // all hit the same four banks.  SWZ = the largest power of two dividing the chunks per row, at most 16.
+    constexpr int NCHR = BN / 4;
+    constexpr int SWZ = (NCHR % 16 == 0) ? 16 : (NCHR % 8 == 0) ? 8 : (NCHR % 4 == 0) ? 4 : (NCHR % 2 == 0) ? 2 : 1;
+    auto tile_addr = [&](int row_byte_off, int chunk) {       // byte address of `chunk` of the tile row at row_byte_off
+        return row_byte_off + 16 * (chunk ^ ((row_byte_off / (BN * 4)) & (SWZ - 1)));
+    };
 
     // XCD-aware tile mapping: the column tiles of one row tile share an XCD (their gathers hit the
     // same L2), consecutive row tiles round-robin over the 8 XCDs.
@@ -131,10 +140,13 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #endif
 
     // ---- pair lists: ordered compaction of nbr[k, row0 : row0+rows_here] per offset --------
-    for (int e = tid; e < (BM + 1) * BN / 4; e += NT)     // the tile and the dummy row behind it
-        reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = tid; r < rows_here; r += NT) orow[r] = p.row_order ? p.row_order[row0 + r] : (int32_t)(row0 + r);
+    auto zero_tile = [&]() {
+        for (int e = tid; e < (BM + 1) * BN / 4; e += NT)     // the tile and the dummy row behind it
+            reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = tid; r < rows_here; r += NT) orow[r] = p.row_order ? p.row_order[row0 + r] : (int32_t)(row0 + r);
+    };
     if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
+        zero_tile();
         for (int r = tid; r < BM; r += NT) {
             const int64_t gr = min(row0 + r, p.m_out - 1);
             in_list[r] = p.row_order ? p.row_order[gr] : (int32_t)gr;
@@ -146,9 +158,20 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         // every load of the block is in flight at once -- ONE global latency instead of one per offset.
         int32_t* raw = reinterpret_cast<int32_t*>(a_buf);
         static_assert(27 * BM * 4 <= 2 * AF * 4, "raw neighbour block must fit in the A images");
-        for (int e = tid; e < p.k_vol * BM; e += NT) {
-            const int k = e / BM, r = e % BM;
-            raw[e] = r < rows_here ? p.nbr[(int64_t)k * p.m_out + row0 + r] : -1;
+        // (all of a thread's loads are issued before the first is stored: the loop form left them to the compiler, which waited
+        // for each -- a chain of up to 14 global latencies at the head of every tile)
+        constexpr int NRAW = (27 * BM + NT - 1) / NT;
+        int rawv[NRAW];
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) {
+            const int e = tid + i * NT, k = e / BM, r = e % BM;
+            rawv[i] = (k < p.k_vol && r < rows_here) ? p.nbr[(int64_t)k * p.m_out + row0 + r] : -1;
+        }
+        zero_tile();                             // ... and the tile is zeroed while they are in flight
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) {
+            const int e = tid + i * NT;
+            if (e < p.k_vol * BM) raw[e] = rawv[i];
         }
         __syncthreads();
         for (int k = wave; k < p.k_vol; k += NW) {
@@ -281,7 +304,10 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #pragma unroll
             for (int j = 0; j < T; ++j) {                      // RPI rows x KS*4 B per wave-instruction; no branches,
                 const int t = wave + NW * j;                   // no per-stage VALU: the slab offset rides in soffset
-                if ((T * NW == NINST || t < NINST) && !PROBE(1)) {
+                // (an instruction whose RPI rows all lie behind the item's last pair is not issued: those image rows feed only
+                // accumulator rows that are flushed into the dummy row, and every vector-memory instruction costs the SIMD
+                // ~100 cycles of issue while fp32 MFMAs are queued -- wave-uniform test, scalar branch)
+                if ((T * NW == NINST || t < NINST) && RPI * t < n && !PROBE(1)) {
                     const int voff = rowoff[j];
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, cb4, 0, 0);
                 }
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
-                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][j - J0][e], wc[j][e], acc[b], 0, 0, 0);
+                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j][e], a[b][j - J0][e], acc[b], 0, 0, 0);
                 // Fragment reads run one 16-channel group ahead of the MFMAs: left to itself the scheduler issues
                 // the reads of group j+1 only after the last MFMA of group j, and the MFMA pipe then idles for an LDS
                 // round trip four times per stage (both waves of a SIMD leave the barrier in lockstep, so neither
@@ -400,24 +426,20 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                 //    output instead of 27 short ones: 10x the rounding error against the float64 oracle (5.1e-5 vs 4.7e-6);
                 //  * list words, addresses and tile reads issued in FRONT of the last slab's MFMAs (they do not depend on the
                 //    results): 252 VGPRs, 4-7 % SLOWER (98 -> 94 TFLOP/s on 256 -> 256, 84 -> 78 on 128 -> 128).
-                const OutT* ol = out_list + item.k * BM + item.start + 4 * lq;
-                const int colb = (16 * wn + li) * 4;
+                // The MFMAs run with the operands SWAPPED (W fragment as A, the gathered rows as B): the transposed product
+                // leaves in each lane four CONSECUTIVE channels (16 wn + 4 lq .. + 3) of ONE pair row (16 b + li) -- one 16-byte
+                // read-modify-write of the tile per block instead of four 4-byte ones to four different rows, one list word per
+                // block instead of four (round 4; the sums and their order are the same: bit-identical results).
+                const OutT* ol = out_list + item.k * BM + item.start + li;
                 char* accb = reinterpret_cast<char*>(acc_lds);
-                int addr[NB][4];
+                int addr[NB];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int4 o = out4(ol + 16 * (wm + WM * b));
-                    addr[b][0] = o.x + colb; addr[b][1] = o.y + colb; addr[b][2] = o.z + colb; addr[b][3] = o.w + colb;
-                }
-                float old[NB][4];
+                for (int b = 0; b < NB; ++b) addr[b] = tile_addr((int)ol[16 * (wm + WM * b)], 4 * wn + lq);
+                f32x4 old[NB];
 #pragma unroll
-                for (int b = 0; b < NB; ++b)
+                for (int b = 0; b < NB; ++b) old[b] = *reinterpret_cast<const f32x4*>(accb + addr[b]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) old[b][r] = *reinterpret_cast<const float*>(accb + addr[b][r]);
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(accb + addr[b][r]) = old[b][r] + acc[b][r];
+                for (int b = 0; b < NB; ++b) *reinterpret_cast<f32x4*>(accb + addr[b]) = old[b] + acc[b];
             }
         }
 #ifdef LIDIFF_CONV_PROBE
@@ -505,59 +527,75 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                         for (int e = 0; e < 4; ++e)
 #pragma unroll
                             for (int b = 0; b < RBW; ++b)
-                                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][j][e], wcs[b / BLQ][j][e], acc[b], 0, 0, 0);
+                                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcs[b / BLQ][j][e], a[b][j][e], acc[b], 0, 0, 0);
                 };
                 auto stage_end = [&]() {
+#ifdef LIDIFF_CONV_PROBE
+                    STAMP(tb0);
                     __syncthreads();
+                    t_barrier += __builtin_readcyclecounter() - tb0;
+#else
+                    __syncthreads();
+#endif
 #pragma unroll
                     for (int q = 0; q < NSW; ++q)
 #pragma unroll
                         for (int h = 0; h < NJ; ++h) wcs[q][h] = wns[q][h];
                     img ^= IMG;
                 };
+#ifdef LIDIFF_CONV_PROBE
+                long long tp = __builtin_readcyclecounter();
+#endif
                 for (int sl = 0; sl + 1 < nslab; ++sl) {
                     issue_packed(img ^ IMG, dc, sl + 1, wns);
+                    PHASE(t_issue, tp);
                     mma();
+                    PHASE(t_mma, tp);
                     stage_end();
+#ifdef LIDIFF_CONV_PROBE
+                    tp = __builtin_readcyclecounter();
+#endif
                 }
                 if (pack + 1 < npack) {
                     load_pack(pack + 1, dn);
                     issue_packed(img ^ IMG, dn, 0, wns);
                 }
+                PHASE(t_issue, tp);
                 mma();
+                PHASE(t_mma, tp);
+                STAMP(tf0);
                 // flush: every block through its own segment's pair list.  Unlike a single-offset stage, the
                 // segments of a pack can hit the SAME output row (one row, several offsets), so the adds are
                 // ordered: the wm groups take turns (barrier in between), and inside a wave the segments go one
                 // after the other (LDS executes a wave's accesses in order).  Fixed order => deterministic.
+                // (Round 4 tried ordering by OFFSET instead -- the segments of one offset touch every output row at most once and
+                // can be flushed by all waves at once, runs of equal offsets separated by barriers: 3-4 runs per pack of 8
+                // segments, and each needs a workgroup barrier: 388 vs 338 us on 64 -> 64 at stride 4; not kept.)
                 for (int round = 0; round < WM; ++round) {
                     if (wm == round) {
+                        char* accb = reinterpret_cast<char*>(acc_lds);
 #pragma unroll
                         for (int q = 0; q < NSW; ++q) {
                             if (dc.n[q] == 0) continue;          // no segment here: nothing to add
-                            int addr[BLQ][4];
-                            char* accb = reinterpret_cast<char*>(acc_lds);
-                            const int colb = (16 * wn + li) * 4;
+                            int addr[BLQ];
 #pragma unroll
                             for (int g = 0; g < BLQ; ++g) {
                                 const int gb = wm + WM * (q * BLQ + g);
-                                const int4 o = out4(out_list + dc.k[q] * BM + dc.start[q] + 16 * (gb % BPS) + 4 * lq);
-                                addr[g][0] = o.x + colb; addr[g][1] = o.y + colb; addr[g][2] = o.z + colb; addr[g][3] = o.w + colb;
+                                addr[g] = tile_addr((int)out_list[dc.k[q] * BM + dc.start[q] + 16 * (gb % BPS) + li], 4 * wn + lq);
                             }
-                            float old[BLQ][4];
+                            f32x4 old[BLQ];
 #pragma unroll
-                            for (int g = 0; g < BLQ; ++g)
+                            for (int g = 0; g < BLQ; ++g) old[g] = *reinterpret_cast<const f32x4*>(accb + addr[g]);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) old[g][r] = *reinterpret_cast<const float*>(accb + addr[g][r]);
-#pragma unroll
-                            for (int g = 0; g < BLQ; ++g)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    *reinterpret_cast<float*>(accb + addr[g][r]) = old[g][r] + acc[q * BLQ + g][r];
+                            for (int g = 0; g < BLQ; ++g) *reinterpret_cast<f32x4*>(accb + addr[g]) = old[g] + acc[q * BLQ + g];
                             asm volatile("" ::: "memory");       // keep the segments' read-modify-writes in order
                         }
                     }
                     if (WM > 1) __syncthreads();
                 }
+#ifdef LIDIFF_CONV_PROBE
+                t_flush += __builtin_readcyclecounter() - tf0;
+#endif
                 stage_end();
                 dc = dn;
             }
@@ -598,7 +636,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     for (int e = tid; e < rows_here * (BN / 4); e += NT) {
         const int r = e / (BN / 4), cq = e % (BN / 4);
         const int col = n0 + 4 * cq;
-        float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + cq];
+        float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + (cq ^ (r & (SWZ - 1)))];
         if (p.tail) {                              // contributions computed elsewhere (the non-centre offsets), fixed order
             const int orw = orow[r];
             for (int q = p.tail_ptr[orw], qe = p.tail_ptr[orw + 1]; q < qe; ++q) {
@@ -629,7 +667,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
         STAMP(t_end);
         long long* d = p.timeline + ((int64_t)blockIdx.x * 2 + (wave != 0)) * 10;
         d[0] = t_loop - t_start; d[1] = t_epi - t_loop; d[2] = t_end - t_epi; d[3] = t_barrier; d[4] = t_flush;
-        d[5] = nwork; d[6] = nslab; d[7] = __builtin_amdgcn_s_memrealtime() - rt_start; d[8] = t_issue; d[9] = t_mma;
+        d[5] = packed ? (nwork + SEG - 1) / SEG : nwork; d[6] = nslab; d[7] = __builtin_amdgcn_s_memrealtime() - rt_start; d[8] = t_issue; d[9] = t_mma;
     }
 #endif
 }

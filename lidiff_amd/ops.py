@@ -1013,9 +1013,9 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
         order, ptr_ = _scatter_csr(idx.contiguous(), m)
         dst = torch.empty((m, c), dtype=torch.float32, device=src.device)
         # destinations with > 64 sources (the unconditional training branch: ~180 000 rows gathered from each of 2 part voxels)
-        # go through a worklist to a cooperative kernel instead of one thread walking the segment
-        work = torch.empty(n // 64 + 2, dtype=torch.int32, device=src.device)
-        call("lidiff_segment_sum_rows", ptr(src), ptr(order), ptr(ptr_), m, c, ptr(dst), ptr(work), work.numel(), stream_ptr())
+        # are summed in chunks by whole workgroups instead of by one thread walking the segment
+        work = torch.empty(_lib.load().lidiff_segment_sum_workspace_bytes(n, c), dtype=torch.uint8, device=src.device)
+        call("lidiff_segment_sum_rows", ptr(src), ptr(order), ptr(ptr_), m, c, ptr(dst), n, ptr(work), stream_ptr())
         return dst
     dst = torch.zeros((m, c), dtype=torch.float32, device=src.device)
     call("lidiff_scatter_add_rows", ptr(src), ptr(idx.contiguous()), n, c, ptr(dst), stream_ptr())

@@ -1,14 +1,20 @@
-mkdir -p gpurun_out/r4f
-LIDIFF_PARITY_LOG=gpurun_out/r4f/parity.jsonl timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_network.py -m gpu -x -q -k "scatter or batch_norm or sync or training or two_rank or bit_reproducible" > gpurun_out/r4f/pytest.log 2>&1; tail -3 gpurun_out/r4f/pytest.log
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt --no-kernel-events --no-coords-roofline --no-closed-loop > gpurun_out/r4f/bench_train.json 2> gpurun_out/r4f/bench.err; wc -l gpurun_out/r4f/bench_train.json
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r4f/bench_train.json').readline())
-for k in ('f32','bf16','bf16_syncbn'):
-    print(k, {a:(round(b,2) if isinstance(b,float) else b) for a,b in d['train'][k].items()})
-PY
-for c in "2,64,64,k3,-1,0" "2,128,128,k3,-1,0" "3,128,128,k3,-1,0" "3,256,256,k3,-1,0" "2,32,64,k3,-1,0"; do
-  python tools/conv_probe.py --replicas 2 --timeline --cases "$c" >> gpurun_out/r4f/timeline.txt 2>&1
+# one GPU session of the round (edited per call; results under gpurun_out/<tag>)
+T=${1:-r4j}
+mkdir -p gpurun_out/$T
+LIDIFF_PARITY_LOG=gpurun_out/$T/parity.jsonl timeout 1500 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "spconv" > gpurun_out/$T/pytest.log 2>&1; tail -3 gpurun_out/$T/pytest.log
+for c in "2,64,64,k3,-1,0" "2,128,128,k3,0,0" "2,32,64,k3,-1,0" "3,256,256,k3,-1,0"; do
+  python tools/conv_probe.py --replicas 2 --timeline --cases "$c" >> gpurun_out/$T/timeline.txt 2>&1
 done
-cat gpurun_out/r4f/timeline.txt | grep -v amdgpu.ids
-bash tools/pmc_mfma.sh > gpurun_out/r4f/pmc.log 2>&1; tail -30 gpurun_out/r4f/pmc.log
+grep -v amdgpu.ids gpurun_out/$T/timeline.txt | grep "TFLOP\|wave "
+B="--steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-train --no-closed-loop --no-coords-roofline"
+python bench.py $B > gpurun_out/$T/bench_prio0.json 2> gpurun_out/$T/bench.err
+LIDIFF_MAIN_HIGH_PRIORITY=1 python bench.py $B > gpurun_out/$T/bench_prio1.json 2>> gpurun_out/$T/bench.err
+python bench.py $B --no-kernel-events > gpurun_out/$T/bench_prio0_noev.json 2>> gpurun_out/$T/bench.err
+LIDIFF_MAIN_HIGH_PRIORITY=1 python bench.py $B --no-kernel-events > gpurun_out/$T/bench_prio1_noev.json 2>> gpurun_out/$T/bench.err
+python - <<PY
+import json
+for n in ("prio0","prio1","prio0_noev","prio1_noev"):
+    d=json.loads(open("gpurun_out/$T/bench_%s.json"%n).readline())
+    r=d.get("roofline",{})
+    print(n, round(d["ms_per_step"],3), r.get("frac"), (r.get("serial") or {}).get("frac"))
+PY

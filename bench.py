@@ -642,6 +642,15 @@ def main():
         # layers, the stems and the narrow row-kernel launches are HBM-bound; each class against ITS peak
         narrow_variants = ("bn96", "bn64", "bn32", "bn16", "rows", "thin")
         split = ops.launches_by_bound(vprof or prof, PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9), narrow_variants)
+        tiny = split.pop("tiny")
+        if tiny["launches"]:
+            out["roofline_narrow_tiny"] = {
+                "kernel": "launches with fewer than 32768 output rows (replicas included): the condition encoders (18000-point partial scan, "
+                          "5800 voxels at stride 16) and the one-voxel unconditional branch -- at most one 128-row tile per compute unit",
+                "bound": "launch latency (no roofline applies: the grid cannot fill the chip); queued on the side stream one step ahead",
+                "ms_per_step": tiny["ms"] / args.steps, "launches_per_step": tiny["launches"] / args.steps,
+                "avg_us": 1e3 * tiny["ms"] / tiny["launches"],
+                "algorithmic_gflop_per_step": tiny["flops"] / args.steps / 1e9, "algorithmic_mbytes_per_step": tiny["bytes"] / args.steps / 1e6}
         for bound, d in split.items():
             if not d["launches"]:
                 continue
@@ -656,10 +665,10 @@ def main():
                                "ms_per_step": round(r["ms"] / args.steps, 4), "achieved": round(a_, 2), "frac": round(a_ / peak, 4),
                                "flop_per_byte": round(r["flops"] / r["bytes"], 1)})
             out["roofline_narrow_" + bound] = {
-                "kernel": ("launches outside the 128-column tile kernel with arithmetic intensity >= 19.7 FLOP/B (bn64 / bn96 kernel_size-3 "
-                           "tiles at stride 2-4, wide spconv_rows_kernel launches)" if mfma else
-                           "launches outside the 128-column tile kernel with arithmetic intensity < 19.7 FLOP/B (32-channel layers, stems, "
-                           "low-density stride-1/2 tail passes, narrow spconv_rows_kernel launches)"),
+                "kernel": ("launches outside the 128-column tile kernel with arithmetic intensity >= 19.7 FLOP/B and >= 32768 output rows (bn64 / "
+                           "bn96 kernel_size-3 tiles at stride 2-4, wide spconv_rows_kernel launches)" if mfma else
+                           "launches outside the 128-column tile kernel with arithmetic intensity < 19.7 FLOP/B and >= 32768 output rows "
+                           "(32-channel layers, stems, low-density stride-1/2 tail passes, narrow spconv_rows_kernel launches)"),
                 "bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s", "frac": ach / peak,
                 "ms_per_step": d["ms"] / args.steps, "launches_per_step": d["launches"] / args.steps,
                 "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,

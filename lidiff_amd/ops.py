@@ -342,13 +342,15 @@ class ConvProfiler:
         return out
 
 
-def launches_by_bound(prof: "ConvProfiler", ridge: float, variants=None):
+def launches_by_bound(prof: "ConvProfiler", ridge: float, variants=None, tiny_rows: int = 32768):
     """The timed launches of `variants` (None = all) split by what bounds them: arithmetic intensity = algorithmic flops /
     algorithmic bytes of the launch against the machine's ridge point (peak FLOP/s / peak B/s) -- "mfma" at or
-    above it, "hbm" below.  Per class: launches, ms, flops, bytes and the per-shape rows (variant, k, c_in, c_out) inside it."""
+    above it, "hbm" below; launches with fewer than `tiny_rows` output rows (replicas included: at most one 128-row tile per
+    compute unit -- the condition encoders' maps, the one-voxel unconditional branch) are "tiny": bound by launch latency, no
+    roofline applies.  Per class: launches, ms, flops, bytes and the per-shape rows (variant, k, c_in, c_out) inside it."""
     torch.cuda.synchronize()
     counts = {}
-    out = {b: {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "shapes": {}} for b in ("mfma", "hbm")}
+    out = {b: {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "shapes": {}} for b in ("mfma", "hbm", "tiny")}
     for variant, start, end, m_in, m_out, c_in, c_out, k, nbr, reps in prof.launches:
         if start is None or (variants is not None and variant not in variants):
             continue
@@ -361,7 +363,7 @@ def launches_by_bound(prof: "ConvProfiler", ridge: float, variants=None):
             p = counts[key]
         p, m_in, m_out = reps * p, reps * m_in, reps * m_out
         fl, by = 2.0 * p * c_in * c_out, 4.0 * (m_in * c_in + m_out * c_out) + 4.0 * k * c_in * c_out + 8.0 * p
-        d = out["mfma" if fl / by >= ridge else "hbm"]
+        d = out["tiny" if m_out < tiny_rows else "mfma" if fl / by >= ridge else "hbm"]
         ms = start.elapsed_time(end)
         d["launches"] += 1
         d["ms"] += ms

@@ -633,34 +633,58 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 
     STAMP(t_epi);
     // ---- epilogue: BN scale/shift, residual, ReLU; one coalesced float4 store per 4 channels --
-    for (int e = tid; e < rows_here * (BN / 4); e += NT) {
-        const int r = e / (BN / 4), cq = e % (BN / 4);
-        const int col = n0 + 4 * cq;
-        float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + (cq ^ (r & (SWZ - 1)))];
-        if (p.tail) {                              // contributions computed elsewhere (the non-centre offsets), fixed order
-            const int orw = orow[r];
-            for (int q = p.tail_ptr[orw], qe = p.tail_ptr[orw + 1]; q < qe; ++q) {
-                const float4 s = *reinterpret_cast<const float4*>(p.tail + (int64_t)p.tail_idx[q] * p.c_out + col);
-                v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+    // A thread keeps its channel quad over the whole loop when NT is a multiple of BN / 4 (every instantiation but the 3 x 2 /
+    // 6 x 1 wave grids of 96 / 48 columns): scale and shift are loaded once; the residual rows of a batch of EB elements are all
+    // requested before the first is used (the stores to `out` may alias the epilogue's inputs as far as the compiler knows, so
+    // the plain loop waited for one global latency per element).
+    {
+        constexpr int CQ = BN / 4;
+        constexpr bool FIXED_CQ = NT % CQ == 0;
+        constexpr int EB = 4;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FIXED_CQ) {
+            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n0 + 4 * (tid % CQ));
+            if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n0 + 4 * (tid % CQ));
+        }
+        const int total = rows_here * CQ;
+        for (int e0 = tid; e0 < total; e0 += EB * NT) {
+            float4 res[EB];
+            int64_t oo[EB];
+#pragma unroll
+            for (int i = 0; i < EB; ++i) {
+                const int e = e0 + i * NT;
+                const int r = min(e, total - 1) / CQ, cq = min(e, total - 1) % CQ;
+                oo[i] = (int64_t)orow[r] * p.c_out + n0 + 4 * cq;
+                res[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.residual && e < total) res[i] = *reinterpret_cast<const float4*>(p.residual + oo[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < EB; ++i) {
+                const int e = e0 + i * NT;
+                if (e >= total) break;
+                const int r = e / CQ, cq = e % CQ;
+                const int col = n0 + 4 * cq;
+                float4 v = reinterpret_cast<const float4*>(acc_lds)[r * CQ + (cq ^ (r & (SWZ - 1)))];
+                if (p.tail) {                          // contributions computed elsewhere (the non-centre offsets), fixed order
+                    const int orw = orow[r];
+                    for (int q = p.tail_ptr[orw], qe = p.tail_ptr[orw + 1]; q < qe; ++q) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(p.tail + (int64_t)p.tail_idx[q] * p.c_out + col);
+                        v.x += s4.x; v.y += s4.y; v.z += s4.z; v.w += s4.w;
+                    }
+                }
+                if constexpr (!FIXED_CQ) {
+                    sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+                if (p.shift) { v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w; }
+                if (p.residual) { v.x += res[i].x; v.y += res[i].y; v.z += res[i].z; v.w += res[i].w; }
+                if (p.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(p.out + oo[i]) = v;
             }
         }
-        if (p.scale) {
-            const float4 s = *reinterpret_cast<const float4*>(p.scale + col);
-            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-        }
-        if (p.shift) {
-            const float4 s = *reinterpret_cast<const float4*>(p.shift + col);
-            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-        }
-        const int64_t o = (int64_t)orow[r] * p.c_out + col;
-        if (p.residual) {
-            const float4 s = *reinterpret_cast<const float4*>(p.residual + o);
-            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-        }
-        if (p.relu) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(p.out + o) = v;
     }
 #ifdef LIDIFF_CONV_PROBE
     if (p.timeline != nullptr && lane == 0 && (wave == 0 || wave == NW / 2)) {   // the two waves of SIMD 0

@@ -167,6 +167,20 @@ def pmc_profile():
     return (json.load(open(paths[0])), os.path.relpath(paths[0], ROOT)) if paths else (None, None)
 
 
+def mfma_busy_profile():
+    """MFMA-pipe occupancy per layer class from the newest committed PMC session (tools/pmc_mfma.sh ->
+    profiles/rNN_pmc_mfma.json): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- static, like `traffic`."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")), reverse=True)
+    if not paths:
+        return None
+    js = json.load(open(paths[0]))
+    return {"source": "static: " + os.path.relpath(paths[0], ROOT) + " (rocprofv3 PMC over tools/conv_probe.py, one process per layer, "
+                      "bench scan at sigma 1, CFG pair stacked; counters cannot be read inside the timed process)",
+            "layers": {k: {"mfma_busy": round(v["mfma_busy"], 3), "tflops": v["tflops"], "kernel": v["kernel"][:48]}
+                       for k, v in js["layers"].items()}}
+
+
 def traffic_from_profile(variants, per="launch"):
     """HBM-side bytes of the conv variants `variants` from the committed PMC passes: FETCH_SIZE x2 (gfx950 correction) +
     WRITE_SIZE, summed over their kernel instantiations -- per launch, or in total over the profiled command.  PMC counters
@@ -617,6 +631,7 @@ def main():
             "traffic_unit": "GB per launch (HBM-side, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": None if traffic is None else f"static: {traffic_src} (tools/pmc_bench.sh over this bench "
                                                             "command; counters cannot be read inside the timed process)",
+            "mfma_busy": mfma_busy_profile(),
             "step_frac": step_flops / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "step_conv_gflop": step_flops / 1e9,
             "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,

@@ -49,5 +49,17 @@ with open("$OUT/summary.txt", "w") as f:
             f.write(f"    {name}: mfma_busy {100 * busy:.1f} %  valu/mfma {(c['SQ_INSTS_VALU'] - c['SQ_INSTS_MFMA']) / max(1, c['SQ_INSTS_MFMA']):.2f}  "
                     f"wait {100 * c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.0f} %  lds_conf {100 * c['SQ_LDS_BANK_CONFLICT'] / max(1, c['SQ_LDS_IDX_ACTIVE']):.1f} %  "
                     f"insts: mfma {c['SQ_INSTS_MFMA']} valu {c['SQ_INSTS_VALU']} lds {c['SQ_INSTS_LDS']} vmem_rd {c['SQ_INSTS_VMEM_RD']} salu {c['SQ_INSTS_SALU']}  waves {c['SQ_WAVES']}  gui_active {c['GRBM_GUI_ACTIVE']}\n")
+import json
+js = {"command": "tools/pmc_mfma.sh: rocprofv3 --kernel-trace --pmc (separate passes) over tools/conv_probe.py, one process per layer, "
+                 "bench scan sigma 1, replicas 2", "layers": {}}
+for tag, d in rows.items():
+    for name, c in d.get("kernels", {}).items():
+        if "SQ_INSTS_MFMA" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            js["layers"][tag] = {"kernel": name, "us": d.get("us"), "tflops": d.get("tflops"),
+                                 "mfma_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024),
+                                 "valu_per_mfma": (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / max(1, c["SQ_INSTS_MFMA"]),
+                                 "wait_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                                 "lds_bank_conflict_share": c["SQ_LDS_BANK_CONFLICT"] / max(1, c["SQ_LDS_IDX_ACTIVE"])}
+json.dump(js, open("$OUT/summary.json", "w"), indent=1)
 print(open("$OUT/summary.txt").read())
 PY

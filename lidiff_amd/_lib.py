@@ -108,6 +108,10 @@ def load() -> C.CDLL:
 # stream runs the convolutions that are already queued.  Every launch through call() on a stream that is NOT a build stream first
 # joins the build streams that have queued work since the last join (one event each) -- so a consumer can never run ahead of the
 # map it reads, whichever operator it goes through.
+# CONTRACT: a tensor built under CoordinateManager.building() may be consumed (a) through call() -- every entry point joins first --
+# or (b) by a torch op only behind a host read of the same build stream (the map sizes: build_pyramid's one read) or behind
+# DiffCompletion._adopt / an explicit event; nothing else touches them (TailMap.fill, up_order and the voxel mean all run inside
+# building() themselves and hand their results on through call()).
 _BUILD_STREAMS: set = set()
 _PENDING: set = set()
 

@@ -163,6 +163,9 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
             call("lidiff_tail_map_dev", ptr(nbr), 27, n, cptr(lv), 13, ptr(off), ptr(row_ptr), 0, None, None, ptr(ws), st2)
             counts[strides + 1 + lv:strides + 2 + lv].copy_(off[27:28])
             tails.append((nbr, ws, off, row_ptr))
+            if second_stream is not None:                   # allocated under second_stream, consumed on the current one
+                for t_ in (nbr, ws, off, row_ptr):
+                    t_.record_stream(cur)
         if second_stream is not None:
             joined = torch.cuda.Event()
             joined.record(second_stream)

@@ -1,11 +1,8 @@
 # one GPU session of the round (edited per call; results under gpurun_out/<tag>)
-T=${1:-r4n}
-O=$PWD/gpurun_out/$T; mkdir -p $O; R=$PWD
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train --no-closed-loop > $O/bench_prof.json 2> $O/bench_prof.err
-cd $R
-DB=$(find $O/prof -name "*results.db" | head -1)
-python tools/rocpd_main_queue.py $DB --last-ms 400 > $O/main_queue.txt 2>&1
-python tools/rocpd_gaps.py $DB --last-ms 400 --top 12 > $O/gaps.txt 2>&1
-rm -rf $O/prof
-cat $O/main_queue.txt; head -3 $O/gaps.txt; cut -c1-200 $O/bench_prof.json
+T=${1:-r4o}
+mkdir -p gpurun_out/$T
+for s in 1.0 0.5 0.2; do
+for f in 0 32; do
+  python tools/conv_probe.py --sigma $s --replicas 2 --iters 20 --cases "2,128,128,k3,0,$f;2,192,128,k3,0,$f;3,128,128,k3,0,$f;3,64,128,k3,0,$f;3,256,256,k3,0,$f" 2>&1 | grep TFLOP >> gpurun_out/$T/tall.txt
+done; done
+cat gpurun_out/$T/tall.txt | cut -c1-200

@@ -90,6 +90,10 @@ def _trace(label):
         PYRAMID_TRACE.append((label, time.perf_counter(), ev))
 
 
+PINNED_READ = os.environ.get("LIDIFF_PINNED_READ", "1") != "0"
+_PINNED: dict = {}
+
+
 class Pyramid:
     """What build_pyramid() hands over: per level the coordinate rows, hash table and (levels >= 1) the parent array of the
     finer level; for the first `tail_levels` levels also the kernel_size-3 self map and the phase-1 state of its tail map."""
@@ -181,7 +185,20 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     if second_stream is not None:
         cur.wait_event(joined)
     _trace("tails queued")
-    host = counts.tolist()                                     # THE host read of this pyramid
+    # THE host read of this pyramid: into a pinned buffer, the host spinning on an event query (torch's tolist() goes through a
+    # pageable staging copy and a blocking synchronise: ~0.1 ms later at the next launch; LIDIFF_PINNED_READ=0 keeps that form)
+    if PINNED_READ:
+        hb = _PINNED.get(counts.numel())
+        if hb is None:
+            hb = _PINNED[counts.numel()] = torch.empty(counts.numel(), dtype=torch.int32, pin_memory=True)
+        hb.copy_(counts, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        while not done.query():
+            pass
+        host = hb.tolist()
+    else:
+        host = counts.tolist()
     _trace("sizes read")
     out = Pyramid()
     out.coords = [rows[lv][:host[lv]] for lv in range(strides + 1)]

@@ -65,6 +65,19 @@ def _worker(rank, world, port, result_q):
             opt = torch.optim.SGD(self.parameters(), lr=1e-3)
             return opt, {"scheduler": torch.optim.lr_scheduler.ExponentialLR(opt, 0.5), "interval": "epoch", "frequency": 5}
 
+    # SyncBatchNorm wiring (train.py:90) on the host side: the conversion gives every MinkowskiBatchNorm an ops.SyncBatchNorm1d
+    # child whose process group is the 2-rank world (the statistics themselves run on the HIP kernels: GPU tests); eval mode is
+    # the local nn.BatchNorm1d arithmetic on any device
+    import lidiff_amd.MinkowskiEngine as ME
+    from lidiff_amd import ops
+    holder = torch.nn.Sequential(ME.MinkowskiBatchNorm(8))
+    ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(holder)
+    bn = holder[0].bn
+    out["sync_bn"] = [type(bn) is ops.SyncBatchNorm1d, bn.group() is not None and tdist.get_world_size(bn.group()) == 2]
+    bn.eval()
+    xs = torch.randn(5, 8)
+    out["sync_bn_eval_equal"] = bool(torch.equal(bn(xs), torch.nn.functional.batch_norm(xs, bn.running_mean, bn.running_var, bn.weight,
+                                                                                         bn.bias, False, 0.1, bn.eps)))
     toy = Toy()
     data = [{"id": i, "x": torch.full((2, 3), float(i))} for i in range(8)]
     losses = train_loop(toy, data, steps=40, sync_bn=False, log_every=16)     # 8 batches / 2 ranks = 4 steps per epoch
@@ -94,6 +107,7 @@ def test_two_rank_gloo():
         assert results[r]["max"] == 2.0 and results[r]["sum"] == 30.0
         assert results[r]["w0"] == results[0]["w0"]
         assert results[r]["caches_dropped"] and results[r]["version_bumped"]
+        assert results[r]["sync_bn"] == [True, True] and results[r]["sync_bn_eval_equal"]
         assert results[r]["seen"] == [(s * 2 + r) % 8 for s in range(6)] and results[r]["n_losses"] == 40
         assert results[r]["toy_w"] == results[0]["toy_w"]                    # averaged gradients: ranks stay in step
         for got, want, got16 in zip(results[r]["avg"], results[r]["want"], results[r]["avg_bf16"]):

@@ -496,6 +496,54 @@ def test_nn_match(device):
             assert np.array_equal(got, me.argmin_match(fc, pc)), (n_full, n_bound, pc.shape)
 
 
+def test_step_boundary_kernels_edge_cases(device):
+    """lidiff_points_to_field / lidiff_cfg_dpm_step (step.hip) and lidiff_nn_match_dev on the inputs the happy path never sees: no
+    points, ties of the rounding (x * 20 exactly half-way: round half to EVEN, as torch.round does), negative coordinates, a
+    second-order update whose previous prediction is given, no noise term, and a match over a map with zero valid rows."""
+    from lidiff_amd import ops
+    from lidiff_amd.schedulers import DPMSolverMultistepScheduler
+    f, c = ops.points_to_field(torch.zeros((1, 0, 3), dtype=torch.float64, device=device), 0.05)
+    assert f.shape == (0, 3) and c.shape == (0, 4)
+    pts = torch.tensor([[[0.025, 0.075, -0.025], [-0.075, 0.125, 1e-9], [81.9175, -81.92, 0.0499999]]], dtype=torch.float64, device=device)
+    f, c = ops.points_to_field(pts, 0.05)
+    want = torch.round(pts[0].float() * 20.0).to(torch.int32)
+    assert torch.equal(c[:, 1:], want) and torch.equal(c[:, 0], torch.zeros(3, dtype=torch.int32, device=device))
+    assert c[0].tolist() == [0, 0, 2, 0] and c[1].tolist()[:3] == [0, -2, 2]          # half-way cases go to the even neighbour
+    s = DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_start=3.5e-5, beta_end=0.007, beta_schedule="linear",
+                                    algorithm_type="sde-dpmsolver++", solver_order=2)
+    s.set_timesteps(50)
+    s.to(device)
+    x_init = torch.zeros((1, 0, 3), dtype=torch.float64, device=device)
+    e = torch.zeros((1, 0, 3), device=device)
+    x0, f, c = ops.cfg_dpm_step(e, e, 6.0, torch.zeros((0, 3), device=device), x_init, s.step_plan(999), None, 0.05)
+    assert x0.shape == (1, 0, 3) and f.shape == (0, 3) and c.shape == (0, 4)
+    # one point, no noise term, first then second order: against the scheduler's own torch arithmetic
+    g = torch.Generator().manual_seed(1)
+    x_init = torch.randn(1, 7, 3, generator=g, dtype=torch.float64).to(device) * 10
+    x_t = (x_init[0] + torch.randn(7, 3, generator=g, dtype=torch.float64).to(device)).float()
+    s2 = DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_start=3.5e-5, beta_end=0.007, beta_schedule="linear",
+                                     algorithm_type="sde-dpmsolver++", solver_order=2)
+    s2.set_timesteps(50)
+    s2.to(device)
+    s.set_timesteps(50)
+    xa = xb = x_t
+    for t in s.host_timesteps[:3]:
+        ec, eu = (torch.randn(1, 7, 3, generator=g).to(device) for _ in range(2))
+        z = torch.zeros(1, 7, 3, dtype=torch.float64, device=device)
+        x0, fa, ca = ops.cfg_dpm_step(ec, eu, 6.0, xa, x_init, s.step_plan(t), z, 0.05)
+        s.commit(x0)
+        prev = s2.step(eu + 6.0 * (ec - eu), t, xb.reshape(1, -1, 3) - x_init, noise=z)["prev_sample"]
+        fb = (x_init + prev).float()[0]
+        assert torch.equal(fa, fb) and torch.equal(ca[:, 1:], torch.round(fb / 0.05).to(torch.int32)), t
+        xa, xb = fa, fb
+    # a map with zero valid rows (count 0 on the device): nothing is written, nothing faults
+    part = dev_i32(np.array([[0, 1, 2, 3], [0, 5, 5, 5]], np.int32), device)
+    buf = dev_i32(np.full((500, 4), 7, np.int32), device)
+    idx = ops.nn_match_dev(buf, torch.zeros(1, dtype=torch.int32, device=device), part)
+    torch.cuda.synchronize()
+    assert idx.shape == (500,)
+
+
 def test_fps_reproduces_the_committed_scan_from_the_range_filtered_input(device, fps_scan):
     """preprocess_scan's FPS (pipeline:97-99) on the range-filtered bundled scan (119 035 points)
     through the HIP kernel selects exactly the committed 18 000 points, in order; spot-checked against the FPS oracle."""

@@ -14,7 +14,7 @@ WARM=${PMC_WARMUP:-2}
 cd /tmp && export TMPDIR=/tmp
 for pass in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/$pass -o p -- \
-    python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train > $OUT/$pass.log 2>&1
+    python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-kernel-events --no-alt --no-coords-roofline --no-train --no-closed-loop > $OUT/$pass.log 2>&1
 done
 cd $R
 python - <<PY

@@ -99,10 +99,10 @@ extern "C" int lidiff_cfg_dpm_step(const float* eps_cond, const float* eps_uncon
                                    double c_m0, double c_d1, double inv_r0, double c_noise, float inv_resolution,
                                    int64_t n_points, int64_t n_per_batch, int32_t scale_batch_column, double* x0_out,
                                    float* feats_out, int32_t* coords_out, void* stream) {
-    LIDIFF_CHECK_ARG(eps_cond && eps_uncond && x_t && x_init && x0_out && feats_out && coords_out, "null pointer");
     LIDIFF_CHECK_ARG(n_points >= 0 && n_per_batch >= 1, "need n_points >= 0 and n_per_batch >= 1");
+    if (n_points == 0) return 0;                 // (an empty field: nothing to do, and its tensors have no storage to point at)
+    LIDIFF_CHECK_ARG(eps_cond && eps_uncond && x_t && x_init && x0_out && feats_out && coords_out, "null pointer");
     LIDIFF_CHECK_ARG(((uintptr_t)coords_out & 15) == 0, "coords_out must be 16-byte aligned");
-    if (n_points == 0) return 0;
     const StepCoeffs k{w, sigma_t, inv_resolution, inv_alpha_t, c_sample, c_m0, c_d1, inv_r0, c_noise};
     const unsigned grid = (unsigned)ceil_div(n_points, kStepBlock);
     hipStream_t st = (hipStream_t)stream;
@@ -119,10 +119,10 @@ extern "C" int lidiff_cfg_dpm_step(const float* eps_cond, const float* eps_uncon
 extern "C" int lidiff_points_to_field(const void* points, int32_t is_f64, float inv_resolution, int64_t n_points,
                                       int64_t n_per_batch, int32_t scale_batch_column, float* feats_out, int32_t* coords_out,
                                       void* stream) {
-    LIDIFF_CHECK_ARG(points && feats_out && coords_out, "null pointer");
     LIDIFF_CHECK_ARG(n_points >= 0 && n_per_batch >= 1, "need n_points >= 0 and n_per_batch >= 1");
-    LIDIFF_CHECK_ARG(((uintptr_t)coords_out & 15) == 0, "coords_out must be 16-byte aligned");
     if (n_points == 0) return 0;
+    LIDIFF_CHECK_ARG(points && feats_out && coords_out, "null pointer");
+    LIDIFF_CHECK_ARG(((uintptr_t)coords_out & 15) == 0, "coords_out must be 16-byte aligned");
     const unsigned grid = (unsigned)ceil_div(n_points, kStepBlock);
     hipStream_t st = (hipStream_t)stream;
     if (is_f64)

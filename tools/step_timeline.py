@@ -82,6 +82,11 @@ if __name__ == "__main__":
     between = np.array([tl[i][3].elapsed_time(tl[i + 1][0]) for i in range(len(tl) - 1)])
     print(f"wall {wall:.2f} ms per step; main stream: encoders {seg[:, 0].mean():.2f}  wait for x_t maps {seg[:, 1].mean():.2f}  "
           f"UNet {seg[:, 2].mean():.2f}  between steps (scheduler, next field) {between.mean():.2f} ms")
+    if len(seg) > 4:        # steady state: without the first three steps (cold encoders, first lazy pyramids)
+        s3, b3 = seg[3:], between[2:]
+        print(f"steady state (steps 3..): encoders {s3[:, 0].mean():.2f}  wait for x_t maps {s3[:, 1].mean():.2f}  UNet {s3[:, 2].mean():.2f}  "
+              f"between steps {b3.mean():.2f} ms  =>  UNet end -> next UNet start (mark to mark) "
+              f"{(b3.mean() + s3[:, 0].mean() + s3[:, 1].mean()):.2f} ms")
     for j, r in enumerate(seg):
         print(f"  step {j} (t={tvals[j]}): encoders {r[0]:.2f}  wait {r[1]:.2f}  UNet {r[2]:.2f}")
     # host thread: where its time goes between the stamps (ms, averaged over the steps after the first two)

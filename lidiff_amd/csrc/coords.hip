@@ -193,11 +193,19 @@ static int run_unique(const int32_t* coords, int64_t n, const int32_t* d_n, int 
 // |x| < 2^7, N < 2^18) shift = 37: every fp32 value above 2^-14 m is represented exactly, the sum is exact, and it is rounded
 // to fp32 ONCE -- for one or two points per voxel (x_t: ~1.0 per voxel) that is bit for bit the sequential fp32 sum.
 __global__ void mean_absmax_kernel(const float* __restrict__ feats, int64_t total, uint32_t* __restrict__ amax) {
+    // ONE atomic per workgroup (round 4: one per wave from 1 024 workgroups were 4 096 serialised atomics on one word -- 50 us on
+    // the critical path between two denoising steps for 2 MB of input)
+    __shared__ uint32_t wmax[kBlock / kWave];
     uint32_t m = 0;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
         m = max(m, __float_as_uint(feats[e]) & 0x7fffffffu);          // |x| as bits: monotonic for finite values
     for (int off = kWave / 2; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off));
-    if (lane_id() == 0 && m) atomicMax(amax, m);
+    if (lane_id() == 0) wmax[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x / kWave); ++w) m = max(m, wmax[w]);
+        if (m) atomicMax(amax, m);
+    }
 }
 
 // 2^shift: the largest power of two for which n_bits-many values below 2^(exponent of amax + 1) sum to less than 2^62
@@ -861,7 +869,13 @@ __global__ void coord_max_dev_kernel(const int32_t* __restrict__ coords, const i
         best = max(best, max(max(c.x, c.y), max(c.z, c.w)));
     }
     for (int off = kWave / 2; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
-    if (lane_id() == 0 && best != INT32_MIN) atomicMax(d_max, best);
+    __shared__ int wbest[kBlock / kWave];                 // one atomic per workgroup, not per wave
+    if (lane_id() == 0) wbest[threadIdx.x / kWave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x / kWave); ++w) best = max(best, wbest[w]);
+        if (best != INT32_MIN) atomicMax(d_max, best);
+    }
 }
 
 // Same arg-min through the part map's hash table: part voxels sit on a lattice of pitch `ps` (their tensor
@@ -1256,7 +1270,7 @@ int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, 
     while ((1ll << n_bits) <= n_rows) ++n_bits;                       // n_rows < 2^n_bits
     if (n_rows > 0) {
         const int64_t total = n_rows * c;
-        mean_absmax_kernel<<<(unsigned)(ceil_div(total, kBlock) < 1024 ? ceil_div(total, kBlock) : 1024), kBlock, 0, st>>>(feats, total, amax);
+        mean_absmax_kernel<<<(unsigned)(ceil_div(total, 4 * kBlock) < 256 ? ceil_div(total, 4 * kBlock) : 256), kBlock, 0, st>>>(feats, total, amax);
         mean_accum_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(feats, inverse, n_rows, c, n_bits, amax, acc, cnt);
     }
     mean_div_kernel<<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(acc, cnt, m * c, c, n_bits, amax, out, counts);
@@ -1504,7 +1518,7 @@ int lidiff_nn_match_dev(const int32_t* full, int64_t m_full_bound, const int32_t
     if (m_full_bound == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     LIDIFF_CHECK_HIP(hipMemsetAsync(d_max_coord, 0x80, sizeof(int32_t), st));       // 0x80808080: below every coordinate
-    coord_max_dev_kernel<<<(unsigned)min((int64_t)512, ceil_div(m_full_bound, kBlock)), kBlock, 0, st>>>(full, d_m_full, d_max_coord);
+    coord_max_dev_kernel<<<(unsigned)min((int64_t)128, ceil_div(m_full_bound, 4 * kBlock)), kBlock, 0, st>>>(full, d_m_full, d_max_coord);
     return nn_match_launch<false>(full, m_full_bound, part, m_part, d_max_coord, idx, st, d_m_full);
 }
 

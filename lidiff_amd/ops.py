@@ -556,6 +556,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     start = end = None
     if timed:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.join_pending()             # (the wait for maps still being built on a side stream is not the kernel's time)
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
          c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas), flags,
@@ -746,6 +747,7 @@ def spconv_fwd_pairs(in_a: torch.Tensor, w: torch.Tensor, pair_in: torch.Tensor,
     start = end = None
     if timed:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.join_pending()             # (the wait for maps still being built on a side stream is not the kernel's time)
         start.record()
     call("lidiff_spconv_fwd_pairs", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), k, ptr(pair_in), ptr(pair_out), ptr(offset_ptr),
          n, m_in, m_out, c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), stream_ptr())
@@ -868,6 +870,7 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
     start = end = None
     if timed:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.join_pending()             # (the wait for maps still being built on a side stream is not the kernel's time)
         start.record()
     call("lidiff_spconv_fwd_bf16", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), int(planes), ptr(nbr), k, m_in, m_out, c_out,
          ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), stream_ptr())

@@ -420,7 +420,7 @@ def spawn_ranks(args, argv):
     visible GPUs than ranks is refused here, with a clear message, before anything is launched."""
     import socket
     import subprocess
-    if not args.dry_run:
+    if not args.dry_run and os.environ.get("LIDIFF_BENCH_SHARE_GPU") != "1":
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this box "
@@ -496,7 +496,11 @@ def main():
         sys.stdout.flush()
         _STDOUT = os.fdopen(os.dup(1), "w")
         os.dup2(2, 1)
-    rank, world, local = ldist.init_from_env("gloo" if args.dry_run else "nccl")
+    # (LIDIFF_BENCH_BACKEND=gloo with LIDIFF_BENCH_SHARE_GPU=1: the N-rank code path rehearsed on a box with fewer GPUs than ranks --
+    # the ranks share device 0 and rendezvous over gloo; RCCL itself cannot place two ranks on one device.  Testing only.)
+    rank, world, local = ldist.init_from_env("gloo" if args.dry_run else os.environ.get("LIDIFF_BENCH_BACKEND", "nccl"))
+    if os.environ.get("LIDIFF_BENCH_SHARE_GPU") == "1" and not args.dry_run:
+        local = local % max(1, torch.cuda.device_count())
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
     if args.dry_run:

@@ -936,3 +936,25 @@ def test_two_rank_train_loop_rccl_syncbn(device):
     assert res[0][1] > 50 and res[0][1] == res[1][1]              # every BatchNorm became a SyncBatchNorm
     assert res[0][2:4] == res[1][2:4] and res[0][4] == res[1][4]  # weights and synced running statistics agree
     assert all(np.isfinite(res[r][0]).all() for r in (0, 1))
+
+
+def test_bench_n_rank_path_with_two_ranks_sharing_the_gpu(device):
+    """bench.py's N > 1 code path executed for real on the 1-GPU box: `python bench.py --gpus 2` (the form the driver's SCALE run
+    starts) with LIDIFF_BENCH_SHARE_GPU=1 / LIDIFF_BENCH_BACKEND=gloo -- both ranks on cuda:0, rendezvous over gloo (RCCL cannot
+    place two ranks on one device): launcher, rendezvous, the all-reduce that proves the ranks, barrier-bracketed timing with
+    the max over ranks, ONE JSON line on stdout (native libraries' banners routed to stderr), whole-job aggregate value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LIDIFF_BENCH_SHARE_GPU="1", LIDIFF_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["rccl_ranks_seen"] == 2 and js["steps"] == 3 and js["scaling"] == "weak"
+    assert js["value"] > 0 and abs(js["value"] - 2 * 3 / (js["ms_per_step"] * 3e-3)) < 1e-6 * js["value"]
+    assert "roofline" in js and "cpu_baseline" not in js and "train" not in js          # N = 1 legs stay at N = 1

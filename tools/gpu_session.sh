@@ -1,16 +1,5 @@
 # one GPU session of the round (edited per call; results under gpurun_out/<tag>)
-T=${1:-r4v}
+T=${1:-r4w}
 R=$PWD; O=$R/gpurun_out/$T; mkdir -p $O
-LIDIFF_PARITY_LOG=$O/parity.jsonl timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_network.py tests/test_gpu_baseline.py -m gpu -x -q -k "cell_lists or nn_match or overlapped or completion_loop or c1_one or closed_loop" > $O/pytest.log 2>&1; tail -15 $O/pytest.log | cut -c1-250
-B="--steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-train --no-closed-loop --no-coords-roofline"
-for i in 1 2; do
-python bench.py $B > $O/bench_cells$i.json 2> $O/bench.err
-LIDIFF_MATCH_CELLS=0 python bench.py $B > $O/bench_brute$i.json 2>> $O/bench.err
-done
-python - <<PY
-import json
-for n in ("cells1","brute1","cells2","brute2"):
-    d=json.loads(open("$O/bench_%s.json"%n).readline()); r=d.get("roofline",{})
-    print(n, round(d["ms_per_step"],3), round(r.get("frac",0),4), round((r.get("serial") or {}).get("frac",0),4))
-PY
-bash tools/gpu_window.sh > /dev/null 2>&1; cp gpurun_out/window/window.txt $O/window.txt; grep -n "match\|cells\|spconv_thin\|mean_" $O/window.txt | head -30
+LIDIFF_BENCH_BACKEND=gloo LIDIFF_BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_2ranks_shared.json 2> $O/bench_2ranks_shared.err; echo rc=$?; wc -l $O/bench_2ranks_shared.json; cut -c1-700 $O/bench_2ranks_shared.json; tail -5 $O/bench_2ranks_shared.err | cut -c1-200
+LIDIFF_BENCH_BACKEND=gloo LIDIFF_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --pipeline --scans 1 > $O/bench_pipeline_2ranks_shared.json 2> $O/bench_pipeline_2ranks_shared.err; echo rc=$?; wc -l $O/bench_pipeline_2ranks_shared.json; cut -c1-600 $O/bench_pipeline_2ranks_shared.json; tail -3 $O/bench_pipeline_2ranks_shared.err | cut -c1-200

@@ -571,23 +571,27 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                 // (Round 4 tried ordering by OFFSET instead -- the segments of one offset touch every output row at most once and
                 // can be flushed by all waves at once, runs of equal offsets separated by barriers: 3-4 runs per pack of 8
                 // segments, and each needs a workgroup barrier: 388 vs 338 us on 64 -> 64 at stride 4; not kept.)
+                // The list words and tile addresses of ALL of the wave's segments first (independent of each other and of the
+                // order); only the read-modify-writes of the tile are ordered, segment after segment.
+                int addr[NSW][BLQ];
+#pragma unroll
+                for (int q = 0; q < NSW; ++q)
+#pragma unroll
+                    for (int g = 0; g < BLQ; ++g) {
+                        const int gb = wm + WM * (q * BLQ + g);
+                        addr[q][g] = tile_addr((int)out_list[dc.k[q] * BM + dc.start[q] + 16 * (gb % BPS) + li], 4 * wn + lq);
+                    }
                 for (int round = 0; round < WM; ++round) {
                     if (wm == round) {
                         char* accb = reinterpret_cast<char*>(acc_lds);
 #pragma unroll
                         for (int q = 0; q < NSW; ++q) {
                             if (dc.n[q] == 0) continue;          // no segment here: nothing to add
-                            int addr[BLQ];
-#pragma unroll
-                            for (int g = 0; g < BLQ; ++g) {
-                                const int gb = wm + WM * (q * BLQ + g);
-                                addr[g] = tile_addr((int)out_list[dc.k[q] * BM + dc.start[q] + 16 * (gb % BPS) + li], 4 * wn + lq);
-                            }
                             f32x4 old[BLQ];
 #pragma unroll
-                            for (int g = 0; g < BLQ; ++g) old[g] = *reinterpret_cast<const f32x4*>(accb + addr[g]);
+                            for (int g = 0; g < BLQ; ++g) old[g] = *reinterpret_cast<const f32x4*>(accb + addr[q][g]);
 #pragma unroll
-                            for (int g = 0; g < BLQ; ++g) *reinterpret_cast<f32x4*>(accb + addr[g]) = old[g] + acc[q * BLQ + g];
+                            for (int g = 0; g < BLQ; ++g) *reinterpret_cast<f32x4*>(accb + addr[q][g]) = old[g] + acc[q * BLQ + g];
                             asm volatile("" ::: "memory");       // keep the segments' read-modify-writes in order
                         }
                     }

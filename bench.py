@@ -79,9 +79,12 @@ def make_inputs(pipe, scan_np, steps, seed, device):
 def run_steps(pipe, x_init, xs, tvals, first, count, cache_condition=False):
     """`count` denoising steps starting at schedule position `first`.  cache_condition: the SURVEY.md 8(f) row-1
     variant (conditions encoded once per scan) -- reported beside the metric, never as `value`."""
-    x_t = pipe.points_to_tensor(xs[first])
-    x_cond = pipe.points_to_tensor(x_init)
-    x_uncond = pipe.points_to_tensor(torch.zeros_like(x_init))
+    # fields carry their role in the loop: with DiffCompletion.read_free only the FIRST pyramid of a role is built with a host read
+    # (what completion_loop does for a scan); the check of what the read-free steps assumed is part of the timed work (below)
+    pipe.read_free_reset()
+    x_t = pipe.points_to_tensor(xs[first], role="x_t")
+    x_cond = pipe.points_to_tensor(x_init, role="cond")
+    x_uncond = pipe.points_to_tensor(torch.zeros_like(x_init), role="uncond")
     parts = pipe.encode_conditions(x_cond, x_uncond) if cache_condition else None
     for j in range(first, first + count):
         t = torch.full((1,), tvals[j], dtype=torch.int64, device=x_init.device)
@@ -93,9 +96,12 @@ def run_steps(pipe, x_init, xs, tvals, first, count, cache_condition=False):
         # per step than the closed loop has, never less
         _ = pipe.step_boundary(x_init, x_t, e_cond, e_uncond, tvals[j])
         nxt = xs[j + 1] if j + 1 < len(xs) else xs[j]
-        x_t = pipe.points_to_tensor(nxt)               # open loop: next sigma's points (see docstring)
+        x_t = pipe.points_to_tensor(nxt, role="x_t")   # open loop: next sigma's points (see docstring)
         if parts is None:
             x_cond, x_uncond = pipe.reset_partial_pcd(x_cond, x_uncond, next_t=tvals[j + 1] if j + 1 < first + count else None)
+    why = pipe.read_free_check()
+    if why is not None:
+        raise RuntimeError("host-read-free steps voided: " + why + " (LIDIFF_READ_FREE=0 runs every step with its host read)")
     return x_t
 
 
@@ -586,6 +592,7 @@ def main():
         # per operand (3 bf16 MFMAs per block, fp32 accumulation; ops.split_planes, lidiff_spconv_fwd_bf16 planes = 2)
         alt = None
         if world == 1 and not args.no_alt:
+            rf, pipe.read_free = pipe.read_free, False          # (the bf16-split kernel takes exact row counts only)
             with ops.split_planes(2):
                 run_steps(pipe, x_init, wx, wt, 0, 1)                   # packs the bf16 weight planes
                 aprof = None if args.no_kernel_events else ops.ConvProfiler({"bf16x2"})
@@ -596,6 +603,7 @@ def main():
                 torch.cuda.synchronize()
                 alt = (time.perf_counter() - t0, aprof)
                 ops.PROFILER = None
+            pipe.read_free = rf
     elapsed = ldist.max_over_ranks(elapsed, device=device)
     if args.cached_condition:
         elapsed_cached = ldist.max_over_ranks(elapsed_cached, device=device)

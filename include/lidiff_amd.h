@@ -28,13 +28,13 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 24
+#define LIDIFF_ABI_VERSION 25
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
+#define LIDIFF_STATUS_BOUND 4       /* *d_status bit: a device-side count exceeded the bound the host sized a buffer for (host-read-free
+                                       steps, lidiff_tail_map_fill_bounded): nothing was overrun, the results of the step are void */
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
-#define LIDIFF_CONV_DENSE_KERNEL 2  /* lidiff_spconv_fwd flags: software-pipelined kernel for the dense 128-column layers */
-#define LIDIFF_CONV_DENSE_ONE_WAVE 4 /* ... in its four-wave form (one wave per SIMD, 32 columns per wave) */
 #define LIDIFF_CONV_TILE_128 16     /* 64-column layers on 128-row tiles as well (default: 256-row tiles for large maps; A/B measurements) */
 #define LIDIFF_CONV_TILE_ONLY 8     /* identity maps (nbr == NULL) through the tile kernel as well, not the row kernel (A/B measurements, tests) */
 
@@ -119,12 +119,19 @@ int lidiff_kernel_map_self_dev(const int32_t* coords, int64_t m_bound, const int
  * table, ks 2, step ts_fine) builds, bit for bit, from one pass over the fine rows instead of 8 lookups per coarse row. */
 int lidiff_kernel_map_down(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine, int32_t ts_fine,
                            int64_t m_coarse, int32_t* nbr_down, void* stream);
+/* ... with the fine map's row count on the device (*d_m_fine <= m_fine_bound); nbr_down [8, m_coarse_bound] (pitch = the bound of
+ * the coarse map), columns without a fine row stay -1. */
+int lidiff_kernel_map_down_dev(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine_bound, const int32_t* d_m_fine,
+                               int32_t ts_fine, int64_t m_coarse_bound, int32_t* nbr_down, void* stream);
 
 /* Kernel map of MinkowskiConvolutionTranspose(ks=2,stride=2) -- minkunet.py:32-46 (ME:
  * swapped fine->coarse map): nbr_up[k*m_fine + j] = parent[j] if k == kernel index of
  * (fine_coords[j] - coarse coordinate)/ts_fine (x fastest) else -1. */
 int lidiff_kernel_map_up(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine,
                          int32_t ts_fine, int32_t* nbr_up, void* stream);
+/* ... with the row count on the device: nbr_up [8, m_fine_bound], columns >= *d_m_fine are -1. */
+int lidiff_kernel_map_up_dev(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine_bound, const int32_t* d_m_fine,
+                             int32_t ts_fine, int32_t* nbr_up, void* stream);
 
 /* Morton (Z-order) key of every row of a coordinate map at tensor stride ts (batch index above 3 x 16
  * interleaved bits of x, y, z / ts).  No reference counterpart: ME processes rows in hash order; here the
@@ -156,6 +163,21 @@ int lidiff_tail_map(const int32_t* nbr, int32_t k_vol, int64_t m_out, int32_t sk
 int lidiff_tail_map_dev(const int32_t* nbr, int32_t k_vol, int64_t m_bound, const int32_t* d_m, int32_t skip,
                         int32_t* offset_ptr, int32_t* row_ptr, int64_t n_pairs, int32_t* tail_nbr, int32_t* idx,
                         void* workspace, void* stream);
+/* Phase 2 of lidiff_tail_map_dev when the PAIR COUNT stays on the device as well (a denoising step without a host read): the
+ * pair list form of the tail map -- pair_in [n_pairs_bound] (the input row of pair p; what lidiff_spconv_fwd_pairs walks with
+ * offset_ptr) and idx [n_pairs_bound] -- into buffers sized by a bound.  If offset_ptr[k_vol] > n_pairs_bound the pairs behind
+ * the bound are dropped and LIDIFF_STATUS_BOUND is raised in *d_status (the consumers clamp their ranges to the bound, so
+ * nothing is overrun; the caller redoes the step with exact sizes). */
+int lidiff_tail_map_fill_bounded(const int32_t* nbr, int32_t k_vol, int64_t m_bound, const int32_t* d_m, int32_t skip,
+                                 const int32_t* offset_ptr, const int32_t* row_ptr, int64_t n_pairs_bound, int32_t* pair_in,
+                                 int32_t* idx, int32_t* d_status, void* workspace, void* stream);
+
+/* n_words device int32 words (the row counts of a coordinate pyramid) and *d_status (nullable) written into host-visible memory
+ * (host_mapped: pinned, device-mapped; [0] = seq, [1] = status, [2 ..] = the words), the sequence number last behind a
+ * system-scope fence.  The host side of a denoising loop learns the sizes of step i from it while step i + 1 is already queued
+ * -- no device->host copy, no synchronisation (DiffCompletion, pipeline:155-169).  n_words <= 62. */
+int lidiff_publish_words(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* host_mapped, int32_t seq,
+                         void* stream);
 
 /* Weight layout of the sparse convolution.  MinkowskiConvolution.kernel is [K, c_in, c_out] row-major
  * (minkunet.py:17,36,53,61; [c_in, c_out] for kernel_size 1, :72).  The HIP kernel consumes it in MFMA
@@ -183,10 +205,7 @@ int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int3
  *   (pipeline:148-153) in one launch; m_in / m_out are per replica.
  * flags: LIDIFF_CONV_SPARSE_MAP = the kernel map is expected to hold only a few pairs per offset and
  *   128-row tile (a performance hint, results are identical): such tiles pack several offsets into
- *   one 128-row stage.  LIDIFF_CONV_DENSE_KERNEL = run layers with c_out % 128 == 0 and 64 | c_in on the
- *   software-pipelined kernel (spconv_dense.hip: ring of four LDS-DMA images requested three stages ahead, counted
- *   vmcnt barrier, fragments read one stage ahead); bit-identical results, same speed as the tile kernels on the
- *   bench workload -- kept selectable, not the default.
+ *   one 128-row stage.
  *   Identity maps (nbr == NULL, no row order; channel widths multiples of 16 with c_in in {32, 64, 96, 128, 192}, c_out a
  *   multiple of 32) run as a streaming row GEMM (spconv_rows.hip: W column tile resident in LDS, rows straight from HBM
  *   into the MFMA operands, no barrier, 16-byte stores) with bit-identical results; LIDIFF_CONV_TILE_ONLY keeps them on
@@ -198,16 +217,19 @@ int lidiff_spconv_pack_weights(const float* w, int32_t k_vol, int32_t c_in, int3
  *   [M, c_in] x [c_in, c_out] pass over contiguous rows, launched with nbr == NULL and W[13] -- and the few pairs of
  *   the other 26 offsets are multiplied beforehand, grouped by offset (weight stationary: W[k] is read once per 128
  *   pairs instead of once per output tile that has a single pair of offset k), into `tail`, one row per pair
- *   (lidiff_amd/MinkowskiEngine CoordinateManager.tail_map).  Fixed summation order: deterministic. */
+ *   (lidiff_amd/MinkowskiEngine CoordinateManager.tail_map).  Fixed summation order: deterministic.
+ * d_m_out (nullable): the number of valid output rows lives on the device (*d_m_out <= m_out); m_out is then only its BOUND --
+ *   it still sizes the grid, the row pitch of nbr and the replica pitch of in / out / residual -- and tiles behind the count
+ *   leave at once.  A denoising step whose map sizes never reach the host (DiffCompletion). */
 int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
                       const float* w_packed, const int32_t* nbr, int32_t k_vol,
                       int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                       const float* ep_scale, const float* ep_shift, const float* residual,
                       int32_t relu, const int32_t* row_order, int32_t replicas, int32_t flags,
                       const float* tail, const int32_t* tail_ptr, const int32_t* tail_idx, int64_t tail_rows,
-                      void* stream);
+                      const int32_t* d_m_out, void* stream);
 
-/* Which kernel lidiff_spconv_fwd runs for these arguments: 0 = tile kernel (spconv.hip), 1 = dense kernel (spconv_dense.hip),
+/* Which kernel lidiff_spconv_fwd runs for these arguments: 0 = tile kernel (spconv.hip),
  * 2 = row kernel (spconv_rows.hip), 3 = thin-input kernel (c_in <= 4, c_out == 32: the stems; spconv_rows.hip; equal to the
  * tile kernel up to fp32 summation order).  has_nbr / has_row_order: whether those pointers are non-null.  For profilers and tests. */
 int32_t lidiff_spconv_fwd_kernel_id(int32_t c_in_a, int32_t c_in_b, int32_t c_out, int32_t k_vol, int32_t has_nbr,
@@ -285,15 +307,14 @@ int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int
 int64_t lidiff_segment_sum_workspace_bytes(int64_t n_sources, int32_t c);
 int lidiff_segment_sum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t m, int32_t c, float* dst,
                             int64_t n_sources, void* workspace, void* stream);
-int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
-                            float* dst, void* stream);
 
 /* The conditioning multiply x * w, w = latemp(cat(latent(match), temp)) -- minkunet.py:424-431 etc.: for one batch
  * (one time embedding) every layer of that MLP is row-wise and commutes with the gather of match_part_to_full, so w
  * is table[idx] with table = the MLP evaluated on the few part rows: dst[r,:] = x[r,:] * table[idx[r],:] in one pass.
- * c % 4 == 0, pointers 16-byte aligned. */
+ * c % 4 == 0, pointers 16-byte aligned.  idx == NULL: every row takes table row 0 (the one-voxel unconditional branch: a
+ * broadcast).  d_n_rows (nullable): the number of valid rows lives on the device, n_rows is its bound. */
 int lidiff_gather_mul_rows(const float* x, const float* table, const int64_t* idx, int64_t n_rows, int32_t c,
-                           float* dst, void* stream);
+                           float* dst, const int32_t* d_n_rows, void* stream);
 
 /* Hidden layer of the conditioning MLPs -- minkunet.py:424-431 (latemp_* applied to cat(latent(match), temp)):
  * with the row-wise Linear commuted in front of the gather, dst[r,:] = leaky_relu(src[idx[r],:] + bias[:], slope)
@@ -314,13 +335,6 @@ int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, in
  * matches of a step run beside the pyramid's own kernels instead of behind its host read. */
 int lidiff_nn_match_dev(const int32_t* full, int64_t m_full_bound, const int32_t* d_m_full, const int32_t* part, int64_t m_part,
                         int32_t* d_max_coord, int64_t* idx, void* stream);
-
-/* The same arg-min when the part rows are a coordinate map of tensor stride `part_stride` with hash table
- * (hkeys_part, hvals_part, cap_part): searches the lattice cells around every full row in growing shells instead
- * of scanning all part rows; exact (same winner, same tie rule), with the exhaustive scan as per-row fallback. */
-int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
-                         const uint64_t* hkeys_part, const int32_t* hvals_part, int64_t cap_part, int32_t part_stride,
-                         const int32_t* d_max_coord, int64_t* idx, void* stream);
 
 /* The generic brute-force arg-min behind the reference's pykeops expression (minkunet.py:412-416:
  * ((LazyTensor(f[:,None,:]) - LazyTensor(p[None,:,:]))**2).sum(-1).argKmin(1, dim=1)): rows are float4

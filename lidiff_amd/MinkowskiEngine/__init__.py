@@ -48,10 +48,16 @@ _SPLIT_PYRAMID = __import__("os").environ.get("LIDIFF_SPLIT_PYRAMID", "1") != "0
 
 
 class CoordinateMap:
-    __slots__ = ("coords", "table", "ts")
+    """coords [M, 4] of one tensor stride + its hash table.  Host-read-free managers hand the rows over at their BOUND:
+    `count` is then the int32 [1] device tensor holding the number of valid rows and `hint` the row count the host believes
+    (the same level of an earlier pyramid of the same role) -- every size-dependent DECISION uses rows(), never coords.shape."""
+    __slots__ = ("coords", "table", "ts", "count", "hint")
 
-    def __init__(self, coords, table, ts):
-        self.coords, self.table, self.ts = coords, table, ts
+    def __init__(self, coords, table, ts, count=None, hint=None):
+        self.coords, self.table, self.ts, self.count, self.hint = coords, table, ts, count, hint
+
+    def rows(self) -> int:
+        return self.coords.shape[0] if self.count is None else self.hint
 
 
 class CoordinateManager:
@@ -75,6 +81,40 @@ class CoordinateManager:
         # True: insert() builds the whole pyramid (ops.build_pyramid: voxel map, the four strided maps, the kernel_size-3
         # maps and tail-map counts of the first two levels) with ONE host read instead of one per map.  Same maps.
         self.pyramid = False
+        # Host-read-free building (DiffCompletion.read_free): `feed` (ops.SizeFeed) collects the sizes of the
+        # pyramids of this field's role; with read_free the pyramid is built WITHOUT a host read -- maps at their bound, counts on
+        # the device, kernel choices from `hints` (the sizes of the role's previous pyramid).  Fused inference plan only.
+        self.feed = None
+        self.read_free = False
+        self.hints = None               # [rows of levels 0 .. 4, tail pairs of levels 0, 1] believed by the host
+        self.exact_rows = None          # strides whose rows must come out EXACTLY as hinted (the condition's latent), checked later
+        self.hint_lag = False           # exact sizes, but kernel choices from `hints` (the A/B twin of read_free: same choices)
+
+    def rows(self, ts: int) -> int:
+        """Row count of the map of stride ts as the host knows it (exact, or the hint of a read-free map); 0 if absent.
+        With hint_lag (exact maps, decisions from an earlier pyramid's sizes) the hint wins wherever it exists."""
+        m = self.maps.get(ts)
+        if m is None:
+            return 0
+        if self.hint_lag and self.hints is not None and m.count is None:
+            lv = ts.bit_length() - 1
+            if lv < len(self.hints):
+                return self.hints[lv]
+        return m.rows()
+
+    def count(self, ts: int):
+        """int32 [1] device tensor with the valid rows of a read-free map, None for a map of exact size."""
+        return self.maps[ts].count
+
+    def tail_rows(self, ts: int):
+        """Believed pair count of the tail map of stride ts (profiler bookkeeping only)."""
+        tm = self.aux.get(("tail", ts))
+        if tm is None or not getattr(tm, "bounded", False):
+            return None if tm is None else tm.n
+        lv, levels = ts.bit_length() - 1, int(math.log2(self.MAX_STRIDE))
+        if self.hints is not None and levels + 1 + lv < len(self.hints):
+            return self.hints[levels + 1 + lv]
+        return None
 
     # -- asynchronous, on-demand building (DiffCompletion, round 3) ------------------------------------------------------
     def set_async(self, side, side2, ready=None, on_level=None, on_level_dev=None):
@@ -132,14 +172,26 @@ class CoordinateManager:
             # with the row counts on the device, instead of behind the pyramid's host read
             def hook(lv, rows, d_count):
                 early.append((lv, self._on_level_dev(1 << lv, rows, d_count)))
+        free = False
+        if self.feed is not None:
+            if self.hints is None and self.feed.has_records():
+                self.hints = self.feed.get()[1]      # the role's previous pyramid (waits for the device if it is not there yet)
+            free = self.read_free and self.hints is not None
         with self.building():
-            pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2, second_stream=second, on_level_dev=hook)
+            pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2, second_stream=second, on_level_dev=hook,
+                                    feed=self.feed, read_free=free)
+        self._counts = pyr.counts
+        if free:           # rows the host takes as exact (exact_view) are checked when the device's counts arrive
+            self.feed.expect(self.feed.seq, {ts.bit_length() - 1: self.hints[ts.bit_length() - 1] for ts in (self.exact_rows or ())})
         for lv, results in early:
             for key, owner, bound_tensor, event in results:
-                self.aux[key] = (owner, bound_tensor[:pyr.coords[lv].shape[0]], event)
+                self.aux[key] = (owner, bound_tensor if free else bound_tensor[:pyr.coords[lv].shape[0]], event)
         for lv in range(levels + 1):
             ts = 1 << lv
-            self.maps[ts] = CoordinateMap(pyr.coords[lv], pyr.tables[lv], ts)
+            if free:
+                self.maps[ts] = CoordinateMap(pyr.coords[lv], pyr.tables[lv], ts, count=pyr.counts[lv:lv + 1], hint=self.hints[lv])
+            else:
+                self.maps[ts] = CoordinateMap(pyr.coords[lv], pyr.tables[lv], ts)
             if lv:
                 self.parents[ts] = pyr.parents[lv]
         for lv, (nbr, tail) in enumerate(zip(pyr.nbr3, pyr.tails)):
@@ -176,6 +228,15 @@ class CoordinateManager:
         return nbr
 
     def _build_kernel_map(self, ts_in, ts_out, ks, transposed):
+        if self.maps[ts_out].count is not None:      # read-free maps: tables at the bound, the row counts read on the device
+            if transposed and ks == 2 and ts_in == 2 * ts_out and ts_in in self.parents:
+                return ops.kernel_map_up_dev(self.maps[ts_out].coords, self.parents[ts_in], self.maps[ts_out].count, ts_out)
+            if not transposed and ks == 2 and ts_out == 2 * ts_in and ts_out in self.parents:
+                return ops.kernel_map_down_dev(self.maps[ts_in].coords, self.parents[ts_out], self.maps[ts_in].count, ts_in,
+                                               self.maps[ts_out].coords.shape[0])
+            if not transposed and ks == 3 and ts_in == ts_out:
+                return ops.kernel_map_self_dev(self.maps[ts_out].coords, self.maps[ts_out].count, self.maps[ts_in].table, ts_in)
+            raise RuntimeError("a host-read-free coordinate manager serves LiDiff's maps only (k3 s1, k2 s2 down / up)")
         if transposed:      # input = coarse map (ts_in), output = existing fine map (ts_out)
             if ks != 2 or ts_in != 2 * ts_out or ts_in not in self.parents:
                 raise RuntimeError("transposed convolution supported for kernel_size=2, stride=2 "
@@ -194,7 +255,10 @@ class CoordinateManager:
         if key not in self.aux:
             nbr = self.kernel_map(ts, ts, 3)
             with self.building():
-                self.aux[key] = ops.TailMap(nbr)
+                if self.maps[ts].count is not None:
+                    self.aux[key] = ops.TailMap.on_device(nbr, self.maps[ts].count, self.status).fill()
+                else:
+                    self.aux[key] = ops.TailMap(nbr)
         elif getattr(self.aux[key], "_pending", None) is not None:      # counted in build_pyramid(): fill, no host read
             with self.building():
                 self.aux[key].fill()
@@ -235,13 +299,13 @@ class CoordinateManager:
         key = ("up_order", ts_in, ts_out)
         if key not in self.aux:
             nbr = self.kernel_map(ts_in, ts_out, 2, True)
-            if nbr.shape[1] < self.UP_ORDER_MIN_ROWS:
+            if self.rows(ts_out) < self.UP_ORDER_MIN_ROWS:
                 self.aux[key] = None
             else:
                 # the ME-layout rulebook of the map lists its pairs by offset, then by output row: its output-row column IS the
                 # order (one pair per row => a permutation), built by three small kernels without a host read
                 with self.building():
-                    pin, order, off = ops.rulebook_compact(nbr, total=nbr.shape[1])
+                    pin, order, off = ops.rulebook_compact(nbr, total=nbr.shape[1], bounded=self.maps[ts_out].count is not None)
                     self.aux[key] = (nbr.index_select(1, order.long()).contiguous(), order)
                     self.aux[("up_pairs", ts_in, ts_out)] = (pin, order, off)
         return self.aux[key]
@@ -263,7 +327,7 @@ class CoordinateManager:
         narrow tiles (C_out 96 / 64: 3 x 2 and 4 x 2 wave grids, eight offsets per stage) win up to ~7 neighbours per voxel --
         +38 % on 64 -> 64 at stride 4 (4.3 neighbours, r = 0.69), +36 % on 96 -> 96 at stride 2 with 3.6 (r = 0.73), equal at
         11 (r = 0.38) -- so they take it for r >= 0.5."""
-        m = lambda ts: self.maps[ts].coords.shape[0] if ts in self.maps else 0
+        m = self.rows
         if ks == 1:
             return False
         if ks == 2:                                   # stride-2 down: 16 / r pairs per offset and tile; up: 16
@@ -299,7 +363,7 @@ class CoordinateManager:
                 self.up_order(nxt, ts)
             ts = nxt
         for ts in list(self.maps):                      # the sparse-map hint of a level needs the next level's size
-            if tail_maps and self.maps[ts].coords.shape[0] >= 1024 and self.is_sparse_map(ts, ts, 3):
+            if tail_maps and self.rows(ts) >= 1024 and self.is_sparse_map(ts, ts, 3):
                 self.tail_map(ts)
 
     def prebuild_rulebooks(self):
@@ -310,6 +374,8 @@ class CoordinateManager:
     def tensors(self):
         """Every device tensor this manager holds (for record_stream when it was built on another stream)."""
         out = [self.status]
+        if getattr(self, "_counts", None) is not None:
+            out.append(self._counts)
         for m in self.maps.values():
             out += [m.coords, m.table.keys, m.table.vals]
         out += list(self.parents.values())
@@ -334,6 +400,8 @@ class CoordinateManager:
             raise RuntimeError("coordinate outside [-32768, 32767]: not representable in the 64-bit key")
         if s & ops.STATUS_HASH_FULL:
             raise RuntimeError("coordinate hash table overflow")
+        if s & ops.STATUS_BOUND:
+            raise RuntimeError("a device-side count exceeded the bound of a host-read-free step (the step must be redone)")
 
 
 # ----------------------------------------------------------------------------------------
@@ -472,6 +540,7 @@ class SparseTensor:
         self.tensor_stride = int(tensor_stride)
         self.coordinate_manager = coordinate_manager
         self.replicas = 1          # > 1: that many feature matrices stacked row-wise on ONE coordinate map (CFG pair)
+        self._rows = None          # exact_view(): the first _rows rows of a read-free map, taken as its exact size
 
     @property
     def F(self):
@@ -479,11 +548,23 @@ class SparseTensor:
 
     @property
     def C(self):
-        return self.coordinate_manager.maps[self.tensor_stride].coords
+        c = self.coordinate_manager.maps[self.tensor_stride].coords
+        return c if self._rows is None else c[:self._rows]
 
     @property
     def device(self):
         return self._F.device
+
+    def exact_view(self) -> "SparseTensor":
+        """A tensor on a host-read-free map cut to the rows the host BELIEVES it has (the map's hint), to be used where the
+        row count shapes host-side work (the condition's latent: MLP tables, match targets).  The manager registers the belief
+        with its SizeFeed, which checks it against the device's count when that arrives.  Exact maps: self."""
+        m = self.coordinate_manager.maps[self.tensor_stride]
+        if m.count is None or self.replicas != 1:
+            return self
+        out = SparseTensor(self._F[:m.hint], tensor_stride=self.tensor_stride, coordinate_manager=self.coordinate_manager)
+        out._rows = m.hint
+        return out
 
     def _like(self, features):
         out = SparseTensor(features, tensor_stride=self.tensor_stride, coordinate_manager=self.coordinate_manager)
@@ -592,6 +673,8 @@ class _ConvBase(nn.Module):
     def forward(self, x: SparseTensor) -> SparseTensor:
         nbr, nbr_sw, ts_out, flip = self.maps(x)
         mgr = x.coordinate_manager
+        if mgr.maps[ts_out].count is not None:
+            raise RuntimeError("host-read-free coordinate maps serve the fused inference plan only")
         m_out = mgr.maps[ts_out].coords.shape[0]
         if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad):
             f = _SparseConv.apply(x.F, self.kernel, nbr, nbr_sw, m_out, flip, self.sparse_hint(x, ts_out))

@@ -41,7 +41,7 @@ SIGNATURES = {
     "lidiff_spconv_packed_weight_floats": (_i64, [_i32, _i32, _i32]),
     "lidiff_spconv_pack_weights": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
     "lidiff_spconv_fwd": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i32, _i32,
-                                 _p, _p, _p, _i64, _p]),
+                                 _p, _p, _p, _i64, _p, _p]),
     "lidiff_spconv_fwd_kernel_id": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "lidiff_spconv_fwd_pairs_supported": (_i32, [_i32, _i32, _i32]),
     "lidiff_spconv_fwd_pairs": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _i32,
@@ -66,10 +66,9 @@ SIGNATURES = {
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
-    "lidiff_scatter_add_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_segment_sum_workspace_bytes": (_i64, [_i64, _i32]),
     "lidiff_segment_sum_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
-    "lidiff_gather_mul_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
+    "lidiff_gather_mul_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
     "lidiff_nn_match": (_i32, [_p, _i64, _p, _i64, _p, _p, _p]),
     "lidiff_nn_match_dev": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _p]),
     "lidiff_argmin_rows_f32": (_i32, [_p, _i64, _p, _i64, _p, _p]),
@@ -77,12 +76,15 @@ SIGNATURES = {
     "lidiff_fps": (_i32, [_p, _i64, _i64, _p, _p, _p]),
     "lidiff_fps_coop_supported": (_i32, [_i64]),
     "lidiff_fps_coop": (_i32, [_p, _i64, _i64, _p, _p, _p, _p]),
-    "lidiff_nn_match_grid": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p]),
+    "lidiff_kernel_map_down_dev": (_i32, [_p, _p, _i64, _p, _i32, _i64, _p, _p]),
+    "lidiff_kernel_map_up_dev": (_i32, [_p, _p, _i64, _p, _i32, _p, _p]),
+    "lidiff_tail_map_fill_bounded": (_i32, [_p, _i32, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p, _p]),
+    "lidiff_publish_words": (_i32, [_p, _i32, _p, _p, _i32, _p]),
     "lidiff_nn_dist_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 _lib = None
 
 

@@ -389,10 +389,15 @@ __global__ __launch_bounds__(kBlock) void kernel_map_self_kernel(const int32_t* 
     }
 }
 
+// (d_m != nullptr: the row count lives on the device, `m` is the bound and the row pitch; rows behind the count get no pair)
 __global__ void kernel_map_up_kernel(const int32_t* __restrict__ fine, const int32_t* __restrict__ parent,
-                                     int64_t m, int ts, int32_t* __restrict__ nbr_up) {
+                                     int64_t m, const int32_t* __restrict__ d_m, int ts, int32_t* __restrict__ nbr_up) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
+    if (d_m && j >= (int64_t)*d_m) {
+        for (int k = 0; k < 8; ++k) nbr_up[(int64_t)k * m + j] = -1;
+        return;
+    }
     const int4 c = reinterpret_cast<const int4*>(fine)[j];
     const int s = 2 * ts;
     const int dx = (c.y - floor_div(c.y, s) * s) / ts;
@@ -407,9 +412,10 @@ __global__ void kernel_map_up_kernel(const int32_t* __restrict__ fine, const int
 // under the offset given by its position inside the coarse cell.  One coalesced pass over the fine rows and one scattered
 // 4-byte write each, instead of 8 table lookups per coarse row (the same table as kernel_map_kernel<2>).  nbr pre-filled -1.
 __global__ void kernel_map_down_kernel(const int32_t* __restrict__ fine, const int32_t* __restrict__ parent, int64_t m_fine,
-                                       int ts, int64_t m_coarse, int32_t* __restrict__ nbr_down) {
+                                       const int32_t* __restrict__ d_m_fine, int ts, int64_t m_coarse,
+                                       int32_t* __restrict__ nbr_down) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m_fine) return;
+    if (j >= (d_m_fine ? min((int64_t)*d_m_fine, m_fine) : m_fine)) return;
     const int4 c = reinterpret_cast<const int4*>(fine)[j];
     const int s = 2 * ts;
     const int dx = (c.y - floor_div(c.y, s) * s) / ts;
@@ -622,6 +628,55 @@ __global__ void tail_fill_kernel(const int32_t* __restrict__ nbr, int64_t m_out,
     }
 }
 
+// The same fill into a pair list whose length is only BOUNDED on the host (host-read-free steps: the pair count stays on the
+// device): pair_in[pos] = the pair's input row (what lidiff_spconv_fwd_pairs walks -- the [K, P] table form is not made),
+// idx as above.  Pairs behind the bound are dropped and LIDIFF_STATUS_BOUND raised in *d_status: the caller redoes the step
+// with exact sizes; consumers clamp their ranges to the bound, so nothing is overrun meanwhile.  idx must be pre-zeroed.
+__global__ void tail_fill_bounded_kernel(const int32_t* __restrict__ nbr, int64_t m_out, const int32_t* __restrict__ d_m, int skip,
+                                         int k_vol, int64_t n_bound, const int32_t* __restrict__ scanned,
+                                         const int32_t* __restrict__ offset_ptr, const int32_t* __restrict__ row_ptr,
+                                         int32_t* __restrict__ pair_in, int32_t* __restrict__ idx, int32_t* __restrict__ d_status) {
+    __shared__ int wave_cnt[kWavesPerBlock];
+    const int k = blockIdx.y;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = d_m ? min((int64_t)*d_m, m_out) : m_out;
+    if (blockIdx.x == 0 && k == 0 && threadIdx.x == 0 && (int64_t)offset_ptr[k_vol] > n_bound) atomicOr(d_status, LIDIFF_STATUS_BOUND);
+    int v = -1;
+    if (k != skip && o < rows) v = nbr[(int64_t)k * m_out + o];
+    const bool valid = v >= 0;
+    const unsigned long long m = __ballot(valid);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < w; ++q) wbase += wave_cnt[q];
+    if (valid) {
+        const int64_t pos = (int64_t)scanned[(int64_t)k * gridDim.x + blockIdx.x] + wbase + popc_below(m);
+        if (pos < n_bound) {
+            pair_in[pos] = v;
+            int rank = 0;                                            // pairs of this output row at lower offsets
+            for (int q = 0; q < k; ++q) rank += (q != skip && nbr[(int64_t)q * m_out + o] >= 0) ? 1 : 0;
+            const int64_t slot = (int64_t)row_ptr[o] + rank;
+            if (slot < n_bound) idx[slot] = (int32_t)pos;
+        }
+    }
+}
+
+// counts / status words of a coordinate pyramid -> host-visible (pinned, device-mapped) memory, then a sequence number: the
+// host learns the sizes of step i while step i + 1 is already queued, without a copy or a synchronisation on its side
+__global__ void publish_kernel(const int32_t* __restrict__ words, int n, const int32_t* __restrict__ d_status,
+                               volatile int32_t* __restrict__ host, int32_t seq) {
+    const int i = threadIdx.x;
+    if (i < n) host[2 + i] = words[i];
+    if (i == 0) host[1] = d_status ? *d_status : 0;
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0) {
+        host[0] = seq;
+        __threadfence_system();
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // row gather / scatter-add
 template <bool VEC4>
@@ -642,14 +697,16 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
 // out[r, :] = leaky_relu(src[idx[r], :] + bias[:], slope): the conditioning path's hidden layer
 // (minkunet.py:424-431 after commuting the row-wise MLP with the gather): one pass instead of gather + add + activation.
 // dst[r,:] = x[r,:] * table[idx[r],:] -- the conditioning multiply with the whole MLP commuted in front of the gather
+// (idx == nullptr: every row takes table row 0 -- the one-voxel unconditional branch; d_n: the valid rows live on the device)
 __global__ void gather_mul_rows_kernel(const float* __restrict__ x, const float* __restrict__ table,
-                                       const int64_t* __restrict__ idx, int64_t n, int c4, float* __restrict__ dst) {
+                                       const int64_t* __restrict__ idx, int64_t n, const int32_t* __restrict__ d_n, int c4,
+                                       float* __restrict__ dst) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n * c4) return;
+    if (e >= (d_n ? min((int64_t)*d_n, n) : n) * c4) return;
     const int64_t r = e / c4;
     const int j = (int)(e % c4);
     const float4 v = reinterpret_cast<const float4*>(x)[e];
-    const float4 w = reinterpret_cast<const float4*>(table)[idx[r] * c4 + j];
+    const float4 w = reinterpret_cast<const float4*>(table)[(idx ? idx[r] : 0) * c4 + j];
     reinterpret_cast<float4*>(dst)[e] = make_float4(v.x * w.x, v.y * w.y, v.z * w.z, v.w * w.w);
 }
 
@@ -669,13 +726,6 @@ __global__ void gather_bias_leaky_kernel(const float* __restrict__ src, const in
     reinterpret_cast<float4*>(dst)[r * c4 + j] = o;
 }
 
-__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
-                                        int64_t n, int c, float* __restrict__ dst) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n * c) return;
-    const int64_t r = e / c;
-    atomicAdd(&dst[idx[r] * c + e % c], src[e]);
-}
 
 // dst[o] = sum of src[order[q]] for q in [ptr[o], ptr[o + 1]) -- the scatter-add over a destination-sorted source list: every
 // destination row adds its sources in list order (the stable sort keeps source order), no atomics: deterministic.
@@ -878,61 +928,6 @@ __global__ void coord_max_dev_kernel(const int32_t* __restrict__ coords, const i
         for (int w = 1; w < (int)(blockDim.x / kWave); ++w) best = max(best, wbest[w]);
         if (best != INT32_MIN) atomicMax(d_max, best);
     }
-}
-
-// Same arg-min through the part map's hash table: part voxels sit on a lattice of pitch `ps` (their tensor
-// stride), so the nearest one is found by visiting the lattice cells around the query in growing cubic shells.
-// After shell R every unvisited voxel is at least ps*R + 1 away along some axis, so the search stops as soon as
-// the best squared distance is strictly below (ps*R + 1)^2 (strict: an equal distance further out could carry
-// a lower row index).  Queries with no same-batch part voxel within kMatchShells shells -- or whose best
-// distance could be beaten from another batch -- fall back to the exhaustive scan.  Exact, ties to the lowest row.
-constexpr int kMatchShells = 6;
-__global__ void nn_match_grid_kernel(const int32_t* __restrict__ full, int64_t m_full,
-                                     const int32_t* __restrict__ part, int64_t m_part,
-                                     const uint64_t* __restrict__ hkeys, const int32_t* __restrict__ hvals,
-                                     uint32_t mask, int ps, const int32_t* __restrict__ d_max_coord,
-                                     int64_t* __restrict__ idx) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m_full) return;
-    const int4 q = reinterpret_cast<const int4*>(full)[i];
-    const int cx = floor_div(q.y, ps) * ps, cy = floor_div(q.z, ps) * ps, cz = floor_div(q.w, ps) * ps;
-    const float scale = 2.0f * (float)(*d_max_coord);
-    long long best = 0x7fffffffffffffffll;
-    int best_j = 0x7fffffff;
-    bool done = false;
-    for (int R = 0; R <= kMatchShells && !done; ++R) {
-        for (int dz = -R; dz <= R; ++dz)
-            for (int dy = -R; dy <= R; ++dy) {
-                const bool face = (dz == -R || dz == R || dy == -R || dy == R);
-                for (int dx = -R; dx <= R; dx += (face || R == 0) ? 1 : 2 * R) {      // only the shell's cells
-                    bool ok;
-                    const uint64_t key = pack_key(q.x, cx + dx * ps, cy + dy * ps, cz + dz * ps, ok);
-                    if (!ok) continue;
-                    const int j = hash_find(hkeys, hvals, mask, key);
-                    if (j < 0) continue;
-                    const long long ex = q.y - (cx + dx * ps), ey = q.z - (cy + dy * ps), ez = q.w - (cz + dz * ps);
-                    const long long d = ex * ex + ey * ey + ez * ez;
-                    if (d < best || (d == best && j < best_j)) { best = d; best_j = j; }
-                }
-            }
-        const long long lim = (long long)ps * R + 1;
-        done = best < lim * lim;
-    }
-    // another batch is at least `scale` away: only when the same-batch winner is that far does it matter
-    if (!done || (double)best >= (double)scale * (double)scale) {
-        const float fb = (float)q.x * scale, fx = (float)q.y, fy = (float)q.z, fz = (float)q.w;
-        float bd = INFINITY;
-        int64_t bj = 0;
-        for (int64_t j = 0; j < m_part; ++j) {
-            const int4 c = reinterpret_cast<const int4*>(part)[j];
-            const float db = fb - (float)c.x * scale, dx = fx - (float)c.y, dy = fy - (float)c.z, dz = fz - (float)c.w;
-            const float d = db * db + dx * dx + dy * dy + dz * dz;
-            if (d < bd) { bd = d; bj = j; }
-        }
-        idx[i] = bj;
-        return;
-    }
-    idx[i] = best_j;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1339,8 +1334,21 @@ int lidiff_kernel_map_down(const int32_t* fine_coords, const int32_t* parent, in
     hipStream_t st = (hipStream_t)stream;
     LIDIFF_CHECK_HIP(hipMemsetAsync(nbr_down, 0xff, (size_t)8 * m_coarse * sizeof(int32_t), st));
     if (m_fine == 0) return 0;
-    kernel_map_down_kernel<<<(unsigned)ceil_div(m_fine, kBlock), kBlock, 0, st>>>(fine_coords, parent, m_fine, ts_fine,
+    kernel_map_down_kernel<<<(unsigned)ceil_div(m_fine, kBlock), kBlock, 0, st>>>(fine_coords, parent, m_fine, nullptr, ts_fine,
                                                                                   m_coarse, nbr_down);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_kernel_map_down_dev(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine_bound, const int32_t* d_m_fine,
+                               int32_t ts_fine, int64_t m_coarse_bound, int32_t* nbr_down, void* stream) {
+    LIDIFF_CHECK_ARG(ts_fine >= 1 && d_m_fine != nullptr, "tensor stride must be >= 1, d_m_fine set");
+    if (m_coarse_bound == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    LIDIFF_CHECK_HIP(hipMemsetAsync(nbr_down, 0xff, (size_t)8 * m_coarse_bound * sizeof(int32_t), st));
+    if (m_fine_bound == 0) return 0;
+    kernel_map_down_kernel<<<(unsigned)ceil_div(m_fine_bound, kBlock), kBlock, 0, st>>>(fine_coords, parent, m_fine_bound, d_m_fine,
+                                                                                        ts_fine, m_coarse_bound, nbr_down);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -1350,7 +1358,17 @@ int lidiff_kernel_map_up(const int32_t* fine_coords, const int32_t* parent, int6
     LIDIFF_CHECK_ARG(ts_fine >= 1, "tensor stride must be >= 1");
     if (m_fine == 0) return 0;
     kernel_map_up_kernel<<<(unsigned)ceil_div(m_fine, kBlock), kBlock, 0, (hipStream_t)stream>>>(
-        fine_coords, parent, m_fine, ts_fine, nbr_up);
+        fine_coords, parent, m_fine, nullptr, ts_fine, nbr_up);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_kernel_map_up_dev(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine_bound, const int32_t* d_m_fine,
+                             int32_t ts_fine, int32_t* nbr_up, void* stream) {
+    LIDIFF_CHECK_ARG(ts_fine >= 1 && d_m_fine != nullptr, "tensor stride must be >= 1, d_m_fine set");
+    if (m_fine_bound == 0) return 0;
+    kernel_map_up_kernel<<<(unsigned)ceil_div(m_fine_bound, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        fine_coords, parent, m_fine_bound, d_m_fine, ts_fine, nbr_up);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -1432,6 +1450,32 @@ int lidiff_tail_map_dev(const int32_t* nbr, int32_t k_vol, int64_t m_bound, cons
     return tail_map_impl(nbr, k_vol, m_bound, d_m, skip, offset_ptr, row_ptr, n_pairs, tail_nbr, idx, workspace, stream);
 }
 
+int lidiff_tail_map_fill_bounded(const int32_t* nbr, int32_t k_vol, int64_t m_bound, const int32_t* d_m, int32_t skip,
+                                 const int32_t* offset_ptr, const int32_t* row_ptr, int64_t n_pairs_bound, int32_t* pair_in,
+                                 int32_t* idx, int32_t* d_status, void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && m_bound >= 0 && n_pairs_bound >= 0, "bad shape");
+    LIDIFF_CHECK_ARG(nbr && offset_ptr && row_ptr && workspace && d_status, "null pointer");
+    if (n_pairs_bound == 0 || m_bound == 0) return 0;
+    LIDIFF_CHECK_ARG(pair_in != nullptr && idx != nullptr, "pair_in / idx");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)ceil_div(m_bound, kBlock);
+    LIDIFF_CHECK_HIP(hipMemsetAsync(pair_in, 0, (size_t)n_pairs_bound * sizeof(int32_t), st));
+    LIDIFF_CHECK_HIP(hipMemsetAsync(idx, 0, (size_t)n_pairs_bound * sizeof(int32_t), st));
+    tail_fill_bounded_kernel<<<dim3(nblk, k_vol), kBlock, 0, st>>>(nbr, m_bound, d_m, skip, k_vol, n_pairs_bound,
+                                                                   (const int32_t*)workspace, offset_ptr, row_ptr, pair_in, idx,
+                                                                   d_status);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int lidiff_publish_words(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* host_mapped, int32_t seq,
+                         void* stream) {
+    LIDIFF_CHECK_ARG(words != nullptr && host_mapped != nullptr && n_words >= 0 && n_words <= 62, "up to 62 words");
+    publish_kernel<<<1, 64, 0, (hipStream_t)stream>>>(words, n_words, d_status, host_mapped, seq);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
 int lidiff_gather_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c, float* dst,
                        void* stream) {
     LIDIFF_CHECK_ARG(c > 0 && n_rows >= 0, "bad shape");
@@ -1458,22 +1502,12 @@ int lidiff_gather_bias_leaky(const float* src, const int64_t* idx, const float* 
 }
 
 int lidiff_gather_mul_rows(const float* x, const float* table, const int64_t* idx, int64_t n_rows, int32_t c,
-                           float* dst, void* stream) {
+                           float* dst, const int32_t* d_n_rows, void* stream) {
     LIDIFF_CHECK_ARG(c > 0 && c % 4 == 0 && n_rows >= 0, "c must be a positive multiple of 4");
     LIDIFF_CHECK_ARG((((uintptr_t)x | (uintptr_t)dst | (uintptr_t)table) & 15) == 0, "pointers must be 16-byte aligned");
     if (n_rows == 0) return 0;
     gather_mul_rows_kernel<<<(unsigned)ceil_div(n_rows * (c / 4), kBlock), kBlock, 0, (hipStream_t)stream>>>(
-        x, table, idx, n_rows, c / 4, dst);
-    LIDIFF_CHECK_LAUNCH();
-    return 0;
-}
-
-int lidiff_scatter_add_rows(const float* src, const int64_t* idx, int64_t n_rows, int32_t c,
-                            float* dst, void* stream) {
-    LIDIFF_CHECK_ARG(c > 0 && n_rows >= 0, "bad shape");
-    if (n_rows == 0) return 0;
-    scatter_add_rows_kernel<<<(unsigned)ceil_div(n_rows * c, kBlock), kBlock, 0, (hipStream_t)stream>>>(
-        src, idx, n_rows, c, dst);
+        x, table, idx, n_rows, d_n_rows, c / 4, dst);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -1529,19 +1563,6 @@ int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m,
     LIDIFF_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "rows must be 16-byte aligned float4");
     if (n == 0) return 0;
     return nn_match_launch<true>((const int32_t*)a, n, (const int32_t*)b, m, nullptr, idx, (hipStream_t)stream);
-}
-
-int lidiff_nn_match_grid(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
-                         const uint64_t* hkeys_part, const int32_t* hvals_part, int64_t cap_part, int32_t part_stride,
-                         const int32_t* d_max_coord, int64_t* idx, void* stream) {
-    LIDIFF_CHECK_ARG(m_part >= 1, "part tensor has no rows");
-    LIDIFF_CHECK_ARG(part_stride >= 1, "part_stride must be >= 1");
-    LIDIFF_CHECK_ARG(cap_part > 0 && (cap_part & (cap_part - 1)) == 0, "cap must be a power of two");
-    if (m_full == 0) return 0;
-    nn_match_grid_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, (hipStream_t)stream>>>(
-        full, m_full, part, m_part, hkeys_part, hvals_part, (uint32_t)(cap_part - 1), part_stride, d_max_coord, idx);
-    LIDIFF_CHECK_LAUNCH();
-    return 0;
 }
 
 int64_t lidiff_fps_workspace_bytes(int64_t n_points) {

@@ -1,5 +1,5 @@
-// Shared declarations of the sparse-convolution kernels (spconv.hip: tile kernels for every shape;
-// spconv_dense.hip: the one-wave-per-SIMD kernel of the dense 128-column layers).
+// Shared declarations of the sparse-convolution kernels (spconv.hip: tile kernels for every shape; spconv_rows.hip: one pair per
+// output row; spconv_bf16.hip: bf16 operands).
 #pragma once
 #include <type_traits>
 
@@ -27,6 +27,8 @@ struct ConvParams {
     const int32_t* tail_idx;
     int64_t tail_rows;          //   rows of `tail` per replica
     int64_t m_in, m_out;
+    const int32_t* d_m_out;     // nullable: the number of VALID output rows lives on the device (<= m_out, which stays the row
+                                //   pitch of nbr / of the stacked replicas and bounds the grid): tiles behind it leave at once
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
     int tiles_m, tiles_n, flags, replicas;
     int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
@@ -46,14 +48,15 @@ struct ConvParams {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
+// valid output rows of a launch: the device-side count when the caller's row count is only a bound (host-read-free steps)
+__device__ __forceinline__ int64_t valid_rows(const ConvParams& p) {
+    return p.d_m_out ? min((int64_t)*p.d_m_out, p.m_out) : p.m_out;
+}
+
 // weight gradient (spconv.hip, spconv_bf16.hip): pairs per chunk, pair slices per offset, the slice-ordered reduction
 constexpr int kDwPairs = 64;
 int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot);
 __global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n, int slices, float* __restrict__ dw);
-
-// spconv_dense.hip: can this convolution take the dense kernel / launch it.
-bool dense_kernel_applies(const ConvParams& p);
-int launch_fwd_dense(const ConvParams& p, hipStream_t st);
 
 // spconv_rows.hip: identity maps (kernel_size 1 / the centre pass) as a streaming row GEMM.
 bool rows_kernel_applies(const ConvParams& p);

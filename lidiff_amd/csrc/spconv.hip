@@ -127,7 +127,9 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     if (p.tail) p.tail += (int64_t)rep * p.tail_rows * p.c_out;
     const int64_t row0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
-    const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
+    const int64_t m_valid = valid_rows(p);       // == m_out unless the row count lives on the device (m_out: bound and pitch)
+    if (row0 >= m_valid) return;
+    const int rows_here = (int)min((int64_t)BM, m_valid - row0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
     if (p.nbr == nullptr) {                      // kernel_size == 1: identity map
         zero_tile();
         for (int r = tid; r < BM; r += NT) {
-            const int64_t gr = min(row0 + r, p.m_out - 1);
+            const int64_t gr = min(row0 + r, m_valid - 1);
             in_list[r] = p.row_order ? p.row_order[gr] : (int32_t)gr;
             out_list[r] = (OutT)(r < rows_here ? r * BN * 4 : kDummyRow);
         }
@@ -671,7 +673,8 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
                 float4 v = reinterpret_cast<const float4*>(acc_lds)[r * CQ + (cq ^ (r & (SWZ - 1)))];
                 if (p.tail) {                          // contributions computed elsewhere (the non-centre offsets), fixed order
                     const int orw = orow[r];
-                    for (int q = p.tail_ptr[orw], qe = p.tail_ptr[orw + 1]; q < qe; ++q) {
+                    // (qe clamped to the tail's rows: a no-op unless a bounded tail map overflowed -- then the step is redone)
+                    for (int q = p.tail_ptr[orw], qe = min(p.tail_ptr[orw + 1], (int)p.tail_rows); q < qe; ++q) {
                         const float4 s4 = *reinterpret_cast<const float4*>(p.tail + (int64_t)p.tail_idx[q] * p.c_out + col);
                         v.x += s4.x; v.y += s4.y; v.z += s4.z; v.w += s4.w;
                     }
@@ -786,7 +789,6 @@ extern "C" int32_t lidiff_spconv_fwd_kernel_id(int32_t c_in_a, int32_t c_in_b, i
     p.m_in = p.m_out = 1;
     if (!(flags & LIDIFF_CONV_TILE_ONLY) && rows_kernel_applies(p)) return 2;
     if (!(flags & LIDIFF_CONV_TILE_ONLY) && thin_kernel_applies(p)) return 3;
-    if ((flags & LIDIFF_CONV_DENSE_KERNEL) && dense_kernel_applies(p)) return 1;
     return 0;
 }
 
@@ -795,7 +797,8 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
                                  int64_t m_out, int32_t c_out, float* out, const float* ep_scale,
                                  const float* ep_shift, const float* residual, int32_t relu,
                                  const int32_t* row_order, int32_t replicas, int32_t flags, const float* tail,
-                                 const int32_t* tail_ptr, const int32_t* tail_idx, int64_t tail_rows, void* stream) {
+                                 const int32_t* tail_ptr, const int32_t* tail_idx, int64_t tail_rows,
+                                 const int32_t* d_m_out, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0, "in_a / c_in_a");
     LIDIFF_CHECK_ARG((tail == nullptr) == (tail_ptr == nullptr) && (tail == nullptr) == (tail_idx == nullptr),
                      "tail, tail_ptr and tail_idx must be all set or all null");
@@ -811,7 +814,7 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     p.in_a = in_a; p.in_b = in_b; p.wp = w_packed; p.nbr = nbr; p.row_order = row_order; p.out = out;
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.tail = tail; p.tail_ptr = tail_ptr; p.tail_idx = tail_idx; p.tail_rows = tail_rows;
-    p.m_in = m_in; p.m_out = m_out;
+    p.m_in = m_in; p.m_out = m_out; p.d_m_out = d_m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
     p.k_vol = k_vol; p.relu = relu; p.flags = flags; p.replicas = replicas; p.probe = g_conv_probe; p.timeline = g_conv_timeline;
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
@@ -826,9 +829,6 @@ extern "C" int lidiff_spconv_fwd(const float* in_a, int32_t c_in_a, const float*
     if (!(flags & LIDIFF_CONV_TILE_ONLY) && al16(in_a) && al16(in_b) && rows_kernel_applies(p)) return launch_fwd_rows(p, st);
     // inputs of <= 4 channels (the stems): nothing to multiply, a VALU kernel over the table
     if (!(flags & LIDIFF_CONV_TILE_ONLY) && thin_kernel_applies(p)) return launch_fwd_thin(p, st);
-    // dense 128-column layers: the software-pipelined kernel of spconv_dense.hip on request (bit-identical results,
-    // measured equal to the tile kernels below on the bench workload: DESIGN.md section 4.2)
-    if ((flags & LIDIFF_CONV_DENSE_KERNEL) && dense_kernel_applies(p)) return launch_fwd_dense(p, st);
     if (c_out % 128 == 0) return dispatch_fwd<128, 8, 1>(p, vec, st);
     if (c_out % 96 == 0) {
         // low-density maps: two 48-column tiles of 3 x 2 waves -- their packed stages hold 8 offsets (own W

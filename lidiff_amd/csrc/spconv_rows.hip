@@ -35,6 +35,8 @@ struct PairList {
     const int32_t* pair_in;     // input row of every pair, pairs grouped by offset
     const int32_t* pair_out;    // its output row (nullable: the pair's own position)
     const int32_t* offset_ptr;  // [k_vol + 1] pair ranges of the offsets
+    int64_t n_pairs;            // rows of pair_in / pair_out: offset ranges are clamped to it (a no-op unless the list is a
+                                //   bounded tail map that overflowed -- the caller then redoes the step, nothing is overrun)
 };
 
 template <int NJ, int NT16, bool GATHER>
@@ -49,10 +51,18 @@ __global__ __launch_bounds__(64 * kRowsWaves) void spconv_rows_kernel(const Conv
     const int nt0 = (GATHER ? blockIdx.y % tiles_n : blockIdx.y) * NT16;
     constexpr int NS = (NJ + 1) / 2;                       // 32-channel slabs of the packed weights
     int64_t seg_lo = 0, seg_hi = p.m_out * p.replicas;     // positions of this workgroup's offset
+    if constexpr (!GATHER) {
+        // row count on the device (m_out: bound and replica pitch): the replicas' valid rows are not contiguous any more, each
+        // replica is a grid slice of its own
+        if (p.d_m_out) {
+            seg_lo = (int64_t)blockIdx.z * p.m_out;
+            seg_hi = seg_lo + valid_rows(p);
+        }
+    }
     if constexpr (GATHER) {
         const int k = blockIdx.z, rep = blockIdx.y / tiles_n;
-        seg_lo = pl.offset_ptr[k];
-        seg_hi = pl.offset_ptr[k + 1];
+        seg_lo = min((int64_t)pl.offset_ptr[k], pl.n_pairs);
+        seg_hi = min((int64_t)pl.offset_ptr[k + 1], pl.n_pairs);
         p.wp += (int64_t)k * NS * nt16 * 512;
         p.in_a += (int64_t)rep * p.m_in * p.c_in_a;
         if (p.in_b) p.in_b += (int64_t)rep * p.m_in * p.c_in_b;
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void spconv_rows_kernel(const Conv
                     const int rep = (int)(row / p.m_out);
                     const int64_t rloc = row - (int64_t)rep * p.m_out;
                     const float* tb = p.tail + (int64_t)rep * p.tail_rows * p.c_out + col0;
-                    for (int q = p.tail_ptr[rloc], qe = p.tail_ptr[rloc + 1]; q < qe; ++q) {
+                    for (int q = p.tail_ptr[rloc], qe = min(p.tail_ptr[rloc + 1], (int)p.tail_rows); q < qe; ++q) {
                         const float* tr = tb + (int64_t)p.tail_idx[q] * p.c_out;
 #pragma unroll
                         for (int nt = 0; nt < NT16; ++nt) acc[nt] += *reinterpret_cast<const f32x4*>(tr + 16 * nt);
@@ -181,10 +191,13 @@ static int launch_rows(const ConvParams& p, const PairList& pl, int64_t n_pos, h
     const int64_t nblk = ceil_div(n_pos, 16);
     if (!GATHER) {
         // every wave the same number of 16-row blocks (+-1), with as many workgroups as the chip holds at once
-        const int64_t slots = max((int64_t)1, (int64_t)256 * per_cu / tiles_n) * kRowsWaves;
-        const int64_t per_wave = ceil_div(nblk, slots);
-        const unsigned gx = (unsigned)ceil_div(nblk, per_wave * kRowsWaves);
-        hipLaunchKernelGGL(kern, dim3(gx, (unsigned)tiles_n), dim3(64 * kRowsWaves), lds, st, p, pl);
+        // (row count on the device: one grid slice per replica, each sized for the bound)
+        const int reps_z = p.d_m_out ? p.replicas : 1;
+        const int64_t nblk_z = p.d_m_out ? ceil_div(p.m_out, 16) : nblk;
+        const int64_t slots = max((int64_t)1, (int64_t)256 * per_cu / (tiles_n * reps_z)) * kRowsWaves;
+        const int64_t per_wave = ceil_div(nblk_z, slots);
+        const unsigned gx = (unsigned)ceil_div(nblk_z, per_wave * kRowsWaves);
+        hipLaunchKernelGGL(kern, dim3(gx, (unsigned)tiles_n, (unsigned)reps_z), dim3(64 * kRowsWaves), lds, st, p, pl);
     } else {
         // the pair counts of the offsets live on the device: every offset gets the workgroups an even split would need
         // (x 2: a transposed stride-2 map is even, a tail map is not); a workgroup strides over its offset's blocks and
@@ -308,7 +321,7 @@ int launch_fwd_thin(const ConvParams& p, hipStream_t st) {
 }
 
 int launch_fwd_rows(const ConvParams& p, hipStream_t st) {
-    return dispatch_rows_nj<false>(p, PairList{nullptr, nullptr, nullptr}, p.m_out * p.replicas, st);
+    return dispatch_rows_nj<false>(p, PairList{nullptr, nullptr, nullptr, 0}, p.m_out * p.replicas, st);
 }
 
 }  // namespace lidiff
@@ -343,5 +356,5 @@ extern "C" int lidiff_spconv_fwd_pairs(const float* in_a, int32_t c_in_a, const 
     p.m_in = m_in; p.m_out = m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
     p.k_vol = k_vol; p.relu = relu; p.replicas = replicas;
-    return dispatch_rows_nj<true>(p, PairList{pair_in, pair_out, offset_ptr}, n_pairs, (hipStream_t)stream);
+    return dispatch_rows_nj<true>(p, PairList{pair_in, pair_out, offset_ptr, n_pairs}, n_pairs, (hipStream_t)stream);
 }

@@ -121,6 +121,11 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
     nbr, _, ts_out, _ = conv.maps(x)
     mgr = x.coordinate_manager
     m_out = mgr.maps[ts_out].coords.shape[0]
+    # host-read-free maps (DiffCompletion.read_free): m_out is the BOUND of the rows, d_rows their count on the device; every
+    # kernel CHOICE below is made from rows the host believes (mgr.rows: the same level of the role's previous pyramid)
+    d_rows, free = mgr.count(ts_out), mgr.count(ts_out) is not None
+    rows_out = mgr.rows(ts_out)
+    hints = dict(d_rows=d_rows, rows_hint=rows_out, in_rows_hint=mgr.rows(x.tensor_stride)) if (free or mgr.hint_lag) else {}
     order = None
     if nbr is not None and _ORDERED_TILES:
         nbr, order = mgr.kernel_map_ordered(x.tensor_stride, ts_out, conv.kernel_size, conv.transposed)
@@ -133,20 +138,24 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
             if ops.pairs_kernel_applies(x.F.shape[1], 0 if extra is None else extra.shape[1], conv.out_channels):
                 pin, pout, off = mgr.up_pairs(x.tensor_stride, ts_out)       # one pair per output row: the streaming row kernel
                 f = ops.spconv_fwd_pairs(x.F, conv.kernel, pin, pout, off, m_out, in_b=extra, scale=scale, shift=shift,
-                                         residual=residual, relu=relu, replicas=x.replicas)
+                                         residual=residual, relu=relu, replicas=x.replicas,
+                                         rows_hint=hints.get("rows_hint"), in_rows_hint=hints.get("in_rows_hint"))
                 out = ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
                 out.replicas = x.replicas
                 return out
     # centre + tail only on really isolated voxels (<= ~2 neighbours each: the 128-column rule of is_sparse_map); the wider
     # hint of the narrow tiles keeps the one-launch kernel with packed stages (3.6 neighbours per voxel: 429 vs 495 us)
     # (not for the 3-channel stem: the thin-input kernel walks the whole table in one launch)
-    if (_CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and m_out >= 1024
-            and x.F.shape[1] > 4 and mgr.is_sparse_map(ts_out, ts_out, 3)):
+    if (_CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and rows_out >= 1024
+            and x.F.shape[1] > 4 and mgr.is_sparse_map(ts_out, ts_out, 3)
+            and (not free or ops.pairs_kernel_applies(x.F.shape[1], 0 if extra is None else extra.shape[1], conv.out_channels))):
+        if hints:
+            hints["tail_hint"] = mgr.tail_rows(ts_out)
         f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
-                                   residual=residual, relu=relu, replicas=x.replicas)
+                                   residual=residual, relu=relu, replicas=x.replicas, **hints)
     else:
         f = ops.spconv_fwd(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift,
-                           residual=residual, relu=relu, sparse_map=hint, replicas=x.replicas, row_order=order)
+                           residual=residual, relu=relu, sparse_map=hint, replicas=x.replicas, row_order=order, **hints)
     out = ME.SparseTensor(f, tensor_stride=ts_out, coordinate_manager=mgr)
     out.replicas = x.replicas
     return out
@@ -311,7 +320,7 @@ class MinkGlobalEnc(_Base):
         x = _run_stem(self.stem, x.sparse())
         for n in (1, 2, 3, 4):
             x = getattr(self, f"stage{n}")(x)
-        return x
+        return x.exact_view()      # (a no-op unless the field's maps were built without a host read: DiffCompletion.read_free)
 
 
 # level name -> (channels multiplied by w, hidden width of latemp); order of minkunet.py:420-495
@@ -416,7 +425,8 @@ class MinkUNetDiff(_Base):
             return hit[1]
         # exhaustive scan: on the noisy x_t of the bench workload (sigma up to 1 m, many voxels far from every part voxel)
         # it beats the lattice-shell search of lidiff_nn_match_grid (0.44 vs 1.1 ms at 180k x 5.8k rows)
-        idx = ops.nn_match(x_full.C, x_part.C)
+        d_full = x_full.coordinate_manager.count(x_full.tensor_stride)
+        idx = ops.nn_match(x_full.C, x_part.C) if d_full is None else ops.nn_match_dev(x_full.C, d_full, x_part.C)
         done = None
         if ahead:                                              # the consumer's stream joins when it first asks (above)
             done = torch.cuda.Event()
@@ -519,10 +529,12 @@ class MinkUNetDiff(_Base):
                     table = tables[lo:lo + q.F.shape[0]]
                     lo += q.F.shape[0]
                     rows = slice(r * m, (r + 1) * m)
-                    if table.shape[0] == 1:
+                    d_rows = x.coordinate_manager.count(x.tensor_stride)
+                    if table.shape[0] == 1 and d_rows is None:
                         torch.mul(x.F[rows], table, out=out[rows])
-                    else:
-                        ops.gather_mul_rows(x.F[rows], table, self.match_index(x, q), out=out[rows])
+                    else:           # (one part row: a broadcast of it -- the same products as torch.mul)
+                        ops.gather_mul_rows(x.F[rows], table, None if table.shape[0] == 1 else self.match_index(x, q), out=out[rows],
+                                            d_rows=d_rows)
                 return x._like(out)
             hidden = torch.empty((x.F.shape[0], lin2.in_features), dtype=torch.float32, device=x.F.device)
             for r, q in enumerate(parts):

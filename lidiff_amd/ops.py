@@ -16,6 +16,7 @@ from ._lib import call, ptr, require_device, stream_ptr
 
 STATUS_KEY_RANGE = 1
 STATUS_HASH_FULL = 2
+STATUS_BOUND = 4          # a device-side count exceeded the bound a buffer was sized for (host-read-free steps)
 
 
 class HashTable:
@@ -97,11 +98,109 @@ _PINNED: dict = {}
 class Pyramid:
     """What build_pyramid() hands over: per level the coordinate rows, hash table and (levels >= 1) the parent array of the
     finer level; for the first `tail_levels` levels also the kernel_size-3 self map and the phase-1 state of its tail map."""
-    __slots__ = ("coords", "tables", "parents", "inverse", "first_idx", "nbr3", "tails")
+    __slots__ = ("coords", "tables", "parents", "inverse", "first_idx", "nbr3", "tails", "counts", "bound")
+
+
+# pair bound of a tail map built without a host read, per row of the map's bound: centre + tail is only chosen for maps with at
+# most ~2 non-centre neighbours per voxel (CoordinateManager.is_sparse_map), so 3 per POINT is generous; a map that exceeds it
+# raises STATUS_BOUND on the device and the step is redone with exact sizes
+TAIL_PAIR_BOUND = 3
+
+
+class SizeFeed:
+    """Host-visible sizes of the coordinate pyramids of one ROLE in a denoising loop (x_t / condition / unconditional), one
+    record per pyramid in build order.  A pyramid built with a host read pushes its sizes directly; a pyramid built WITHOUT one
+    (build_pyramid(read_free=True)) has the device write them into pinned, device-mapped memory (lidiff_publish_words) -- no
+    device->host copy, no synchronisation: the host polls the record's sequence number when it next needs the sizes, which is
+    one step later (kernel-choice hints and the validation of the bounds it sized buffers by)."""
+    SLOTS = 8
+    WORDS = 64
+
+    def __init__(self, device):
+        self.device = device
+        self.ring = torch.zeros((self.SLOTS, self.WORDS), dtype=torch.int32).pin_memory()
+        self.view = self.ring.numpy()
+        self.seq = 0                 # records announced so far
+        self.seq_base = 0            # records before this one belong to an earlier scan (reset())
+        self.done = {}               # seq -> (status, [sizes]) read back or pushed
+        self.n_words = {}
+        self.checks = {}             # seq -> {level: rows the host took as exact}
+        self.bad = None              # first failed validation (message), sticky until reset()
+
+    def reset(self):
+        """Forget every record (a new scan: its first pyramid is built with a host read again)."""
+        self.drain()
+        self.done.clear()
+        self.checks.clear()
+        self.seq_base = self.seq
+        self.bad = None
+
+    def has_records(self) -> bool:
+        return self.seq > self.seq_base
+
+    def expect(self, seq: int, exact_rows: dict):
+        self.checks[seq] = dict(exact_rows)
+
+    def drain(self):
+        """Read every record the device still owes (end of a loop: all checks done).  Returns self.bad."""
+        for seq in sorted(self.n_words):
+            self.get(seq)
+        return self.bad
+
+    def _check(self, seq, status, sizes):
+        exact = self.checks.pop(seq, {})
+        if self.bad is not None:
+            return
+        if status & STATUS_BOUND:
+            self.bad = f"record {seq}: a device-side count exceeded its bound (status {status})"
+        for lv, rows in exact.items():
+            if sizes[lv] != rows:
+                self.bad = f"record {seq}: level {lv} has {sizes[lv]} rows, the host took {rows} as exact"
+
+    def push_host(self, sizes, status: int = 0):
+        self.seq += 1
+        self.done[self.seq] = (int(status), [int(v) for v in sizes])
+        self._trim()
+        return self.seq
+
+    def publish(self, counts: torch.Tensor, status: torch.Tensor | None):
+        """Queue the device-side write of `counts` (int32 [k]) and *status into this feed's next record."""
+        self.seq += 1
+        slot = self.ring[self.seq % self.SLOTS]
+        if self.seq - self.SLOTS in self.n_words and self.seq - self.SLOTS not in self.done:
+            self.get(self.seq - self.SLOTS)            # the slot's previous record has not been consumed yet: do it now
+        self.n_words[self.seq] = counts.numel()
+        call("lidiff_publish_words", ptr(counts), counts.numel(), ptr(status), slot.data_ptr(), self.seq, stream_ptr())
+        return self.seq
+
+    def get(self, seq: int | None = None, timeout_s: float = 30.0):
+        """(status, sizes) of record `seq` (default: the latest); waits for the device if it has not written it yet."""
+        seq = self.seq if seq is None else seq
+        hit = self.done.get(seq)
+        if hit is not None:
+            return hit
+        if seq not in self.n_words:
+            raise KeyError(f"size record {seq} is gone")
+        import time
+        row = self.view[seq % self.SLOTS]
+        t0 = time.perf_counter()
+        while int(row[0]) != seq:                      # the device has not got there yet (plain memory reads, no HIP call)
+            if time.perf_counter() - t0 > timeout_s:
+                raise RuntimeError("SizeFeed: the device never published record %d" % seq)
+            time.sleep(0)
+        n = self.n_words.pop(seq)
+        hit = self.done[seq] = (int(row[1]), [int(v) for v in row[2:2 + n]])
+        self._check(seq, *hit)
+        self._trim()
+        return hit
+
+    def _trim(self):
+        for k in [k for k in self.done if k <= self.seq - 2 * self.SLOTS]:
+            del self.done[k]
 
 
 def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, tail_levels: int = 2,
-                  second_stream=None, on_level_dev=None) -> Pyramid:
+                  second_stream=None, on_level_dev=None, feed: "SizeFeed | None" = None, read_free: bool = False) -> Pyramid:
     """Voxelise int32 coords [N, 4] (vox_unique), the `strides` strided maps below it (map_stride, tensor strides 2, 4, ...),
     and for the first `tail_levels` levels the kernel_size-3 map onto itself plus the COUNT phase of its tail map -- all queued
     back to back on the current stream with every row count staying on the device (the *_dev entry points), followed by
@@ -112,7 +211,12 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     two halves overlap almost completely; the current stream joins before the read.
     on_level_dev(lv, rows_bound, d_count) (only with second_stream): called for every level under second_stream, BEHIND the event
     the read waits for -- work that needs a level's coordinates but not its size on the host (DiffCompletion: the part -> full
-    matches, lidiff_nn_match_dev) runs there while the host is still blocked in the read."""
+    matches, lidiff_nn_match_dev) runs there while the host is still blocked in the read.
+    feed: a SizeFeed that receives this pyramid's sizes -- from the host read, or (read_free) from the device itself.
+    read_free: NO host read.  Every level is handed over at its BOUND (the point count: coords [n, 4], tables of pitch n, tail
+    maps pending with a pair bound) together with the device-side counts (Pyramid.counts); the sizes reach the host through
+    `feed` (lidiff_publish_words) while later work is already queued.  The caller passes the counts on to every consumer
+    (d_rows of spconv_fwd, ...), decides kernel choices from the sizes of an EARLIER pyramid and checks feed.validate() later."""
     require_device(coords, status)
     assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
     coords = coords.contiguous()
@@ -185,6 +289,19 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     if second_stream is not None:
         cur.wait_event(joined)
     _trace("tails queued")
+    if read_free:
+        assert feed is not None
+        feed.publish(counts, status)
+        out = Pyramid()
+        out.counts, out.bound = counts, n
+        out.coords = rows
+        out.tables, out.inverse, out.first_idx = tables, inverse, first_idx
+        out.parents = parents
+        out.nbr3 = [t[0] for t in tails]
+        out.tails = [TailMap(None, bounded=(nbr, n, counts[lv:lv + 1], ws, off, row_ptr, TAIL_PAIR_BOUND * n, status))
+                     for lv, (nbr, ws, off, row_ptr) in enumerate(tails)]
+        _trace("done")
+        return out
     # THE host read of this pyramid: into a pinned buffer, the host spinning on an event query (torch's tolist() goes through a
     # pageable staging copy and a blocking synchronise: ~0.1 ms later at the next launch; LIDIFF_PINNED_READ=0 keeps that form)
     if PINNED_READ:
@@ -200,7 +317,10 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     else:
         host = counts.tolist()
     _trace("sizes read")
+    if feed is not None:
+        feed.push_host(host)
     out = Pyramid()
+    out.counts, out.bound = counts, n
     out.coords = [rows[lv][:host[lv]] for lv in range(strides + 1)]
     out.tables, out.inverse, out.first_idx = tables, inverse, first_idx[:host[0]]
     out.parents = [None] + [parents[lv][:host[lv - 1]] for lv in range(1, strides + 1)]
@@ -249,6 +369,38 @@ def kernel_map(out_coords: torch.Tensor, in_table: HashTable, ks: int, step: int
     return nbr
 
 
+def kernel_map_self_dev(coords_bound: torch.Tensor, d_rows: torch.Tensor, table: HashTable, step: int) -> torch.Tensor:
+    """kernel_map(self_map=True) of a map whose row count lives on the device: coords_bound [n, 4] (the first d_rows[0] rows
+    valid) -> nbr [27, n], columns behind the count -1."""
+    require_device(coords_bound, d_rows)
+    n = coords_bound.shape[0]
+    nbr = torch.empty((27, n), dtype=torch.int32, device=coords_bound.device)
+    call("lidiff_kernel_map_self_dev", ptr(coords_bound), n, ptr(d_rows), ptr(table.keys), ptr(table.vals), table.cap, int(step),
+         ptr(nbr), stream_ptr())
+    return nbr
+
+
+def kernel_map_down_dev(fine_bound: torch.Tensor, parent_bound: torch.Tensor, d_rows_fine: torch.Tensor, ts_fine: int,
+                        m_coarse_bound: int) -> torch.Tensor:
+    """kernel_map_down with the fine map's row count on the device -> nbr [8, m_coarse_bound]."""
+    require_device(fine_bound, parent_bound, d_rows_fine)
+    assert parent_bound.dtype == torch.int32 and parent_bound.shape[0] == fine_bound.shape[0] and fine_bound.is_contiguous()
+    nbr = torch.empty((8, m_coarse_bound), dtype=torch.int32, device=fine_bound.device)
+    call("lidiff_kernel_map_down_dev", ptr(fine_bound), ptr(parent_bound), fine_bound.shape[0], ptr(d_rows_fine), int(ts_fine),
+         int(m_coarse_bound), ptr(nbr), stream_ptr())
+    return nbr
+
+
+def kernel_map_up_dev(fine_bound: torch.Tensor, parent_bound: torch.Tensor, d_rows_fine: torch.Tensor, ts_fine: int) -> torch.Tensor:
+    """kernel_map_up with the row count on the device -> nbr [8, n], columns behind the count -1."""
+    require_device(fine_bound, parent_bound, d_rows_fine)
+    assert fine_bound.is_contiguous()
+    n = fine_bound.shape[0]
+    nbr = torch.empty((8, n), dtype=torch.int32, device=fine_bound.device)
+    call("lidiff_kernel_map_up_dev", ptr(fine_bound), ptr(parent_bound), n, ptr(d_rows_fine), int(ts_fine), ptr(nbr), stream_ptr())
+    return nbr
+
+
 def kernel_map_down(fine_coords: torch.Tensor, parent: torch.Tensor, ts_fine: int, m_coarse: int) -> torch.Tensor:
     """The ks=2 / stride-2 table nbr[8, M_coarse] of a strided convolution (minkunet.py:13-29) from the parent array of
     map_stride -- the table kernel_map(coarse, fine table, 2, ts_fine) builds, without a lookup."""
@@ -282,10 +434,13 @@ def tile_order(coords: torch.Tensor, ts: int) -> torch.Tensor:
     return torch.argsort(keys).to(torch.int32)
 
 
-def rulebook_compact(nbr: torch.Tensor, total: int | None = None):
+def rulebook_compact(nbr: torch.Tensor, total: int | None = None, bounded: bool = False):
     """ME-layout rulebook from a neighbour table: (pairs_in, pairs_out, offset_ptr[K+1]) -- pairs sorted by kernel offset,
     then by output row.  total: the number of pairs when the caller knows it (e.g. a transposed kernel_size-2 / stride-2 map
-    has exactly one pair per output row) -- one pass, no host read; otherwise a counting pass, one read of the total, a fill pass."""
+    has exactly one pair per output row) -- one pass, no host read; otherwise a counting pass, one read of the total, a fill pass.
+    bounded (with total = the table's columns): a one-pair-per-row map whose valid columns are a device-side prefix of the table
+    (the rest -1): the lists get `total` entries of which the first offset_ptr[K] are the pairs; pairs_out is completed to a
+    PERMUTATION of the rows (the rows without a pair keep their own position), pairs_in behind the pairs is row 0."""
     require_device(nbr)
     k, m = nbr.shape
     dev = nbr.device
@@ -294,8 +449,13 @@ def rulebook_compact(nbr: torch.Tensor, total: int | None = None):
     if total is None:
         call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), None, None, ptr(ws), stream_ptr())
         total = int(off[-1].item())
-    pin = torch.empty(total, dtype=torch.int32, device=dev)
-    pout = torch.empty(total, dtype=torch.int32, device=dev)
+    if bounded:
+        assert total == m
+        pin = torch.zeros(total, dtype=torch.int32, device=dev)
+        pout = torch.arange(total, dtype=torch.int32, device=dev)
+    else:
+        pin = torch.empty(total, dtype=torch.int32, device=dev)
+        pout = torch.empty(total, dtype=torch.int32, device=dev)
     call("lidiff_rulebook_compact", ptr(nbr), k, m, ptr(off), ptr(pin), ptr(pout), ptr(ws), stream_ptr())
     return pin, pout, off
 
@@ -430,9 +590,6 @@ def layer_table(prof: "ConvProfiler", steps: int = 1):
 PROFILER: ConvProfiler | None = None
 # weight gradients: pair slices summed in slice order through a workspace (bit-reproducible); False = fp32 atomics
 DETERMINISTIC_DW = True
-# Kernel choice for the dense 128-column layers: "tile" (spconv.hip, default), "dense" (spconv_dense.hip, eight waves),
-# "dense1" (its four-wave form).  Results are bit-identical; DESIGN.md section 4.2 has the measurements.
-DENSE_KERNEL = os.environ.get("LIDIFF_CONV_KERNEL", "tile")
 # extra lidiff_spconv_fwd flag bits (include/lidiff_amd.h LIDIFF_CONV_*), e.g. 8 = LIDIFF_CONV_TILE_ONLY
 CONV_FLAGS = int(os.environ.get("LIDIFF_CONV_FLAGS", "0"))
 
@@ -493,7 +650,8 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
                in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None,
                relu: bool = False, sparse_map: bool = False, replicas: int = 1,
                row_order: torch.Tensor | None = None, kernel: str | None = None, tail=None,
-               offset: int | None = None) -> torch.Tensor:
+               offset: int | None = None, d_rows: torch.Tensor | None = None, rows_hint: int | None = None,
+               in_rows_hint: int | None = None) -> torch.Tensor:
     """Sparse convolution forward with fused epilogue (MinkowskiConvolution[Transpose];
     minkunet.py:17,36,53,61,72).  w: [K, C_in, C_out] ([C_in, C_out] accepted for K == 1).  sparse_map: hint that
     the kernel map has only a few pairs per offset and 128-row tile (CoordinateManager.is_sparse_map).
@@ -501,14 +659,16 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     [R * M_in, C], the result [R * m_out, C_out].
     row_order: int32 permutation of the output rows (tile_order()); `nbr` must then hold its columns in that
     order (nbr[:, row_order]).  Results do not depend on it.
-    kernel: "tile" | "dense" | "dense1" (default: DENSE_KERNEL) -- which kernel runs a dense 128-column layer;
-    "tile_only" keeps identity maps off the row kernel (spconv_rows.hip) as well; "tile128" keeps 64-column layers on 128-row
+    kernel: "tile_only" keeps identity maps off the row kernel (spconv_rows.hip); "tile128" keeps 64-column layers on 128-row
     tiles (large maps take 256-row tiles by default).
+    d_rows: int32 [1] on the device -- the number of VALID output rows when m_out is only their bound (a step without host reads):
+    m_out still shapes the result, the table's pitch and the replica pitch; tiles behind the count leave at once.  rows_hint: the
+    row count the host BELIEVES (an earlier step's): it alone picks the tile size where the bound would pick another one.
     offset: convolve with the single kernel offset w[offset] over the identity map (nbr must be None): the centre of a
     kernel_size-3 map.  tail = (rows [R * P, C_out], ptr int32 [m_out + 1], idx int32 [P]): rows added to the sum before
     the epilogue, out[o] += sum(rows[idx[ptr[o]:ptr[o + 1]]]) -- the other offsets' contributions (TailMap)."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
-    if (SPLIT_PLANES and not sparse_map and row_order is None and tail is None and offset is None
+    if (SPLIT_PLANES and not sparse_map and row_order is None and tail is None and offset is None and d_rows is None
             and bf16_conv_applies(in_a.shape[1], 0 if in_b is None else in_b.shape[1], w.shape[-1])
             and w.shape[-1] % SPLIT_MIN_COUT == 0):
         return spconv_fwd_bf16(in_a, w, nbr, m_out, in_b=in_b, scale=scale, shift=shift, residual=residual, relu=relu,
@@ -546,7 +706,9 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert t_rows.shape == (replicas * n_tail, c_out) and t_rows.is_contiguous() and t_rows.dtype == torch.float32
         assert t_ptr.dtype == torch.int32 and t_ptr.shape == (m_out + 1,) and t_idx.dtype == torch.int32
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
-    flags = int(bool(sparse_map)) | {"tile": 0, "dense": 2, "dense1": 6, "tile_only": 8, "tile128": 16}[kernel or DENSE_KERNEL] | CONV_FLAGS
+    flags = int(bool(sparse_map)) | {"tile": 0, "tile_only": 8, "tile128": 16}[kernel or "tile"] | CONV_FLAGS
+    if rows_hint is not None and rows_hint * replicas < 256 * 512:
+        flags |= 16                 # the exact-size path would keep 128-row tiles for this map: the same choice under a bound
     prof = PROFILER
     variant = None
     if prof is not None:
@@ -560,11 +722,13 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         start.record()
     call("lidiff_spconv_fwd", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), ptr(nbr), k, m_in, m_out,
          c_out, ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(row_order), int(replicas), flags,
-         ptr(t_rows), ptr(t_ptr), ptr(t_idx), n_tail, stream_ptr())
+         ptr(t_rows), ptr(t_ptr), ptr(t_idx), n_tail, ptr(d_rows), stream_ptr())
     if timed:
         end.record()
     if prof is not None:
-        prof.launches.append((variant, start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
+        # (algorithmic bytes of a launch under a bound: from the rows the host believes, not from the bound)
+        prof.launches.append((variant, start, end, m_in if in_rows_hint is None else int(in_rows_hint),
+                              m_out if rows_hint is None else int(rows_hint), c_in, c_out, k, nbr, replicas))
     return out
 
 
@@ -718,7 +882,8 @@ def pairs_kernel_applies(c_a: int, c_b: int, c_out: int) -> bool:
 
 def spconv_fwd_pairs(in_a: torch.Tensor, w: torch.Tensor, pair_in: torch.Tensor, pair_out: torch.Tensor | None,
                      offset_ptr: torch.Tensor, m_out: int, in_b: torch.Tensor | None = None, scale=None, shift=None,
-                     residual=None, relu: bool = False, replicas: int = 1) -> torch.Tensor:
+                     residual=None, relu: bool = False, replicas: int = 1, rows_hint: int | None = None,
+                     in_rows_hint: int | None = None) -> torch.Tensor:
     """Sparse convolution over a map in which every output row has exactly ONE pair, given as a pair list grouped by kernel
     offset (lidiff_spconv_fwd_pairs; include/lidiff_amd.h): out[pair_out[p]] = epilogue(in[pair_in[p]] @ w[offset of p]),
     offset_ptr [K + 1] the pair ranges of the offsets; pair_out None = one output row per pair, in list order (then m_out ==
@@ -754,7 +919,8 @@ def spconv_fwd_pairs(in_a: torch.Tensor, w: torch.Tensor, pair_in: torch.Tensor,
     if timed:
         end.record()
     if prof is not None:
-        prof.launches.append(("rows", start, end, m_in, m_out, c_in, c_out, k, None, replicas))
+        prof.launches.append(("rows", start, end, m_in if in_rows_hint is None else int(in_rows_hint),
+                              m_out if rows_hint is None else int(rows_hint), c_in, c_out, k, None, replicas))
     return out
 
 
@@ -996,22 +1162,26 @@ def gather_bias_leaky(src: torch.Tensor, idx: torch.Tensor, bias: torch.Tensor, 
     return out
 
 
-def gather_mul_rows(x: torch.Tensor, table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor | None = None):
+def gather_mul_rows(x: torch.Tensor, table: torch.Tensor, idx: torch.Tensor | None, out: torch.Tensor | None = None,
+                    d_rows: torch.Tensor | None = None):
     """x * table[idx] in one pass (the conditioning multiply of minkunet.py:431 etc. with its MLP evaluated on the
-    part rows).  `out`: optional destination of x's shape (may be a row slice of a larger buffer)."""
-    require_device(x, table, idx)
-    x, table, idx = x.contiguous(), table.contiguous(), idx.contiguous()
+    part rows).  `out`: optional destination of x's shape (may be a row slice of a larger buffer).  idx None: every row takes
+    table row 0 (a broadcast).  d_rows: int32 [1], the valid rows when x's row count is only a bound."""
+    require_device(x, table, idx, d_rows)
+    x, table = x.contiguous(), table.contiguous()
     n, c = x.shape
-    assert table.shape[1] == c and idx.shape[0] == n and idx.dtype == torch.int64
+    assert table.shape[1] == c
+    if idx is not None:
+        idx = idx.contiguous()
+        assert idx.shape[0] == n and idx.dtype == torch.int64
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=x.device)
     assert out.shape == (n, c) and out.is_contiguous()
-    call("lidiff_gather_mul_rows", ptr(x), ptr(table), ptr(idx), n, c, ptr(out), stream_ptr())
+    call("lidiff_gather_mul_rows", ptr(x), ptr(table), ptr(idx), n, c, ptr(out), ptr(d_rows), stream_ptr())
     return out
 
 
-# scatter-adds (the backward of row gathers) as segment sums over a destination-sorted source list: deterministic, no atomics
-DETERMINISTIC_SCATTER = os.environ.get("LIDIFF_DETERMINISTIC_SCATTER", "1") != "0"
+# scatter-adds (the backward of row gathers) run as segment sums over a destination-sorted source list: deterministic, no atomics
 
 
 def _scatter_csr(idx: torch.Tensor, m: int):
@@ -1034,7 +1204,7 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
     """dst[idx[i]] += src[i] over the rows i (dst [m, C]): the backward of gather_rows."""
     src = src.contiguous()
     n, c = src.shape
-    if DETERMINISTIC_SCATTER and n > 0:
+    if n > 0:
         order, ptr_ = _scatter_csr(idx.contiguous(), m)
         dst = torch.empty((m, c), dtype=torch.float32, device=src.device)
         # destinations with > 64 sources (the unconditional training branch: ~180 000 rows gathered from each of 2 part voxels)
@@ -1042,9 +1212,7 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
         work = torch.empty(_lib.load().lidiff_segment_sum_workspace_bytes(n, c), dtype=torch.uint8, device=src.device)
         call("lidiff_segment_sum_rows", ptr(src), ptr(order), ptr(ptr_), m, c, ptr(dst), n, ptr(work), stream_ptr())
         return dst
-    dst = torch.zeros((m, c), dtype=torch.float32, device=src.device)
-    call("lidiff_scatter_add_rows", ptr(src), ptr(idx.contiguous()), n, c, ptr(dst), stream_ptr())
-    return dst
+    return torch.zeros((m, c), dtype=torch.float32, device=src.device)
 
 
 FPS_COOPERATIVE = os.environ.get("LIDIFF_FPS_COOPERATIVE", "1") != "0"
@@ -1145,22 +1313,15 @@ def nn_dist(a: torch.Tensor, b: torch.Tensor):
     return d2, idx
 
 
-def nn_match(full_c: torch.Tensor, part_c: torch.Tensor, part_table: HashTable | None = None,
-             part_stride: int = 0) -> torch.Tensor:
-    """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416).  With the part map's hash table and
-    tensor stride the search walks lattice shells around every row instead of scanning all part rows (same result)."""
+def nn_match(full_c: torch.Tensor, part_c: torch.Tensor) -> torch.Tensor:
+    """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416): exhaustive scan of the part rows."""
     require_device(full_c, part_c)
     full_c = full_c.contiguous()
     part_c = part_c.contiguous()
     assert full_c.dtype == torch.int32 and part_c.dtype == torch.int32
     max_coord = full_c.max().to(torch.int32).reshape(1)
     idx = torch.empty(full_c.shape[0], dtype=torch.int64, device=full_c.device)
-    if part_table is not None and part_stride >= 1 and part_c.shape[0] > 64:
-        call("lidiff_nn_match_grid", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(part_table.keys),
-             ptr(part_table.vals), part_table.cap, int(part_stride), ptr(max_coord), ptr(idx), stream_ptr())
-    else:
-        call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord),
-             ptr(idx), stream_ptr())
+    call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord), ptr(idx), stream_ptr())
     return idx
 
 
@@ -1199,9 +1360,17 @@ class TailMap:
       ptr [M + 1], idx [P]   CSR over the map's output rows: the pairs landing on output row o, in ascending offset.
     Built once per coordinate map from its neighbour table (shared by every convolution on the map)."""
 
-    def __init__(self, nbr: torch.Tensor | None, phase1=None):
+    bounded = False
+
+    def __init__(self, nbr: torch.Tensor | None, phase1=None, bounded=None):
         if phase1 is not None:          # build_pyramid(): counts taken with the row count on the device, size already read
             self._from_phase1(*phase1)
+            return
+        if bounded is not None:         # ... and never read: the pair count stays on the device, `n` is its bound
+            nbr_bound, m_bound, d_m, ws, off, row_ptr, n_bound, status = bounded
+            self.bounded, self.n, self.off, self.ptr = True, int(n_bound), off, row_ptr
+            self.nbr = self.idx = self.pair_in = None
+            self._pending = (nbr_bound, m_bound, d_m, ws, row_ptr, status)
             return
         require_device(nbr)
         k, m = nbr.shape
@@ -1221,6 +1390,22 @@ class TailMap:
                  ptr(ws), stream_ptr())
             self.pair_in = self.nbr.amax(0)                              # the pair list form of the same map (one entry per column)
 
+    @classmethod
+    def on_device(cls, nbr_bound: torch.Tensor, d_m: torch.Tensor, status: torch.Tensor, n_bound: int | None = None):
+        """The tail map of a kernel map whose row count lives on the device (nbr_bound [27, m_bound], columns behind the count
+        -1): counting phase now, the pair lists (bounded by n_bound pairs, default TAIL_PAIR_BOUND per row of the bound) when
+        fill() is called; no host read at all."""
+        require_device(nbr_bound, d_m, status)
+        k, m_bound = nbr_bound.shape
+        assert k == 27 and nbr_bound.dtype == torch.int32 and nbr_bound.is_contiguous()
+        dev = nbr_bound.device
+        ws = torch.empty(_lib.load().lidiff_tail_map_workspace_bytes(k, m_bound), dtype=torch.uint8, device=dev)
+        off = torch.empty(k + 1, dtype=torch.int32, device=dev)
+        row_ptr = torch.empty(m_bound + 1, dtype=torch.int32, device=dev)
+        call("lidiff_tail_map_dev", ptr(nbr_bound), k, m_bound, ptr(d_m), 13, ptr(off), ptr(row_ptr), 0, None, None, ptr(ws), stream_ptr())
+        return cls(None, bounded=(nbr_bound, m_bound, d_m, ws, off, row_ptr,
+                                  TAIL_PAIR_BOUND * m_bound if n_bound is None else n_bound, status))
+
     def _from_phase1(self, nbr_bound, m_bound, d_m, ws, off, row_ptr, n, m):
         """Phase 2 over the table of pitch m_bound whose phase 1 ran in build_pyramid(); filled when first asked for."""
         self.n, self.off, self.ptr = int(n), off, row_ptr[:m + 1]
@@ -1230,7 +1415,15 @@ class TailMap:
     def fill(self):
         """The pair arrays (nbr / idx / pair_in) of a map that came out of build_pyramid(): no host read (n is known)."""
         pend = getattr(self, "_pending", None)
-        if pend is not None:
+        if pend is not None and self.bounded:
+            nbr_bound, m_bound, d_m, ws, row_ptr, status = pend
+            dev = nbr_bound.device
+            self.pair_in = torch.empty(self.n, dtype=torch.int32, device=dev)
+            self.idx = torch.empty(self.n, dtype=torch.int32, device=dev)
+            call("lidiff_tail_map_fill_bounded", ptr(nbr_bound), 27, m_bound, ptr(d_m), 13, ptr(self.off), ptr(row_ptr), self.n,
+                 ptr(self.pair_in), ptr(self.idx), ptr(status), ptr(ws), stream_ptr())
+            self._pending = None
+        elif pend is not None:
             nbr_bound, m_bound, d_m, ws, row_ptr = pend
             dev = nbr_bound.device
             self.nbr = torch.empty((27, self.n), dtype=torch.int32, device=dev)
@@ -1249,12 +1442,15 @@ def spconv_centre_tail(in_a, w, tmap: TailMap, m_out, **kw):
     offsets multiplied offset by offset (weight stationary) into one row per pair, then the centre offset as a dense pass
     over contiguous rows that adds those rows through the map's CSR in its epilogue.  Same arguments as spconv_fwd."""
     replicas = kw.get("replicas", 1)
+    tail_hint = kw.pop("tail_hint", None)           # the pair count the host believes (bounded maps: for the profiler only)
     tail = None
     if tmap.n > 0:
         in_b = kw.get("in_b")
         if pairs_kernel_applies(in_a.shape[1], 0 if in_b is None else in_b.shape[1], w.shape[-1]):
-            rows = spconv_fwd_pairs(in_a, w, tmap.pair_in, None, tmap.off, tmap.n, in_b=in_b, replicas=replicas)
+            rows = spconv_fwd_pairs(in_a, w, tmap.pair_in, None, tmap.off, tmap.n, in_b=in_b, replicas=replicas,
+                                    rows_hint=tail_hint, in_rows_hint=kw.get("in_rows_hint"))
         else:
+            assert not tmap.bounded, "a bounded tail map is a pair list: shapes outside lidiff_spconv_fwd_pairs take the one-launch kernel"
             rows = spconv_fwd(in_a, w, tmap.nbr, tmap.n, in_b=in_b, replicas=replicas)
         tail = (rows, tmap.ptr, tmap.idx)
     return spconv_fwd(in_a, w, None, m_out, tail=tail, offset=13, **kw)

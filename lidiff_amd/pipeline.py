@@ -77,22 +77,65 @@ class DiffCompletion(nn.Module):
     # LIDIFF_FUSED_STEP=0: the torch sequence.
     fused_step = os.environ.get("LIDIFF_FUSED_STEP", "1") != "0"
 
+    # -- a denoising step WITHOUT a host read ---------------------------------------------
+    # Every step rebuilds three coordinate pyramids, and the sizes of their maps used to come back to the host (one blocking read
+    # per pyramid) because they shaped every later launch and allocation: the main queue idled ~1 ms per step behind x_t's read and
+    # the host never got ahead of the device.  With read_free the fields of a loop carry a ROLE ("x_t" / "cond" / "uncond"); the
+    # first pyramid of a role is built with its read, every later one without: maps are handed over at their bound (the point
+    # count) with the row counts on the device -- every kernel of the fused plan takes them from there --, kernel choices are
+    # made from the sizes of the role's PREVIOUS pyramid (deterministic: always the previous one), and the device publishes the
+    # sizes into pinned memory (ops.SizeFeed) where the host finds them one step later.  What the host assumed (tail-pair bounds,
+    # the condition latent's row count) is checked then; a failed check voids the loop, which is redone with exact sizes
+    # (completion_loop does that itself; callers of denoise_step ask read_free_check()).  Results are independent of the mode
+    # up to the kernel choices; LIDIFF_HINT_LAG=1 runs the EXACT-size path with the same choices (the bit-for-bit twin).
+    read_free = os.environ.get("LIDIFF_READ_FREE", "1") != "0"
+    hint_lag = os.environ.get("LIDIFF_HINT_LAG", "0") == "1"
+
+    def _feed(self, role):
+        from . import ops
+        feeds = self.__dict__.setdefault("_feeds", {})
+        if role not in feeds:
+            feeds[role] = ops.SizeFeed(self.device)
+        return feeds[role]
+
+    def read_free_reset(self):
+        """A new scan: the first pyramid of every role is built with a host read again."""
+        for f in self.__dict__.get("_feeds", {}).values():
+            f.reset()
+
+    def read_free_check(self):
+        """None, or why the host-read-free steps since the last reset are void (waits for the sizes the device still owes)."""
+        for role, f in self.__dict__.get("_feeds", {}).items():
+            bad = f.drain()
+            if bad is not None:
+                return f"{role}: {bad}"
+        return None
+
     # pipeline:68-84
-    def points_to_tensor(self, points):
+    def points_to_tensor(self, points, role=None):
+        """role: "x_t" / "cond" / "uncond" inside a denoising loop (see read_free above); None: a field on its own."""
         if (self.fused_step and isinstance(points, torch.Tensor) and points.is_cuda and points.dim() == 3
                 and points.shape[2] == 3 and points.dtype in (torch.float32, torch.float64)):
             from . import ops
             feats, coords = ops.points_to_field(points.detach(), self.hparams["data"]["resolution"], scale_batch_column=True)
-            return self._make_field(feats, coords)
+            return self._make_field(feats, coords, role)
         x_feats = ME.utils.batched_coordinates(list(points[:]), dtype=torch.float32, device=self.device)
         x_coord = torch.round(x_feats / self.hparams["data"]["resolution"])
-        return self._make_field(x_feats[:, 1:], x_coord)
+        return self._make_field(x_feats[:, 1:], x_coord, role)
 
-    def _make_field(self, feats, coords):
+    def _make_field(self, feats, coords, role=None):
         field = ME.TensorField(features=feats, coordinates=coords,
                                quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
                                minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
-        field.coordinate_manager.pyramid = self.single_read and field.F.device.type == "cuda"
+        mgr = field.coordinate_manager
+        mgr.pyramid = self.single_read and field.F.device.type == "cuda"
+        if (role is not None and mgr.pyramid and (self.read_free or self.hint_lag) and self.pair_cfg and minknet._FUSION
+                and not self.training and feats.shape[0] >= 1):
+            mgr.feed = self._feed(role)
+            mgr.read_free = bool(self.read_free)
+            mgr.hint_lag = bool(self.hint_lag) and not self.read_free
+            if role != "x_t":            # the condition's latent shapes host-side work (MLP tables, match targets): exact rows
+                mgr.exact_rows = (ME.CoordinateManager.MAX_STRIDE,)
         if self.overlap_maps and field.F.device.type == "cuda":
             field.ready = torch.cuda.Event()         # its points exist once the current stream gets here
             field.ready.record(torch.cuda.current_stream(self.device))
@@ -227,8 +270,8 @@ class DiffCompletion(nn.Module):
     # pipeline:86-90
     def reset_partial_pcd(self, x_part, x_uncond, next_t=None):
         if not self.overlap_maps or x_part.F.device.type != "cuda":
-            x_part = self.points_to_tensor(x_part.F.reshape(1, -1, 3).detach())
-            x_uncond = self.points_to_tensor(torch.zeros_like(x_part.F.reshape(1, -1, 3)))
+            x_part = self.points_to_tensor(x_part.F.reshape(1, -1, 3).detach(), role="cond")
+            x_uncond = self.points_to_tensor(torch.zeros_like(x_part.F.reshape(1, -1, 3)), role="uncond")
             return self.prepare(x_part), self.prepare(x_uncond, tail_maps=False)
         # The next step's conditions are rebuilt from the same points (pipeline:86-90), which were there before this step's
         # network was queued: the whole rebuild -- batched coordinates, rounding, voxelisation, maps -- runs on the side
@@ -244,8 +287,8 @@ class DiffCompletion(nn.Module):
         x_part.F.record_stream(side)
         with torch.cuda.stream(side):
             pts = x_part.F.reshape(1, -1, 3).detach()
-            x_part = self.points_to_tensor(pts)
-            x_uncond = self.points_to_tensor(torch.zeros_like(pts))
+            x_part = self.points_to_tensor(pts, role="cond")
+            x_uncond = self.points_to_tensor(torch.zeros_like(pts), role="uncond")
             self.prepare(x_part)
             self.prepare(x_uncond, tail_maps=False)       # one voxel: nothing to gain from tail maps
             if (self.encode_ahead and self.pair_cfg and not self.cache_condition
@@ -295,9 +338,10 @@ class DiffCompletion(nn.Module):
         scan = self.preprocess_scan(scan)
         t0 = lap("preprocess_s", t0)
         x_feats = scan + torch.randn(scan.shape, device=self.device, generator=generator, dtype=scan.dtype)
-        x_full = self.points_to_tensor(x_feats)
-        x_cond = self.points_to_tensor(scan)
-        x_uncond = self.points_to_tensor(torch.zeros_like(scan))
+        self.read_free_reset()
+        x_full = self.points_to_tensor(x_feats, role="x_t")
+        x_cond = self.points_to_tensor(scan, role="cond")
+        x_uncond = self.points_to_tensor(torch.zeros_like(scan), role="uncond")
         self.new_scheduler()
         completed_scan = self.completion_loop(scan, x_full, x_cond, x_uncond)
         t0 = lap("denoise_s", t0)
@@ -489,20 +533,58 @@ class DiffCompletion(nn.Module):
             x0, feats, coords = ops.cfg_dpm_step(e_cond, e_uncond, self.w_uncond, x_t.F, x_init, sch.step_plan(t_int), noise,
                                                  self.hparams["data"]["resolution"], scale_batch_column=True)
             sch.commit(x0)
-            return self._make_field(feats, coords)
+            return self._make_field(feats, coords, "x_t")
         noise_t = e_uncond + self.w_uncond * (e_cond - e_uncond)
         input_noise = x_t.F.reshape(x_init.shape[0], -1, 3) - x_init
         x_new = x_init + sch.step(noise_t, t_int, input_noise, noise=noise)["prev_sample"]
-        return self.points_to_tensor(x_new)
+        return self.points_to_tensor(x_new, role="x_t")
 
     # pipeline:155-169
     def completion_loop(self, x_init, x_t, x_cond, x_uncond, noises=None):
+        """The loop runs host-read-free where it can (read_free above); if the device later reports that an assumption of those
+        steps did not hold (a tail map above its pair bound, a condition latent of another size than the step before), the whole
+        loop is redone from the same inputs, scheduler state and random draws with exact sizes -- same results as if it had run
+        that way from the start."""
+        if not (self.read_free and x_t.F.device.type == "cuda"):
+            return self._completion_loop(x_init, x_t, x_cond, x_uncond, noises)
+        import copy
+        sch = self.dpm_scheduler
+        saved = {k: (list(v) if isinstance(v, list) else v) for k, v in sch.__dict__.items()}
+        rng = torch.cuda.get_rng_state(self.device) if noises is None else None
+        for f in self.__dict__.get("_feeds", {}).values():
+            f.bad = None
+        try:
+            out = self._completion_loop(x_init, x_t, x_cond, x_uncond, noises, check=False)
+            why = self.read_free_check()
+        except RuntimeError as e:                    # (a consumer tripped over the same overflow before the host looked)
+            if "bound" not in str(e):
+                raise
+            out, why = None, str(e)
+        if why is None:
+            x_t_last, out = out
+            x_t_last.coordinate_manager.check()
+            return out
+        import warnings
+        warnings.warn(f"host-read-free denoising loop voided ({why}); redone with exact sizes")
+        sch.__dict__.update({k: (list(v) if isinstance(v, list) else v) for k, v in saved.items()})
+        if rng is not None:
+            torch.cuda.set_rng_state(rng, self.device)
+        self.read_free_reset()
+        prev, self.read_free = self.read_free, False
+        try:
+            return self._completion_loop(x_init, x_t, x_cond, x_uncond, noises)
+        finally:
+            self.read_free = prev
+
+    def _completion_loop(self, x_init, x_t, x_cond, x_uncond, noises=None, check=True):
         parts = self.encode_conditions(x_cond, x_uncond) if self.cache_condition and self.pair_cfg else None
         ts = self.dpm_scheduler.host_timesteps
         for i, t_int in enumerate(ts):
             x_t, x_cond, x_uncond = self.denoise_step(x_init, x_t, x_cond, x_uncond, t_int,
                                                       None if noises is None else noises[i], parts,
                                                       next_t=ts[i + 1] if i + 1 < len(ts) else None)
+        if not check:                    # (the caller validates the read-free steps before it trusts -- or reads -- anything)
+            return x_t, x_t.F.cpu().detach().numpy()
         x_t.coordinate_manager.check()
         return x_t.F.cpu().detach().numpy()
 

@@ -186,7 +186,7 @@ def make_heavy():
     print(f"t50_small: {time.time() - t0:.0f} s", flush=True)
 
 
-def make_closed():
+def make_closed(gpu_rounding=False):
     """python tests/golden/make_golden.py --closed: the oracle's END-TO-END run of BASELINE configs[1] -- closed loop over all
     T = 50 steps on the 180 000-point bench scan with seeded weights and shared scheduler noise, postprocess_scan, MinkUNet
     refinement (tests/heavy_oracle.closed_compute; ~2 min of CPU per step on 8 cores) -> tests/golden/closed_c2.npz, the truth of
@@ -202,12 +202,15 @@ def make_closed():
         off = xo[0] - scan
         print(f"step {i} t={t} max |eps| {np.abs(eps).max():.4f} offsets std {off.std():.4f} max {np.abs(off).max():.2f} "
               f"elapsed {time.time() - t0:.0f} s", flush=True)
-    out = heavy.closed_compute(fps, sd, sdr, log=log)
-    heavy.save_golden("closed_c2", heavy.closed_key(fps, sd, sdr), out)
-    print("closed_c2:", {k: v.shape for k, v in out.items()}, f"{time.time() - t0:.0f} s", flush=True)
+    out = heavy.closed_compute(fps, sd, sdr, log=log, gpu_rounding=gpu_rounding)
+    heavy.save_golden(heavy.closed_name(gpu_rounding), heavy.closed_key(fps, sd, sdr, gpu_rounding), out)
+    print(heavy.closed_name(gpu_rounding) + ":", {k: v.shape for k, v in out.items()}, f"{time.time() - t0:.0f} s", flush=True)
 
 
 if __name__ == "__main__":
+    if "--closed-gpu-rounding" in sys.argv:      # the same loop voxelised as the reference's DEVICE path rounds (x * 20.0f)
+        make_closed(gpu_rounding=True)
+        sys.exit(0)
     if "--closed" in sys.argv:
         make_closed()
         sys.exit(0)

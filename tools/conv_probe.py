@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--ordered", action="store_true", help="Morton-ordered tiles (row_order + permuted table)")
     ap.add_argument("--lpt", action="store_true", help="128-row tiles in descending pair-count order (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
-    ap.add_argument("--kernel", default="tile", choices=["tile", "dense", "dense1", "bf16"], help="kernel of the dense 128-column layers")
+    ap.add_argument("--kernel", default="tile", choices=["tile", "bf16"], help="kernel of the dense 128-column layers")
     ap.add_argument("--planes", type=int, default=1, help="--kernel bf16: bf16 pieces per operand (1 = rounded, 2 / 3 = split)")
     ap.add_argument("--centre-tail", action="store_true", help="k3 layers as centre pass + tail rows (ops.spconv_centre_tail)")
     ap.add_argument("--up-ordered", action="store_true", help="'up' layers with their output rows grouped by offset (CoordinateManager.up_order)")
@@ -58,7 +58,6 @@ def main():
         _lib.load().lidiff_debug_set_conv_probe(ctypes.c_int(args.probe))
     from lidiff_amd import ops
     import lidiff_amd.MinkowskiEngine as ME
-    ops.DENSE_KERNEL = args.kernel if args.kernel != "bf16" else "tile"
     ops.CONV_FLAGS = args.flags
     dev = torch.device("cuda:0")
     scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_fps18000.npy"))
@@ -156,12 +155,6 @@ def main():
                   f"slabs {t[:, 0, 6].mean():.0f} = {stages:.0f} stages")
             for wv, name in ((0, "wave 0"), (1, f"wave NW/2")):
                 q = t[:, wv]
-                if args.kernel != "tile" and cout % 128 == 0 and cin % 64 == 0 and not hint:      # dense kernel: other fields
-                    print(f"  wave {wv}: prologue {q[:, 0].mean():.0f}  main loop {q[:, 1].mean():.0f}  epilogue {q[:, 2].mean():.0f} | "
-                          f"per stage: loop {q[:, 1].mean() / stages:.0f} = barrier+vmcnt {q[:, 3].mean() / stages:.0f} + "
-                          f"P2 wait {q[:, 8].mean() / stages:.0f} + flush {q[:, 4].mean() / stages:.0f} + rest "
-                          f"{(q[:, 1] - q[:, 3] - q[:, 8] - q[:, 4]).mean() / stages:.0f}")
-                    continue
                 print(f"  {name}: prologue {q[:, 0].mean():.0f}  main loop {q[:, 1].mean():.0f}  epilogue {q[:, 2].mean():.0f} | per stage: "
                       f"loop {q[:, 1].mean() / stages:.0f} = issue {q[:, 8].mean() / stages:.0f} + mma {q[:, 9].mean() / stages:.0f} + "
                       f"flush {q[:, 4].mean() / stages:.0f} + barrier {q[:, 3].mean() / stages:.0f} + rest "

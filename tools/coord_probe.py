@@ -79,8 +79,6 @@ def main():
     part = pcur
     us = timed(lambda: ops.nn_match(uniq, part))
     rows.append((f"nn_match exhaustive, full {M} x part {part.shape[0]} ({8e-9 * M * part.shape[0]:.1f} GFLOP)", us, 16 * (M + part.shape[0]) + 8 * M))
-    us = timed(lambda: ops.nn_match(uniq, part, part_table=ptab, part_stride=16))
-    rows.append((f"nn_match lattice shells, full {M} x part {part.shape[0]}", us, 16 * (M + part.shape[0]) + 8 * M))
     print(f"sigma={a.sigma}")
     print("kernel | us | algorithmic MB | GB/s | % of 8 TB/s")
     for name, us, b in rows:

@@ -176,6 +176,9 @@ int lidiff_tail_map_fill_bounded(const int32_t* nbr, int32_t k_vol, int64_t m_bo
  * (host_mapped: pinned, device-mapped; [0] = seq, [1] = status, [2 ..] = the words), the sequence number last behind a
  * system-scope fence.  The host side of a denoising loop learns the sizes of step i from it while step i + 1 is already queued
  * -- no device->host copy, no synchronisation (DiffCompletion, pipeline:155-169).  n_words <= 62. */
+/* The device-side address of pinned host memory (hipHostGetDevicePointer), for host_mapped below; non-zero status when the
+ * memory is not mapped into the device's address space (the caller then copies instead).  Host-only helper. */
+int lidiff_host_device_pointer(void* host_ptr, void** dev_ptr);
 int lidiff_publish_words(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* host_mapped, int32_t seq,
                          void* stream);
 

@@ -45,6 +45,8 @@ class MinkowskiAlgorithm(enum.Enum):
 # coordinate manager
 # ----------------------------------------------------------------------------------------
 _SPLIT_PYRAMID = __import__("os").environ.get("LIDIFF_SPLIT_PYRAMID", "1") != "0"
+# a host-read-free pyramid queued in three lanes ordered by who waits for what (ops.build_pyramid_lanes); 0: one chain
+_PYRAMID_LANES = __import__("os").environ.get("LIDIFF_PYRAMID_LANES", "1") != "0"
 
 
 class CoordinateMap:
@@ -89,6 +91,7 @@ class CoordinateManager:
         self.hints = None               # [rows of levels 0 .. 4, tail pairs of levels 0, 1] believed by the host
         self.exact_rows = None          # strides whose rows must come out EXACTLY as hinted (the condition's latent), checked later
         self.hint_lag = False           # exact sizes, but kernel choices from `hints` (the A/B twin of read_free: same choices)
+        self.lane_up_orders = True      # a pyramid built in lanes also builds the decoder's offset-grouped pair lists (up_order)
 
     def rows(self, ts: int) -> int:
         """Row count of the map of stride ts as the host knows it (exact, or the hint of a read-free map); 0 if absent.
@@ -117,14 +120,16 @@ class CoordinateManager:
         return None
 
     # -- asynchronous, on-demand building (DiffCompletion, round 3) ------------------------------------------------------
-    def set_async(self, side, side2, ready=None, on_level=None, on_level_dev=None):
+    def set_async(self, side, side2, ready=None, on_level=None, on_level_dev=None, side3=None):
         """Build every map of this manager ON DEMAND on `side` (the map-size reads synchronise that stream only) while the
         consumer's stream keeps running what is already queued; consumers join through lidiff_amd._lib.call().  on_level(ts)
         runs on `side2` as soon as the coordinate map of stride ts exists (the part -> full match of that level)."""
         from .. import _lib
         _lib.register_build_stream(side)
         _lib.register_build_stream(side2)
-        self._async, self._ready, self._on_level, self._on_level_dev = (side, side2), ready, on_level, on_level_dev
+        if side3 is not None:           # third lane of a host-read-free pyramid (ops.build_pyramid_lanes): the deeper levels
+            _lib.register_build_stream(side3)
+        self._async, self._ready, self._on_level, self._on_level_dev = (side, side2, side3), ready, on_level, on_level_dev
         if ready is not None:
             side.wait_event(ready)
             side2.wait_event(ready)
@@ -147,23 +152,41 @@ class CoordinateManager:
 
     def _level_built(self, ts: int):
         if self._async is not None and self._on_level is not None:
-            side, side2 = self._async
+            side, side2 = self._async[:2]
             ev = torch.cuda.Event()
             ev.record(side)
             side2.wait_event(ev)
             with self.building(second=True):
                 self._on_level(ts)
 
-    def insert(self, coords_i32: torch.Tensor):
+    def _acquire(self, ts: int, up: bool = False):
+        """A pyramid built in lanes (ops.build_pyramid_lanes) hands its maps over level by level: the first consumer of a level
+        on another stream waits for THAT level's event -- the stem for level 0 only (~0.2 ms behind the points), not for the
+        whole chain; `up`: the decoder's transposed maps, built last."""
+        lane = getattr(self, "_lane", None)
+        if lane is None:
+            return
+        from .. import _lib
+        cur = torch.cuda.current_stream(self.device)
+        if cur in _lib._BUILD_STREAMS:
+            return                       # (builders are ordered by the lanes themselves)
+        for key, ev in ((1, lane["ready"][1]), (ts, lane["ready"].get(ts)), ("up", lane["ready_up"] if up else None)):
+            if ev is not None and (key, cur) not in lane["seen"]:
+                cur.wait_event(ev)
+                lane["seen"].add((key, cur))
+
+    def insert(self, coords_i32: torch.Tensor, feats: torch.Tensor | None = None):
+        """feats: the field's features, for the voxel mean to be queued INSIDE the pyramid chain where that pays (kept in
+        self._feats0 for TensorField.sparse())."""
         if self.pyramid:
-            return self._insert_pyramid(coords_i32)
+            return self._insert_pyramid(coords_i32, feats)
         with self.building():
             uniq, inverse, first_idx, table = ops.vox_unique(coords_i32, self.status)
         self.maps[1] = CoordinateMap(uniq, table, 1)
         self._level_built(1)
         return inverse, first_idx
 
-    def _insert_pyramid(self, coords_i32: torch.Tensor):
+    def _insert_pyramid(self, coords_i32: torch.Tensor, feats=None):
         levels = int(math.log2(self.MAX_STRIDE))
         second = self._async[1] if self._async is not None and _SPLIT_PYRAMID else None
         hook, early = None, []
@@ -177,11 +200,39 @@ class CoordinateManager:
             if self.hints is None and self.feed.has_records():
                 self.hints = self.feed.get()[1]      # the role's previous pyramid (waits for the device if it is not there yet)
             free = self.read_free and self.hints is not None
-        with self.building():
-            pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2, second_stream=second, on_level_dev=hook,
-                                    feed=self.feed, read_free=free)
+        third = self._async[2] if self._async is not None and len(self._async) > 2 else None
+        if free and second is not None and third is not None and _PYRAMID_LANES:
+            from .. import _lib
+            h = self.hints
+            # (a level's tail map is filled inside the chain when the layers will use it: the centre + tail rule of conv_bn_act;
+            #  the decoder's pair lists for the maps large enough to take them: up_order())
+            sparse = tuple(h[lv] >= 1024 and h[lv + 1] >= 0.85 * h[lv] for lv in (0, 1))
+            ups = tuple(lv for lv in range(1, levels + 1) if self.lane_up_orders and h[lv - 1] >= self.UP_ORDER_MIN_ROWS)
+            with self.building():
+                pyr = ops.build_pyramid_lanes(coords_i32, self.status, self.feed, second, third, strides=levels, on_level_dev=hook,
+                                              feats=feats, tail_levels=sparse, up_pairs_levels=ups)
+            # every map of the networks exists now and is handed over through per-level events (_acquire): no blanket join
+            _lib.unmark_pending(self._async[0])
+            self._feats0 = pyr.feats0
+            self._lane = {"ready": pyr.ready, "ready_up": pyr.ready_up, "seen": set()}
+            for lv in range(levels + 1):
+                self.kmaps[(1 << lv, 1 << lv, 3, False)] = pyr.nbr3[lv]
+            for lv in range(1, levels + 1):
+                fine, coarse = 1 << (lv - 1), 1 << lv
+                self.kmaps[(fine, coarse, 2, False)] = pyr.down[lv]
+                self.kmaps[(coarse, fine, 2, True)] = pyr.up[lv]
+                hit = pyr.up_lists.get(lv)
+                self.aux[("up_order", coarse, fine)] = None if hit is None else (hit[3], hit[1])
+                if hit is not None:
+                    self.aux[("up_pairs", coarse, fine)] = hit[:3]
+        else:
+            with self.building():
+                pyr = ops.build_pyramid(coords_i32, self.status, strides=levels, tail_levels=2, second_stream=second,
+                                        on_level_dev=hook, feed=self.feed, read_free=free)
         self._counts = pyr.counts
-        if free:           # rows the host takes as exact (exact_view) are checked when the device's counts arrive
+        if free:           # rows the host takes as exact (exact_view) are checked when the device's counts arrive.  (A tail map above
+            # its pair bound is flagged by the kernel that FILLS it -- only a map some layer really uses matters -- in the loop's
+            # shared status word, which travels with every later record and is read at the end of the loop.)
             self.feed.expect(self.feed.seq, {ts.bit_length() - 1: self.hints[ts.bit_length() - 1] for ts in (self.exact_rows or ())})
         for lv, results in early:
             for key, owner, bound_tensor, event in results:
@@ -219,6 +270,7 @@ class CoordinateManager:
         return ts_out
 
     def kernel_map(self, ts_in: int, ts_out: int, ks: int, transposed: bool = False) -> torch.Tensor:
+        self._acquire(max(ts_in, ts_out), up=transposed)
         key = (ts_in, ts_out, ks, transposed)
         nbr = self.kmaps.get(key)
         if nbr is None:
@@ -252,6 +304,7 @@ class CoordinateManager:
     def tail_map(self, ts: int):
         """ops.TailMap of the kernel_size-3 map on stride ts (non-centre pairs by offset + CSR by output row); cached."""
         key = ("tail", ts)
+        self._acquire(ts)
         if key not in self.aux:
             nbr = self.kernel_map(ts, ts, 3)
             with self.building():
@@ -297,6 +350,7 @@ class CoordinateManager:
         holds ~16 pairs of each of the 8 offsets: eight almost empty MFMA stages per channel slab.  Grouped by offset a
         tile is 128 pairs of ONE offset -- a dense stage.  Results do not depend on the order (lidiff_spconv_fwd row_order)."""
         key = ("up_order", ts_in, ts_out)
+        self._acquire(ts_in, up=True)
         if key not in self.aux:
             nbr = self.kernel_map(ts_in, ts_out, 2, True)
             if self.rows(ts_out) < self.UP_ORDER_MIN_ROWS:
@@ -507,16 +561,20 @@ class TensorField:
 
     def sparse(self) -> "SparseTensor":
         mgr = self.coordinate_manager
+        no_graph = not (torch.is_grad_enabled() and self._F.requires_grad)
         if self.inverse_mapping is None:
             with mgr.building():
                 ci = self._C if self._C.dtype == torch.int32 else ops.coords_floor(self._C)
-            self.inverse_mapping, _ = mgr.insert(ci)
+            self.inverse_mapping, _ = mgr.insert(ci, feats=self._F if no_graph and self._F.dtype == torch.float32 else None)
         if self._sparse is not None:
             mgr.flush_levels()
             return self._sparse
         m = mgr.maps[1].coords.shape[0]
-        with mgr.building():
-            f = _VoxelMean.apply(self._F.float(), self.inverse_mapping, m)
+        f = getattr(mgr, "_feats0", None)        # the voxel mean was queued inside the pyramid chain (build_pyramid_lanes)
+        mgr._feats0 = None
+        if f is None or not no_graph:
+            with mgr.building():
+                f = _VoxelMean.apply(self._F.float(), self.inverse_mapping, m)
         mgr.flush_levels()              # the per-level callbacks (matches), behind the voxel mean
         sp = SparseTensor(f, tensor_stride=1, coordinate_manager=mgr)
         if not (torch.is_grad_enabled() and self._F.requires_grad):
@@ -648,8 +706,9 @@ class _ConvBase(nn.Module):
         with torch.no_grad():
             self.kernel.uniform_(-1.0 / math.sqrt(n), 1.0 / math.sqrt(n))
 
-    def maps(self, x: SparseTensor):
-        """(nbr, nbr_swapped, ts_out, flip) for input x; builds / reuses the manager's maps."""
+    def maps(self, x: SparseTensor, swapped: bool = True):
+        """(nbr, nbr_swapped, ts_out, flip) for input x; builds / reuses the manager's maps.  swapped=False: the forward-only
+        caller does not need the swapped map (the input gradient's) -- None in its place."""
         mgr, ts = x.coordinate_manager, x.tensor_stride
         if self.kernel_size == 1:
             return None, None, ts, False
@@ -658,13 +717,13 @@ class _ConvBase(nn.Module):
             if ts_out < 1 or ts_out not in mgr.maps:
                 raise RuntimeError("transposed convolution needs the finer map created by the encoder")
             return (mgr.kernel_map(ts, ts_out, self.kernel_size, True),
-                    mgr.kernel_map(ts_out, ts, self.kernel_size, False), ts_out, False)
+                    mgr.kernel_map(ts_out, ts, self.kernel_size, False) if swapped else None, ts_out, False)
         if self.stride == 1:
             nbr = mgr.kernel_map(ts, ts, self.kernel_size)
             return nbr, nbr, ts, True
         ts_out = mgr.stride(ts, self.stride)
         return (mgr.kernel_map(ts, ts_out, self.kernel_size, False),
-                mgr.kernel_map(ts_out, ts, self.kernel_size, True), ts_out, False)
+                mgr.kernel_map(ts_out, ts, self.kernel_size, True) if swapped else None, ts_out, False)
 
     def sparse_hint(self, x: SparseTensor, ts_out: int) -> bool:
         return x.coordinate_manager.is_sparse_map(x.tensor_stride, ts_out, self.kernel_size, self.transposed,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "lidiff_kernel_map_up_dev": (_i32, [_p, _p, _i64, _p, _i32, _p, _p]),
     "lidiff_tail_map_fill_bounded": (_i32, [_p, _i32, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "lidiff_publish_words": (_i32, [_p, _i32, _p, _p, _i32, _p]),
+    "lidiff_host_device_pointer": (_i32, [_p, _p]),
     "lidiff_nn_dist_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
 }
@@ -115,15 +116,22 @@ def load() -> C.CDLL:
 # DiffCompletion._adopt / an explicit event; nothing else touches them (TailMap.fill, up_order and the voxel mean all run inside
 # building() themselves and hand their results on through call()).
 _BUILD_STREAMS: set = set()
-_PENDING: set = set()
+_PENDING: dict = {}          # build stream -> None (join everything queued on it so far) | an event (join up to that event only)
 
 
 def register_build_stream(stream) -> None:
     _BUILD_STREAMS.add(stream)
 
 
-def mark_pending(stream) -> None:
-    _PENDING.add(stream)
+def mark_pending(stream, upto=None) -> None:
+    """upto: an event already recorded on `stream` -- consumers need only what was queued before it (ops.build_pyramid_lanes: the
+    stem waits for level 0, not for the whole pyramid).  A later mark without an event widens the join to the whole stream again."""
+    _PENDING[stream] = upto
+
+
+def unmark_pending(stream) -> None:
+    """The work queued on `stream` is handed over through events of its own (CoordinateManager._acquire): no blanket join."""
+    _PENDING.pop(stream, None)
 
 
 def join_pending() -> None:
@@ -132,9 +140,10 @@ def join_pending() -> None:
     cur = torch.cuda.current_stream()
     if cur in _BUILD_STREAMS:
         return
-    for st in list(_PENDING):
-        ev = torch.cuda.Event()
-        ev.record(st)
+    for st, ev in list(_PENDING.items()):
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(st)
         cur.wait_event(ev)
     _PENDING.clear()
 

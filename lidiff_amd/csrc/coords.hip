@@ -1468,6 +1468,12 @@ int lidiff_tail_map_fill_bounded(const int32_t* nbr, int32_t k_vol, int64_t m_bo
     return 0;
 }
 
+int lidiff_host_device_pointer(void* host_ptr, void** dev_ptr) {
+    LIDIFF_CHECK_ARG(host_ptr != nullptr && dev_ptr != nullptr, "null pointer");
+    LIDIFF_CHECK_HIP(hipHostGetDevicePointer(dev_ptr, host_ptr, 0));
+    return 0;
+}
+
 int lidiff_publish_words(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* host_mapped, int32_t seq,
                          void* stream) {
     LIDIFF_CHECK_ARG(words != nullptr && host_mapped != nullptr && n_words >= 0 && n_words <= 62, "up to 62 words");

@@ -118,7 +118,7 @@ def _run_seq(seq, x: ME.SparseTensor) -> ME.SparseTensor:
 
 def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=None) -> ME.SparseTensor:
     """relu?( bn(conv([x | extra])) + residual ) as ONE kernel launch (eval mode only)."""
-    nbr, _, ts_out, _ = conv.maps(x)
+    nbr, _, ts_out, _ = conv.maps(x, swapped=False)
     mgr = x.coordinate_manager
     m_out = mgr.maps[ts_out].coords.shape[0]
     # host-read-free maps (DiffCompletion.read_free): m_out is the BOUND of the rows, d_rows their count on the device; every
@@ -148,7 +148,9 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
     # (not for the 3-channel stem: the thin-input kernel walks the whole table in one launch)
     if (_CENTRE_TAIL and hint and conv.kernel_size == 3 and not conv.transposed and order is None and rows_out >= 1024
             and x.F.shape[1] > 4 and mgr.is_sparse_map(ts_out, ts_out, 3)
-            and (not free or ops.pairs_kernel_applies(x.F.shape[1], 0 if extra is None else extra.shape[1], conv.out_channels))):
+            # (shapes the pair-list kernel takes: every layer of the low-density levels; a wider one -- 192 -> 128 on a scene so
+            #  small that even stride 4 is isolated voxels -- keeps the one-launch kernel, in every mode alike)
+            and ops.pairs_kernel_applies(x.F.shape[1], 0 if extra is None else extra.shape[1], conv.out_channels)):
         if hints:
             hints["tail_hint"] = mgr.tail_rows(ts_out)
         f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
@@ -425,6 +427,7 @@ class MinkUNetDiff(_Base):
             return hit[1]
         # exhaustive scan: on the noisy x_t of the bench workload (sigma up to 1 m, many voxels far from every part voxel)
         # it beats the lattice-shell search of lidiff_nn_match_grid (0.44 vs 1.1 ms at 180k x 5.8k rows)
+        x_full.coordinate_manager._acquire(x_full.tensor_stride)
         d_full = x_full.coordinate_manager.count(x_full.tensor_stride)
         idx = ops.nn_match(x_full.C, x_part.C) if d_full is None else ops.nn_match_dev(x_full.C, d_full, x_part.C)
         done = None
@@ -581,11 +584,19 @@ class MinkUNetDiff(_Base):
         finally:
             self._tables = None
 
+    MARK = None        # tools/step_timeline.py: callable(label) at a few points of the forward (records an event on the stream)
+
     def _forward(self, x, x_sparse, part_feats, t, multi, temp_emb):
+        mark = self.MARK or (lambda label: None)
+        mark("unet: enter")
         f0 = _run_stem(self.stem, x_sparse)                      # the stem sees no conditioning: shared
+        mark("unet: stem")
         feats = [f0.replicate(len(part_feats)) if multi else f0]
         for name in _LEVELS[:4]:
-            feats.append(getattr(self, name)(self._condition(name, feats[-1], part_feats, temp_emb)))
+            cond = self._condition(name, feats[-1], part_feats, temp_emb)
+            mark(f"unet: {name} conditioned")
+            feats.append(getattr(self, name)(cond))
+            mark(f"unet: {name}")
         y = feats[4]
         for j, name in enumerate(_LEVELS[4:]):
             y = _run_up(getattr(self, name), self._condition(name, y, part_feats, temp_emb), feats[3 - j])
@@ -594,7 +605,9 @@ class MinkUNetDiff(_Base):
             if multi:
                 m0 = y.F.shape[0] // y.replicas
                 inv = torch.cat([inv + r * m0 for r in range(y.replicas)])
-            out = ops.gather_rows(self.last(y.F), inv)
+            # (the head behind the slice, as the reference orders them: its GEMMs then see [points, 96] whatever the voxel count --
+            #  or its bound -- is, so the library picks the same kernels, i.e. the same summation order, in every mode)
+            out = self.last(ops.gather_rows(y.F, inv))
             return tuple(out.chunk(y.replicas, dim=0)) if multi else out
         return _run_mlp(self.last, y.slice(x).F)
 

@@ -98,7 +98,8 @@ _PINNED: dict = {}
 class Pyramid:
     """What build_pyramid() hands over: per level the coordinate rows, hash table and (levels >= 1) the parent array of the
     finer level; for the first `tail_levels` levels also the kernel_size-3 self map and the phase-1 state of its tail map."""
-    __slots__ = ("coords", "tables", "parents", "inverse", "first_idx", "nbr3", "tails", "counts", "bound")
+    __slots__ = ("coords", "tables", "parents", "inverse", "first_idx", "nbr3", "tails", "counts", "bound", "fast", "feats0",
+                 "ready", "ready_up", "down", "up", "up_lists")
 
 
 # pair bound of a tail map built without a host read, per row of the map's bound: centre + tail is only chosen for maps with at
@@ -120,10 +121,17 @@ class SizeFeed:
         self.device = device
         self.ring = torch.zeros((self.SLOTS, self.WORDS), dtype=torch.int32).pin_memory()
         self.view = self.ring.numpy()
+        # the device writes the ring itself when the pinned block is mapped into its address space (the normal case:
+        # hipHostMalloc); otherwise two small asynchronous copies per record (the sizes, then the sequence number)
+        import ctypes
+        dptr = ctypes.c_void_p()
+        rc = _lib.load().lidiff_host_device_pointer(ctypes.c_void_p(self.ring.data_ptr()), ctypes.byref(dptr))
+        self.dev_base = dptr.value if rc == 0 and dptr.value and os.environ.get("LIDIFF_FEED_COPY", "0") != "1" else None
         self.seq = 0                 # records announced so far
         self.seq_base = 0            # records before this one belong to an earlier scan (reset())
         self.done = {}               # seq -> (status, [sizes]) read back or pushed
         self.n_words = {}
+        self.slot_owner = {}         # ring slot -> the device-written record it holds (host-pushed records use no slot)
         self.checks = {}             # seq -> {level: rows the host took as exact}
         self.bad = None              # first failed validation (message), sticky until reset()
 
@@ -138,8 +146,9 @@ class SizeFeed:
     def has_records(self) -> bool:
         return self.seq > self.seq_base
 
-    def expect(self, seq: int, exact_rows: dict):
-        self.checks[seq] = dict(exact_rows)
+    def expect(self, seq: int, exact_rows: dict, maxima: dict | None = None):
+        """What the host assumed about record `seq`: words that must equal / must not exceed a value."""
+        self.checks[seq] = (dict(exact_rows), dict(maxima or {}))
 
     def drain(self):
         """Read every record the device still owes (end of a loop: all checks done).  Returns self.bad."""
@@ -148,7 +157,7 @@ class SizeFeed:
         return self.bad
 
     def _check(self, seq, status, sizes):
-        exact = self.checks.pop(seq, {})
+        exact, maxima = self.checks.pop(seq, ({}, {}))
         if self.bad is not None:
             return
         if status & STATUS_BOUND:
@@ -156,6 +165,9 @@ class SizeFeed:
         for lv, rows in exact.items():
             if sizes[lv] != rows:
                 self.bad = f"record {seq}: level {lv} has {sizes[lv]} rows, the host took {rows} as exact"
+        for i, top in maxima.items():
+            if sizes[i] > top:
+                self.bad = f"record {seq}: word {i} = {sizes[i]} exceeds the bound {top} the host sized a buffer by"
 
     def push_host(self, sizes, status: int = 0):
         self.seq += 1
@@ -167,10 +179,18 @@ class SizeFeed:
         """Queue the device-side write of `counts` (int32 [k]) and *status into this feed's next record."""
         self.seq += 1
         slot = self.ring[self.seq % self.SLOTS]
-        if self.seq - self.SLOTS in self.n_words and self.seq - self.SLOTS not in self.done:
-            self.get(self.seq - self.SLOTS)            # the slot's previous record has not been consumed yet: do it now
+        prev = self.slot_owner.get(self.seq % self.SLOTS)
+        if prev is not None and prev in self.n_words:
+            self.get(prev)                             # the slot's previous record has not been consumed yet: do it now
+        self.slot_owner[self.seq % self.SLOTS] = self.seq
         self.n_words[self.seq] = counts.numel()
-        call("lidiff_publish_words", ptr(counts), counts.numel(), ptr(status), slot.data_ptr(), self.seq, stream_ptr())
+        if self.dev_base is not None:
+            call("lidiff_publish_words", ptr(counts), counts.numel(), ptr(status), self.dev_base + 4 * self.WORDS * (self.seq % self.SLOTS),
+                 self.seq, stream_ptr())
+        else:
+            body = torch.cat([status.reshape(1) if status is not None else counts.new_zeros(1), counts])
+            slot[1:1 + body.numel()].copy_(body, non_blocking=True)
+            slot[0:1].copy_(torch.full((1,), self.seq, dtype=torch.int32, device=counts.device), non_blocking=True)
         return self.seq
 
     def get(self, seq: int | None = None, timeout_s: float = 30.0):
@@ -293,12 +313,13 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
         assert feed is not None
         feed.publish(counts, status)
         out = Pyramid()
+        out.fast = out.feats0 = None
         out.counts, out.bound = counts, n
         out.coords = rows
         out.tables, out.inverse, out.first_idx = tables, inverse, first_idx
         out.parents = parents
         out.nbr3 = [t[0] for t in tails]
-        out.tails = [TailMap(None, bounded=(nbr, n, counts[lv:lv + 1], ws, off, row_ptr, TAIL_PAIR_BOUND * n, status))
+        out.tails = [TailMap(None, bounded=(nbr, n, counts[lv:lv + 1], ws, off, row_ptr, max(1, int(TAIL_PAIR_BOUND * n)), status))
                      for lv, (nbr, ws, off, row_ptr) in enumerate(tails)]
         _trace("done")
         return out
@@ -320,6 +341,7 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     if feed is not None:
         feed.push_host(host)
     out = Pyramid()
+    out.fast = out.feats0 = None
     out.counts, out.bound = counts, n
     out.coords = [rows[lv][:host[lv]] for lv in range(strides + 1)]
     out.tables, out.inverse, out.first_idx = tables, inverse, first_idx[:host[0]]
@@ -330,6 +352,108 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
         out.nbr3.append(nbr[:, :m].contiguous())               # the table at its own pitch (27 x M ints: a ~10 us copy)
         out.tails.append(TailMap(None, phase1=(nbr, n, counts[lv:lv + 1], ws, off, row_ptr, host[strides + 1 + lv], m)))
     _trace("done")
+    return out
+
+
+def build_pyramid_lanes(coords: torch.Tensor, status: torch.Tensor, feed: "SizeFeed", second_stream, third_stream,
+                        strides: int = 4, on_level_dev=None, feats: torch.Tensor | None = None, tail_levels=(True, False),
+                        up_pairs_levels=()) -> Pyramid:
+    """build_pyramid(read_free=True) with the work ordered by WHO WAITS FOR IT, and with EVERY map of LiDiff's networks queued
+    up front (round 5).  Without a host read nothing about a map has to reach the host before it can be built, so nothing needs
+    to be built "on demand" in the middle of the network any more (each such build stalled the network's queue for a chain of
+    2-3 small kernels: 13 maps per step), and the chain behind x_t's points -- the critical path between two networks -- shrinks
+    to what the stem needs.  Three lanes (tools/debug/event_gap.py: a small kernel cannot start while ANOTHER queue keeps the chip
+    full, so what matters is which queue waits for what, not how much runs "in parallel"):
+      current stream   voxel map of level 0 -> voxel mean of `feats` -> kernel_size-3 map of level 0 + its tail map (counted, and
+                       filled when tail_levels[0]: a bounded fill needs no size on the host) -> event ready[1];
+      third_stream     per level 1 .. strides: strided map -> kernel_size-2 map down into it -> its kernel_size-3 map (+ tail map
+                       of level 1) -> event ready[2 ** level]; then the size record for the feed; then the decoder's maps, coarse
+                       to fine: the transposed kernel_size-2 maps and (up_pairs_levels) their offset-grouped pair lists -> ready_up;
+      second_stream    on_level_dev(level, rows, count) per level as soon as that level's rows exist (the part -> full matches).
+    The current stream finally waits for the other lanes (anything built on it later is ordered behind the pyramid).
+    Pyramid.ready = {tensor stride: event}, Pyramid.ready_up; Pyramid.down / up / up_lists hold the extra maps by level."""
+    require_device(coords, status)
+    assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4 and strides >= 1
+    coords = coords.contiguous()
+    n, dev = coords.shape[0], coords.device
+    lib = _lib.load()
+    cur = torch.cuda.current_stream(dev)
+    counts = torch.zeros(strides + 3, dtype=torch.int32, device=dev)
+    cptr = lambda i: counts.data_ptr() + 4 * i
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    tables = [HashTable(n, dev) for _ in range(strides + 1)]
+    rows = [i32(n, 4) for _ in range(strides + 1)]
+    parents = [None] + [i32(n) for _ in range(strides)]
+    keep = [_workspace(n, dev) for _ in range(strides + 1)]
+    first_idx, inverse = i32(n), torch.empty(n, dtype=torch.int64, device=dev)
+    nbr3 = [i32(27, n) for _ in range(strides + 1)]
+    down = [None] + [i32(8, n) for _ in range(strides)]           # down[lv]: level lv - 1 -> lv
+    up = [None] + [i32(8, n) for _ in range(strides)]             # up[lv]:   level lv -> lv - 1 (output rows: level lv - 1)
+    tail_buf = [(torch.empty(lib.lidiff_tail_map_workspace_bytes(27, n), dtype=torch.uint8, device=dev), i32(28), i32(n + 1))
+                for _ in range(2)]
+    shared = ([counts, first_idx, inverse] + rows + parents[1:] + keep + nbr3 + down[1:] + up[1:]
+              + [q for tb in tables for q in (tb.keys, tb.vals)] + [q for tb in tail_buf for q in tb])
+    for t in shared:           # allocated under the current stream; the other lanes read / write them
+        t.record_stream(third_stream)
+        t.record_stream(second_stream)
+
+    def kmap3(lv):
+        call("lidiff_kernel_map_self_dev", ptr(rows[lv]), n, cptr(lv), ptr(tables[lv].keys), ptr(tables[lv].vals), tables[lv].cap,
+             1 << lv, ptr(nbr3[lv]), stream_ptr())
+
+    def tail(lv, fill):
+        ws, off, row_ptr = tail_buf[lv]
+        call("lidiff_tail_map_dev", ptr(nbr3[lv]), 27, n, cptr(lv), 13, ptr(off), ptr(row_ptr), 0, None, None, ptr(ws), stream_ptr())
+        counts[strides + 1 + lv:strides + 2 + lv].copy_(off[27:28])
+        tm = TailMap(None, bounded=(nbr3[lv], n, counts[lv:lv + 1], ws, off, row_ptr, max(1, int(TAIL_PAIR_BOUND * n)), status))
+        return tm.fill() if fill else tm
+
+    out = Pyramid()
+    out.ready, out.up_lists = {}, {}
+    # ---- lane 1 (current stream): what the stem needs
+    call("lidiff_vox_unique", ptr(coords), n, ptr(tables[0].keys), ptr(tables[0].vals), tables[0].cap, ptr(rows[0]),
+         ptr(first_idx), ptr(inverse), cptr(0), ptr(status), ptr(keep[0]), stream_ptr())
+    ev = [torch.cuda.Event()]
+    ev[0].record(cur)
+    out.feats0 = vox_mean(feats, inverse, n)[0] if feats is not None else None
+    kmap3(0)
+    tails = [tail(0, tail_levels[0])]
+    out.ready[1] = out.fast = torch.cuda.Event()
+    out.fast.record(cur)
+    # ---- lane 3: level by level in the order the encoder walks them, the size record, then the decoder's maps
+    third_stream.wait_event(ev[0])
+    with torch.cuda.stream(third_stream):
+        for lv in range(1, strides + 1):
+            call("lidiff_map_stride_dev", ptr(rows[lv - 1]), n, cptr(lv - 1), 1 << lv, ptr(tables[lv].keys), ptr(tables[lv].vals),
+                 tables[lv].cap, ptr(rows[lv]), ptr(parents[lv]), cptr(lv), ptr(status), ptr(keep[lv]), stream_ptr())
+            ev.append(torch.cuda.Event())
+            ev[lv].record(third_stream)
+            call("lidiff_kernel_map_down_dev", ptr(rows[lv - 1]), ptr(parents[lv]), n, cptr(lv - 1), 1 << (lv - 1), n, ptr(down[lv]),
+                 stream_ptr())
+            kmap3(lv)
+            if lv == 1:
+                tails.append(tail(1, tail_levels[1]))
+            out.ready[1 << lv] = torch.cuda.Event()
+            out.ready[1 << lv].record(third_stream)
+        third_stream.wait_event(out.fast)                   # (level 0's tail count is part of the record)
+        feed.publish(counts, status)
+        for lv in range(strides, 0, -1):
+            call("lidiff_kernel_map_up_dev", ptr(rows[lv - 1]), ptr(parents[lv]), n, cptr(lv - 1), 1 << (lv - 1), ptr(up[lv]), stream_ptr())
+            if lv in up_pairs_levels:          # (pairs grouped by offset, the output-row order, the table's columns in that order)
+                pin, order, off = rulebook_compact(up[lv], total=n, bounded=True)
+                out.up_lists[lv] = (pin, order, off, up[lv].index_select(1, order.long()).contiguous())
+        out.ready_up = torch.cuda.Event()
+        out.ready_up.record(third_stream)
+    # ---- lane 2: per-level callbacks (the matches), each behind its level only
+    if on_level_dev is not None:
+        with torch.cuda.stream(second_stream):
+            for lv in range(strides + 1):
+                second_stream.wait_event(ev[lv])
+                on_level_dev(lv, rows[lv], counts[lv:lv + 1])
+    cur.wait_event(out.ready_up)
+    out.counts, out.bound = counts, n
+    out.coords, out.tables, out.inverse, out.first_idx, out.parents = rows, tables, inverse, first_idx, parents
+    out.nbr3, out.tails, out.down, out.up = nbr3, tails, down, up
     return out
 
 
@@ -1404,7 +1528,7 @@ class TailMap:
         row_ptr = torch.empty(m_bound + 1, dtype=torch.int32, device=dev)
         call("lidiff_tail_map_dev", ptr(nbr_bound), k, m_bound, ptr(d_m), 13, ptr(off), ptr(row_ptr), 0, None, None, ptr(ws), stream_ptr())
         return cls(None, bounded=(nbr_bound, m_bound, d_m, ws, off, row_ptr,
-                                  TAIL_PAIR_BOUND * m_bound if n_bound is None else n_bound, status))
+                                  max(1, int(TAIL_PAIR_BOUND * m_bound)) if n_bound is None else n_bound, status))
 
     def _from_phase1(self, nbr_bound, m_bound, d_m, ws, off, row_ptr, n, m):
         """Phase 2 over the table of pitch m_bound whose phase 1 ran in build_pyramid(); filled when first asked for."""

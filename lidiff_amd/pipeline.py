@@ -98,17 +98,32 @@ class DiffCompletion(nn.Module):
             feeds[role] = ops.SizeFeed(self.device)
         return feeds[role]
 
+    def _loop_status(self):
+        """ONE status word for all the coordinate managers of a loop's fields (roles): a bound exceeded by a kernel that runs long
+        after its pyramid was published (a tail map filled when a layer first asks for it) still reaches the host -- with the
+        next pyramid's record, and through read_free_check() at the latest."""
+        if self.__dict__.get("_status") is None:
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._status
+
     def read_free_reset(self):
         """A new scan: the first pyramid of every role is built with a host read again."""
         for f in self.__dict__.get("_feeds", {}).values():
             f.reset()
+        if self.__dict__.get("_status") is not None:
+            self._status.zero_()
 
     def read_free_check(self):
-        """None, or why the host-read-free steps since the last reset are void (waits for the sizes the device still owes)."""
+        """None, or why the host-read-free steps since the last reset are void (waits for the sizes the device still owes and
+        reads the loop's status word: one synchronisation, at the END of a loop)."""
+        from . import ops
         for role, f in self.__dict__.get("_feeds", {}).items():
             bad = f.drain()
             if bad is not None:
                 return f"{role}: {bad}"
+        if self.__dict__.get("_status") is not None and any(f.has_records() for f in self._feeds.values()):
+            if int(self._status.item()) & ops.STATUS_BOUND:
+                return "a device-side count exceeded its bound (the loop's status word)"
         return None
 
     # pipeline:68-84
@@ -132,6 +147,7 @@ class DiffCompletion(nn.Module):
         if (role is not None and mgr.pyramid and (self.read_free or self.hint_lag) and self.pair_cfg and minknet._FUSION
                 and not self.training and feats.shape[0] >= 1):
             mgr.feed = self._feed(role)
+            mgr.status = self._loop_status()
             mgr.read_free = bool(self.read_free)
             mgr.hint_lag = bool(self.hint_lag) and not self.read_free
             if role != "x_t":            # the condition's latent shapes host-side work (MLP tables, match targets): exact rows
@@ -164,6 +180,7 @@ class DiffCompletion(nn.Module):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._side2 = torch.cuda.Stream(device=self.device)     # second side stream: the matches next to the kernel maps
+            self._side3 = torch.cuda.Stream(device=self.device)     # third: the deeper levels of a host-read-free pyramid
         return torch.cuda.current_stream(self.device), self._side
 
     def prepare(self, field, tail_maps=True, also=None, up_orders=False):
@@ -477,9 +494,10 @@ class DiffCompletion(nn.Module):
                         x_t.ready.record(main)
                     x_t.F.record_stream(side), x_t.C.record_stream(side)
                     mgr = x_t.coordinate_manager
+                    mgr.lane_up_orders = bool(minknet._UP_ORDERED)
                     mgr.set_async(side, self._side2, ready=x_t.ready, on_level=lambda ts: self._match_level(x_t, parts, ts, ahead=True),
                                   on_level_dev=(lambda ts, rows, cnt: self._match_level_dev(parts, ts, rows, cnt))
-                                  if self.match_in_chain else None)
+                                  if self.match_in_chain else None, side3=self._side3)
                     try:
                         x_t_sparse = x_t.sparse()
                         self._mark(marks)
@@ -545,14 +563,12 @@ class DiffCompletion(nn.Module):
         steps did not hold (a tail map above its pair bound, a condition latent of another size than the step before), the whole
         loop is redone from the same inputs, scheduler state and random draws with exact sizes -- same results as if it had run
         that way from the start."""
+        self.read_free_reset()          # the first pyramid of every role in this loop is built with its host read
         if not (self.read_free and x_t.F.device.type == "cuda"):
             return self._completion_loop(x_init, x_t, x_cond, x_uncond, noises)
-        import copy
         sch = self.dpm_scheduler
         saved = {k: (list(v) if isinstance(v, list) else v) for k, v in sch.__dict__.items()}
         rng = torch.cuda.get_rng_state(self.device) if noises is None else None
-        for f in self.__dict__.get("_feeds", {}).values():
-            f.bad = None
         try:
             out = self._completion_loop(x_init, x_t, x_cond, x_uncond, noises, check=False)
             why = self.read_free_check()

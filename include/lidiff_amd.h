@@ -371,6 +371,8 @@ int lidiff_bn_bwd(const float* dy, const float* x, const float* y_relu, int64_t 
  * train.py:90 / train_refine.py:58 (convert_sync_batchnorm) put in place of every MinkowskiBatchNorm under DDP.  The library never
  * communicates: it hands the caller the LOCAL per-channel sums as fp64, the caller all-reduces them (RCCL; SUM is exact enough in
  * fp64 to make every rank derive bit-identical statistics) and hands them back.
+ *   (Every piece below takes m = 0 -- and x / dy / y NULL then: a rank without a row of some layer still joins the layer's
+ *    collectives, with zero sums and a count of zero, as torch's SyncBatchNorm lets it.)
  *   lidiff_bn_sums            : sums[0..c) = sum x, sums[c..2c) = sum x^2 over this rank's m rows, sums[2c] = m.  The caller
  *                               all-reduces all 2c + 1 doubles in ONE collective.
  *   lidiff_bn_stats_from_sums : mean / biased var / invstd of lidiff_bn_stats from such (all-reduced) sums, count = sums[2c]

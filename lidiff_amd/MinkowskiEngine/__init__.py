@@ -771,7 +771,7 @@ class MinkowskiBatchNorm(nn.Module):
         # torch's channels-last batch-norm kernels run at a tenth of the HBM rate on these shapes); the sync variant
         # (ops.SyncBatchNorm1d) takes the same kernels around one all-reduce of the per-channel sums; momentum = None
         # (cumulative average) stays on torch
-        if ops.bn_module_fused(bn) and ops.bn_train_applies(x.F):
+        if ops.bn_module_fused(bn) and ops.bn_fused_applies(bn, x.F):
             return x._like(ops.batch_norm_train(x.F, bn))
         return x._like(bn(x.F))
 

@@ -240,11 +240,17 @@ extern "C" int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, 
 }
 
 // -- SyncBatchNorm pieces: local sums -> [all-reduce by the caller] -> statistics -------------------------------------------------
+// (The synchronised pieces take m == 0 as well: a rank that holds no row of some layer still takes part in the layer's
+//  collective -- with zero sums and a row count of zero -- as torch's SyncBatchNorm lets it)
 extern "C" int lidiff_bn_sums(const float* x, int64_t m, int32_t c, double* sums, void* workspace, void* stream) {
-    LIDIFF_CHECK_ARG(x && sums && workspace, "null pointer");
-    LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
+    LIDIFF_CHECK_ARG(sums && workspace && (x || m == 0), "null pointer");
+    LIDIFF_CHECK_ARG(m >= 0 && bn_shape_ok(m > 0 ? m : 1, c), "need m >= 0 and c a multiple of 4 in [4, 1024]");
     LIDIFF_CHECK_ARG(((uintptr_t)x & 15) == 0, "x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (m == 0) {
+        LIDIFF_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)(2 * c + 1) * sizeof(double), st));
+        return 0;
+    }
     int64_t per;
     const int nblk = bn_blocks(m, c, &per);
     const size_t lds = (size_t)bn_rows_per_block(c) * c * 2 * sizeof(double);
@@ -266,9 +272,13 @@ extern "C" int lidiff_bn_stats_from_sums(const double* sums, int32_t c, float ep
 
 extern "C" int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                                   double* sums, void* workspace, void* stream) {
-    LIDIFF_CHECK_ARG(dy && x && mean && sums && workspace, "null pointer");
-    LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
+    LIDIFF_CHECK_ARG(mean && sums && workspace && ((dy && x) || m == 0), "null pointer");
+    LIDIFF_CHECK_ARG(m >= 0 && bn_shape_ok(m > 0 ? m : 1, c), "need m >= 0 and c a multiple of 4 in [4, 1024]");
     hipStream_t st = (hipStream_t)stream;
+    if (m == 0) {
+        LIDIFF_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)(2 * c) * sizeof(double), st));
+        return 0;
+    }
     int64_t per;
     const int nblk = bn_blocks(m, c, &per);
     const size_t lds = (size_t)bn_rows_per_block(c) * c * 2 * sizeof(double);
@@ -282,11 +292,11 @@ extern "C" int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* 
 extern "C" int lidiff_bn_bwd_apply(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                                    const float* invstd, const float* gamma, const double* sums, const double* count,
                                    float* sum_dy, float* sum_dy_xmu, float* dx, float* d_residual, void* stream) {
-    LIDIFF_CHECK_ARG(dy && x && mean && invstd && sums && count && sum_dy && sum_dy_xmu, "null pointer");
-    LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
+    LIDIFF_CHECK_ARG(mean && invstd && sums && count && sum_dy && sum_dy_xmu && ((dy && x) || m == 0), "null pointer");
+    LIDIFF_CHECK_ARG(m >= 0 && bn_shape_ok(m > 0 ? m : 1, c), "need m >= 0 and c a multiple of 4 in [4, 1024]");
     hipStream_t st = (hipStream_t)stream;
     bn_bwd_from_sums_kernel<<<(unsigned)ceil_div(c, 256), 256, 0, st>>>(sums, c, sum_dy, sum_dy_xmu);
-    if (dx != nullptr || d_residual != nullptr) {
+    if (m > 0 && (dx != nullptr || d_residual != nullptr)) {
         const int64_t total4 = m * (c / 4);
         const unsigned grid = (unsigned)ceil_div(total4, 256);
         if (y_relu) bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(dy, x, y_relu, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, 0.f, dx, d_residual, count);
@@ -299,8 +309,9 @@ extern "C" int lidiff_bn_bwd_apply(const float* dy, const float* x, const float*
 extern "C" int lidiff_bn_apply(const float* x, int64_t m, int32_t c, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, const float* residual, int32_t relu, float* y,
                                void* stream) {
-    LIDIFF_CHECK_ARG(x && mean && invstd && y, "null pointer");
-    LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
+    LIDIFF_CHECK_ARG(mean && invstd && ((x && y) || m == 0), "null pointer");
+    LIDIFF_CHECK_ARG(m >= 0 && bn_shape_ok(m > 0 ? m : 1, c), "need m >= 0 and c a multiple of 4 in [4, 1024]");
+    if (m == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total4 = m * (c / 4);
     const unsigned grid = (unsigned)ceil_div(total4, 256);

@@ -16,7 +16,7 @@
 
 // every product and sum below is rounded on its own, as the reference's separate torch launches round them: no contraction
 // into fused multiply-adds anywhere in this file (hipcc's default for device code is -ffp-contract=fast; build.py also compiles
-// this file with -ffp-contract=off, and tools/check_asm_regs.py --no-fma checks the listing)
+// this file with -ffp-contract=off; tests/test_host.py runs tools/check_asm_regs.py --no-fma over the gfx950 listing)
 #pragma clang fp contract(off)
 
 namespace lidiff {

@@ -107,7 +107,7 @@ def _run_seq(seq, x: ME.SparseTensor) -> ME.SparseTensor:
     while i < len(mods):
         m = mods[i]
         if (i + 1 < len(mods) and type(m) in _ME_BN and isinstance(mods[i + 1], ME.MinkowskiReLU)
-                and ops.bn_module_fused(m.bn) and ops.bn_train_applies(x.F)):
+                and ops.bn_module_fused(m.bn) and ops.bn_fused_applies(m.bn, x.F)):
             x = x._like(ops.batch_norm_train(x.F, m.bn, relu=True))
             i += 2
             continue
@@ -222,7 +222,7 @@ class ResidualBlock(nn.Module):
             # on the tensor that IS normalised (net[:-1]'s output) and only when the shortcut has its shape and dtype
             h = _run_seq(self.net[:-1], x)
             r = self.downsample(x)
-            if ops.bn_train_applies(h.F) and r.F.shape == h.F.shape and r.F.dtype == h.F.dtype:
+            if ops.bn_fused_applies(last.bn, h.F) and r.F.shape == h.F.shape and r.F.dtype == h.F.dtype:
                 return h._like(ops.batch_norm_train(h.F, last.bn, relu=True, residual=r.F))
             return self.relu(last(h) + r)
         return self.relu(_run_seq(self.net, x) + self.downsample(x))

@@ -326,14 +326,19 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     # THE host read of this pyramid: into a pinned buffer, the host spinning on an event query (torch's tolist() goes through a
     # pageable staging copy and a blocking synchronise: ~0.1 ms later at the next launch; LIDIFF_PINNED_READ=0 keeps that form)
     if PINNED_READ:
-        hb = _PINNED.get(counts.numel())
+        import threading
+        key = (counts.numel(), str(dev), threading.get_ident())       # (one staging buffer per size, device AND thread: ADVICE r4)
+        hb = _PINNED.get(key)
         if hb is None:
-            hb = _PINNED[counts.numel()] = torch.empty(counts.numel(), dtype=torch.int32, pin_memory=True)
+            hb = _PINNED[key] = torch.empty(counts.numel(), dtype=torch.int32, pin_memory=True)
         hb.copy_(counts, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        while not done.query():
-            pass
+        for _ in range(20000):                  # a short spin (the chain is ~0.4 ms away), then a blocking wait that frees the GIL
+            if done.query():
+                break
+        else:
+            done.synchronize()
         host = hb.tolist()
     else:
         host = counts.tolist()
@@ -865,6 +870,22 @@ def bn_train_applies(x: torch.Tensor) -> bool:
             and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024)
 
 
+def bn_sync_applies(x: torch.Tensor) -> bool:
+    """The synchronised form of bn_train_applies(): decided from properties that are THE SAME ON EVERY RANK (dtype, width) and
+    never from the local row count -- a rank holding 0 or 1 rows of some layer must issue the same collective as the others
+    (ADVICE r4: a rank-local choice between this path's all-reduce and torch's all-gather-based function deadlocks the group);
+    the kernels take any row count, the statistics are the group's."""
+    return (FUSED_BN_TRAIN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024)
+
+
+def bn_fused_applies(bn, x: torch.Tensor) -> bool:
+    """Does batch_norm_train(x, bn) apply: the rank-invariant rule for a SyncBatchNorm1d that shares statistics, else the local one."""
+    if isinstance(bn, SyncBatchNorm1d) and bn.training and bn.group() is not None:
+        return bn_sync_applies(x)
+    return bn_train_applies(x)
+
+
 class SyncBatchNorm1d(torch.nn.BatchNorm1d):
     """The `.bn` child of ME.MinkowskiSyncBatchNorm (train.py:90 ``convert_sync_batchnorm``): an nn.BatchNorm1d -- same
     parameters, buffers and state-dict keys -- whose TRAINING statistics are taken over every rank of `process_group`.  The
@@ -893,7 +914,7 @@ class SyncBatchNorm1d(torch.nn.BatchNorm1d):
         g = self.group() if self.training else None
         if g is None:
             return super().forward(x)
-        if bn_train_applies(x) and self.momentum is not None and torch.is_grad_enabled():
+        if bn_sync_applies(x) and self.momentum is not None and torch.is_grad_enabled():
             return batch_norm_train(x, self)
         # shapes norm.hip does not take: torch's own synchronised function (same statistics, its kernels)
         from torch.nn.modules._functions import SyncBatchNorm as _TorchSync

@@ -179,7 +179,11 @@ class DiffCompletion(nn.Module):
     def _streams(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
-            self._side2 = torch.cuda.Stream(device=self.device)     # second side stream: the matches next to the kernel maps
+            # second side stream: the part -> full matches next to the kernel maps.  (Round 5 measured this stream with a CU mask --
+            # hipExtStreamCreateWithCUMask, every 8th / 4th / 2nd compute unit left to the other queues, so that the chip-filling
+            # match kernels would not hold back the small kernels of the map-building chain: 41.0 vs 37.5 ms per step, on the
+            # default and on an explicit main stream alike.  A masked queue costs far more than it frees; not kept.)
+            self._side2 = torch.cuda.Stream(device=self.device)
             self._side3 = torch.cuda.Stream(device=self.device)     # third: the deeper levels of a host-read-free pyramid
         return torch.cuda.current_stream(self.device), self._side
 

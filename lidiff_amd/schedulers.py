@@ -131,9 +131,10 @@ class DPMSolverMultistepScheduler:
 
     def step_plan(self, timestep):
         """The host half of step() for a caller that evaluates the update in its own kernel (ops.cfg_dpm_step, the fused step
-        boundary of DiffCompletion.denoise_step): advances the multistep bookkeeping exactly as step() does and returns the
-        update's scalars -- the same Python floats, from the same expressions, that _first_order / _second_order multiply the
-        tensors with -- plus the previous data prediction.  The caller stores the new data prediction with commit()."""
+        boundary of DiffCompletion.denoise_step): returns the update's scalars -- the same Python floats, from the same
+        expressions, that _first_order / _second_order multiply the tensors with -- plus the previous data prediction.  PURE: the
+        multistep bookkeeping step() does (history shift, lower_order_nums) is applied by commit(x0) once the caller's launch
+        has succeeded; a launch that raises leaves the scheduler exactly as it was."""
         if self.num_inference_steps is None:
             raise ValueError("call set_timesteps first")
         if self.algorithm_type != "sde-dpmsolver++":
@@ -144,22 +145,25 @@ class DPMSolverMultistepScheduler:
         t_prev = 0 if step_index == n - 1 else self._host_timesteps[step_index + 1]
         lower_final = step_index == n - 1 and self.lower_order_final and n < 15
         lam, alpha, sigma = self._host_tables()
-        for i in range(self.solver_order - 1):
-            self.model_outputs[i] = self.model_outputs[i + 1]
-        self.model_outputs[-1] = None                       # commit() fills it
         h, a_p, s_p, s_t = self._coeffs(t, t_prev)
         g = a_p * -math.expm1(-2.0 * h)
         plan = {"t": t, "sigma_t": sigma[t], "alpha_t": alpha[t], "c_sample": s_p / s_t * math.exp(-h), "c_m0": g,
                 "c_noise": s_p * math.sqrt(-math.expm1(-2.0 * h)), "m_prev": None, "c_d1": 0.0, "inv_r0": 0.0}
         if not (self.solver_order == 1 or self.lower_order_nums < 1 or lower_final):
+            m_prev = self.model_outputs[-1]                 # (the history has not been shifted yet: the last data prediction)
+            if m_prev is None:
+                raise RuntimeError("second-order step without a previous data prediction (a step was planned but never committed)")
             r0 = (lam[t] - lam[self._host_timesteps[step_index - 1]]) / h
-            plan.update(m_prev=self.model_outputs[-2], c_d1=0.5 * g, inv_r0=1.0 / r0)
-        if self.lower_order_nums < self.solver_order:
-            self.lower_order_nums += 1
+            plan.update(m_prev=m_prev, c_d1=0.5 * g, inv_r0=1.0 / r0)
         return plan
 
     def commit(self, x0):
+        """The bookkeeping of the step that step_plan() described, with its data prediction: what step() does around the update."""
+        for i in range(self.solver_order - 1):
+            self.model_outputs[i] = self.model_outputs[i + 1]
         self.model_outputs[-1] = x0
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
 
     @staticmethod
     def _host_value(timestep: torch.Tensor) -> int:

@@ -891,6 +891,86 @@ def test_two_rank_sync_batchnorm_on_one_gpu_over_gloo(device):
     assert err_out <= 1e-5 and err_grad <= 1e-4 and cos_min >= 0.99999, (err_out, err_grad, cos_min)
 
 
+def _uneven_syncbn_worker(rank, world, port, q):
+    import torch.distributed as tdist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from lidiff_amd import dist as ldist
+    from lidiff_amd import ops
+    ldist.init_from_env("gloo")
+    dev = torch.device("cuda", 0)
+    out = {}
+    for case, rows in _UNEVEN_ROWS.items():
+        x_all, g_all = _uneven_inputs(case)
+        lo = sum(rows[:rank])
+        x = x_all[lo:lo + rows[rank]].to(dev).requires_grad_(True)
+        bn = ops.SyncBatchNorm1d(x_all.shape[1]).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, x_all.shape[1]))
+            bn.bias.copy_(torch.linspace(-1, 1, x_all.shape[1]))
+        assert ops.bn_fused_applies(bn, x), "the synchronised path must not depend on the local row count"
+        y = ops.batch_norm_train(x, bn, relu=(case == "zero"))
+        y.backward(g_all[lo:lo + rows[rank]].to(dev))
+        gw, gb = bn.weight.grad.clone(), bn.bias.grad.clone()
+        tdist.all_reduce(gw)
+        tdist.all_reduce(gb)
+        out[case] = (y.detach().cpu().numpy(), x.grad.cpu().numpy(), gw.cpu().numpy(), gb.cpu().numpy(),
+                     bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy())
+    q.put((rank, out))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+_UNEVEN_ROWS = {"one": (1, 700), "zero": (0, 300)}
+
+
+def _uneven_inputs(case):
+    g = torch.Generator().manual_seed(len(case))
+    n = sum(_UNEVEN_ROWS[case])
+    return torch.randn(n, 32, generator=g) * 2 + 0.5, torch.randn(n, 32, generator=g)
+
+
+def test_sync_batchnorm_when_a_rank_holds_one_or_no_row(device):
+    """the synchronised BatchNorm path is chosen from rank-invariant properties only, and its kernels take 0 / 1 local
+    rows: two processes on cuda:0 over gloo, rank 0 holding ONE row (then NO row) of the layer, rank 1 the rest -- outputs, input
+    gradients, summed weight / bias gradients and running statistics equal nn.BatchNorm1d on the concatenated rows (the collective
+    pattern is the same on both ranks: nothing hangs)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for case in _UNEVEN_ROWS:
+        x_all, g_all = _uneven_inputs(case)
+        x = x_all.clone().double().requires_grad_(True)
+        bn = torch.nn.BatchNorm1d(x_all.shape[1]).double().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, x_all.shape[1]))
+            bn.bias.copy_(torch.linspace(-1, 1, x_all.shape[1]))
+        y = bn(x)
+        if case == "zero":
+            y = torch.relu(y)
+        y.backward(g_all.double())
+        got_y = np.concatenate([res[0][case][0], res[1][case][0]])
+        got_dx = np.concatenate([res[0][case][1], res[1][case][1]])
+        assert got_y.shape == tuple(y.shape)
+        assert np.allclose(got_y, y.detach().numpy(), rtol=1e-5, atol=1e-5), case
+        assert np.allclose(got_dx, x.grad.numpy(), rtol=1e-4, atol=1e-6), case
+        for r in (0, 1):
+            assert np.allclose(res[r][case][2], bn.weight.grad.numpy(), rtol=1e-4, atol=1e-5), case
+            assert np.allclose(res[r][case][3], bn.bias.grad.numpy(), rtol=1e-4, atol=1e-5), case
+            assert np.allclose(res[r][case][4], bn.running_mean.numpy(), rtol=1e-5, atol=1e-6), case
+            assert np.allclose(res[r][case][5], bn.running_var.numpy(), rtol=1e-5, atol=1e-6), case
+
+
 def _two_rank_train_worker(rank, world, port, q):
     import torch.distributed as tdist
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",

@@ -273,6 +273,67 @@ def test_bench_launches_its_own_ranks():
         assert r.returncode != 0 and "only 0 GPU(s) visible" in r.stderr
 
 
+def test_step_boundary_kernels_contain_no_fused_multiply_add(tmp_path):
+    """step.hip promises the torch sequence bit for bit -- every product and sum rounded on its own (the claim has to be
+    checked on the generated code, whatever route built it): the gfx950 listing of the file, compiled as build.py compiles it,
+    holds no v_fma / v_fmac / v_mad instruction; and the same source WITHOUT the flag and pragma would (the check can fail)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    from lidiff_amd.csrc import build as hip_build
+    src = os.path.join(ROOT, "lidiff_amd", "csrc", "step.hip")
+    assert "-ffp-contract=off" in hip_build.EXTRA_FLAGS["step.hip"]
+
+    def listing(path_in, flags, name):
+        out = os.path.join(tmp_path, name)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--cuda-device-only", "-S", path_in,
+                            "-o", out, "-I", os.path.dirname(src)] + flags, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_regs.py"), "--no-fma", out],
+                              capture_output=True, text=True, timeout=120)
+    ok = listing(src, hip_build.EXTRA_FLAGS["step.hip"], "step.s")
+    assert ok.returncode == 0 and ok.stdout.startswith("0 fused"), ok.stdout[:1500]
+    loose = os.path.join(tmp_path, "step_contract.hip")
+    with open(loose, "w") as f:
+        f.write(open(src).read().replace("#pragma clang fp contract(off)", ""))
+    bad = listing(loose, ["-ffp-contract=fast"], "step_contract.s")
+    assert bad.returncode == 1 and not bad.stdout.startswith("0 fused"), "the check cannot see a contracted multiply-add"
+
+
+def test_step_plan_is_pure_until_commit():
+    """DPMSolverMultistepScheduler.step_plan() (the host half of the fused step boundary) changes nothing; commit(x0) applies the
+    bookkeeping step() does -- a planned step whose launch raised leaves the scheduler usable, and a second-order
+    plan without a committed predecessor is refused instead of silently falling back to first order."""
+    import copy
+    from lidiff_amd.schedulers import DPMSolverMultistepScheduler
+    mk = lambda: DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_start=3.5e-5, beta_end=0.007, beta_schedule="linear",
+                                             algorithm_type="sde-dpmsolver++", solver_order=2)
+    s, ref = mk(), mk()
+    s.set_timesteps(50), ref.set_timesteps(50)
+    ts = s.host_timesteps
+    x = torch.zeros(1, 4, 3, dtype=torch.float64)
+    for i, t in enumerate(ts[:4]):
+        before = (list(s.model_outputs), s.lower_order_nums)
+        p1, p2 = s.step_plan(t), s.step_plan(t)                       # planning twice == planning once
+        assert (list(s.model_outputs), s.lower_order_nums) == before
+        assert {k: v for k, v in p1.items() if k != "m_prev"} == {k: v for k, v in p2.items() if k != "m_prev"}
+        assert (p1["m_prev"] is None) == (i == 0)
+        x0 = torch.full_like(x, float(i + 1))
+        s.commit(x0)
+        ref.step(torch.zeros_like(x), t, x, noise=torch.zeros_like(x))
+        assert s.lower_order_nums == ref.lower_order_nums
+        assert [m is None for m in s.model_outputs] == [m is None for m in ref.model_outputs]
+        if i:
+            assert p1["m_prev"] is not None and float(p1["m_prev"].flatten()[0]) == float(i)
+    broken = copy.copy(s)
+    broken.model_outputs = [None, None]
+    with pytest.raises(RuntimeError, match="previous data prediction"):
+        broken.step_plan(ts[4])
+
+
 @pytest.mark.parametrize("source", ["spconv_bf16.hip"])
 def test_asm_kernel_isa_never_reads_an_in_flight_register(tmp_path, source):
     """spconv_bf16.hip requests its LDS fragments with inline asm and waits for them with counted s_waitcnt, so the

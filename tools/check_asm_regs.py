@@ -1,4 +1,16 @@
+"""Checks over a gfx950 assembly listing (hipcc -S --cuda-device-only):
+   python tools/check_asm_regs.py file.s            no instruction reads a register an inline-asm ds_read still has in flight
+   python tools/check_asm_regs.py --no-fma file.s   no fused multiply-add anywhere (step.hip restates separately rounded torch
+                                                    launches: a contracted a * b + c would change voxelisation at cell boundaries)"""
 import re, sys
+if "--no-fma" in sys.argv:
+    path = [a for a in sys.argv[1:] if a != "--no-fma"][0]
+    hits = [(n + 1, l.strip()) for n, l in enumerate(open(path).read().split('\n'))
+            if re.match(r'\s*v_(pk_)?(fma|fmac|mad|mac)_(f|legacy_f)(16|32|64)', l)]
+    print(len(hits), "fused multiply-add instructions")
+    for n, l in hits[:20]:
+        print("  line %d: %s" % (n, l))
+    sys.exit(1 if hits else 0)
 lines=open(sys.argv[1]).read().split('\n')
 def regs(tok):
     mm=re.match(r'v\[?(\d+)(?::(\d+))?\]?$', tok.strip())

@@ -359,6 +359,63 @@ def train_leg(scan_np, device, steps=3, warmup=1):
     return out
 
 
+def train_refine_leg(scan_np, device, items=2, steps=2, warmup=1):
+    """Beside the metric, never `value`: RefineDiffusion.training_step (models_refine.py:53-76) at config_refine.yaml's per-item
+    size -- 180 000 noisy points in, 6 x 180 000 predicted against 2 x 180 000 target points in the Chamfer loss (the grid search
+    of lidiff_nn_dist_grid: the exhaustive one needs 7.8e11 distance evaluations per item) -- B = `items` (the config's 8 is a
+    matter of memory-time only: items are independent in the loss and share nothing but BatchNorm statistics)."""
+    from lidiff_amd import ops
+    from lidiff_amd.diffusion import RefineDiffusion, chamfer_distance
+    rng = np.random.default_rng(1)
+    base = np.tile(scan_np.astype(np.float32), (10, 1))
+    full = np.stack([np.concatenate([base, base + 0.04 * rng.standard_normal(base.shape).astype(np.float32)]) for _ in range(items)])
+    noise = np.stack([base + 0.1 * rng.standard_normal(base.shape).astype(np.float32) for _ in range(items)])
+    batch = {"pcd_noise": torch.from_numpy(noise), "pcd_full": torch.from_numpy(full)}
+    torch.manual_seed(0)
+    module = RefineDiffusion(device=device)
+    module.train()
+    opt = module.configure_optimizers()
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    tot = [0.0, 0.0, 0.0]
+    torch.cuda.reset_peak_memory_stats()
+    for step in range(warmup + steps):
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        loss = module.training_step(batch, step)
+        e[1].record()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        e[2].record()
+        opt.step()
+        e[3].record()
+        torch.cuda.synchronize()
+        if step >= warmup:
+            for i in range(3):
+                tot[i] += e[i].elapsed_time(e[i + 1])
+    # the loss alone (both directed searches + the differentiable distances), forward + backward, per item
+    pred = (torch.from_numpy(np.repeat(noise[:1], 6, axis=1)).to(device) + 0.05 * torch.randn(1, 6 * base.shape[0], 3, device=device))
+    pred.requires_grad_(True)
+    tgt = torch.from_numpy(full[:1]).to(device)
+    cd = []
+    for _ in range(3):
+        a, b = ev(), ev()
+        a.record()
+        chamfer_distance(pred, tgt).backward()
+        b.record()
+        torch.cuda.synchronize()
+        cd.append(a.elapsed_time(b))
+    total = sum(tot) / steps
+    out = {"workload": f"config_refine.yaml per-item shape, B = {items}: 180000 noisy points -> MinkUNet -> 6 x 180000 predicted vs "
+                       "2 x 180000 target points, Chamfer loss (pytorch3d defaults), backward, Adam; random-init weights",
+           "ms_per_step": total, "ms_per_item": total / items, "forward_loss_ms": tot[0] / steps, "backward_ms": tot[1] / steps,
+           "optimizer_ms": tot[2] / steps, "chamfer_fwd_bwd_ms_per_item": min(cd),
+           "nearest_neighbour": f"lidiff_nn_dist_grid, cell {ops.NN_GRID_CELL} m (exact: bit-identical to the exhaustive search)",
+           "peak_memory_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "final_loss": float(loss.detach()), "steps": steps}
+    del module, opt, loss
+    torch.cuda.empty_cache()
+    return out
+
+
 def load_raw_scan():
     """The reference's bundled scan after its range filter (119 035 points): what preprocess_scan's FPS takes in."""
     return np.load(os.path.join(ROOT, "tests", "golden", "scan_000123_range_filtered.npy")).astype(np.float64)
@@ -745,6 +802,7 @@ def main():
         del pipe
         torch.cuda.empty_cache()
         out["train"] = train_leg(scan_np, device)
+        out["train_refine"] = train_refine_leg(scan_np, device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scan_np, threads=args.cpu_threads)
     emit(json.dumps(out))

@@ -83,6 +83,8 @@ SIGNATURES = {
     "lidiff_host_device_pointer": (_i32, [_p, _p]),
     "lidiff_nn_dist_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "lidiff_nn_dist": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
+    "lidiff_nn_dist_grid_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "lidiff_nn_dist_grid": (_i32, [_p, _i64, _p, _i64, _i32, C.c_double, _p, _p, _p, _p]),
 }
 
 ABI_VERSION = 25

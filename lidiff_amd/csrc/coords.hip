@@ -1103,6 +1103,13 @@ __global__ __launch_bounds__(kFpsBlock) void fps_coop_kernel(const double* __res
 // partial winners of the splits are merged in ascending split order with strict '<', so the lowest b index wins ties.
 constexpr int kNnTile = 1024;
 constexpr int kNnPt = 2;
+// the squared distance as BOTH nearest-neighbour kernels form it (one expression, one contraction pattern: equal bits)
+template <typename T>
+__device__ __forceinline__ T nn_d2(T ax, T ay, T az, T bx, T by, T bz) {
+    const T dx = ax - bx, dy = ay - by, dz = az - bz;
+    return dx * dx + dy * dy + dz * dz;
+}
+
 template <typename T>
 __global__ void nn_dist_kernel(const T* __restrict__ a, int64_t n, const T* __restrict__ b, int64_t m,
                                int64_t m_per_split, T* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
@@ -1128,8 +1135,7 @@ __global__ void nn_dist_kernel(const T* __restrict__ a, int64_t n, const T* __re
             const T bx = tx[t], by = ty[t], bz = tz[t];
 #pragma unroll
             for (int q = 0; q < kNnPt; ++q) {
-                const T dx = ax[q] - bx, dy = ay[q] - by, dz = az[q] - bz;
-                const T d = dx * dx + dy * dy + dz * dz;
+                const T d = nn_d2(ax[q], ay[q], az[q], bx, by, bz);
                 if (d < best[q]) { best[q] = d; best_j[q] = (int32_t)(base + t); }
             }
         }
@@ -1155,6 +1161,170 @@ __global__ void nn_dist_merge_kernel(const T* __restrict__ part_d2, const int32_
     }
     d2[i] = best;
     idx[i] = j;
+}
+
+// ---------------------------------------------------------------------------------------
+// The same nearest neighbour through a uniform grid over the searched cloud (the refinement network's Chamfer
+// loss, models_refine.py:72, compares 6 x 180 000 predicted with 2 x 180 000 target points per batch item: 3.9e11 distance
+// evaluations per direction for the exhaustive kernel).  b's points are binned into cubic cells of edge `cell` -- the cells are
+// the voxel hash of coords.hip (insert / flag / scan, 16-bit cell coordinates) -- and stored cell by cell; a query walks the
+// cubic shells of cells around its own cell, nearest first, and stops once its best distance is below the nearest possible
+// point of every unvisited shell.  EXACT: the same squared distances (nn_d2), the lowest index on ties (a tie in a farther
+// shell is still visited: the stop test is strict and takes 0.5 % off the shell's distance for the rounding of the cell
+// assignment) -- bit-identical (d2, idx) to nn_dist_kernel.  Queries that have not finished after kGridShells shells (far from
+// every point of b) and clouds whose cells leave the 16-bit key range go through the exhaustive kernel.
+constexpr int kGridShells = 6;
+
+template <typename T>
+__device__ __forceinline__ int grid_cell(T x, T inv_cell) { return (int)floor((double)x * (double)inv_cell); }
+
+template <typename T>
+__global__ void grid_cells_kernel(const T* __restrict__ b, int64_t m, T inv_cell, int32_t* __restrict__ cells) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    reinterpret_cast<int4*>(cells)[j] = make_int4(0, grid_cell(b[3 * j], inv_cell), grid_cell(b[3 * j + 1], inv_cell),
+                                                  grid_cell(b[3 * j + 2], inv_cell));
+}
+
+__global__ void grid_count_kernel(const int32_t* __restrict__ cell_of, int64_t m, int32_t* __restrict__ cnt) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) atomicAdd(&cnt[cell_of[j]], 1);
+}
+
+// points into their cell's slice (the order inside a cell is whatever the atomics give: the search breaks ties by index)
+template <typename T>
+__global__ void grid_fill_kernel(const T* __restrict__ b, const int32_t* __restrict__ cell_of, int64_t m,
+                                 const int32_t* __restrict__ start, int32_t* __restrict__ cursor, T* __restrict__ sx,
+                                 int32_t* __restrict__ sj) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int c = cell_of[j];
+    const int pos = start[c] + atomicAdd(&cursor[c], 1);
+    sx[3 * (int64_t)pos] = b[3 * j]; sx[3 * (int64_t)pos + 1] = b[3 * j + 1]; sx[3 * (int64_t)pos + 2] = b[3 * j + 2];
+    sj[pos] = (int32_t)j;
+}
+
+template <typename T>
+__global__ void grid_query_kernel(const T* __restrict__ a, int64_t n, T cell, T inv_cell, const uint64_t* __restrict__ hkeys,
+                                  const int32_t* __restrict__ hvals, uint32_t mask, const int32_t* __restrict__ start,
+                                  const T* __restrict__ sx, const int32_t* __restrict__ sj, const int32_t* __restrict__ d_status,
+                                  T* __restrict__ d2, int64_t* __restrict__ idx, int32_t* __restrict__ left, int32_t* __restrict__ n_left) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T ax = a[3 * i], ay = a[3 * i + 1], az = a[3 * i + 2];
+    T best = (T)INFINITY;
+    int32_t best_j = 0x7fffffff;
+    bool done = false;
+    // (a cloud whose cells left the key range was not binned completely: everything goes to the exhaustive pass)
+    if ((*d_status & LIDIFF_STATUS_KEY_RANGE) == 0 && ax == ax && ay == ay && az == az) {
+        const int cx = grid_cell(ax, inv_cell), cy = grid_cell(ay, inv_cell), cz = grid_cell(az, inv_cell);
+        for (int r = 0; r <= kGridShells && !done; ++r) {
+            for (int dz = -r; dz <= r; ++dz)
+                for (int dy = -r; dy <= r; ++dy) {
+                    const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+                    for (int dx = -r; dx <= r; dx += (face || r == 0) ? 1 : 2 * r) {      // interior rows: the two end cells only
+                        bool ok;
+                        const uint64_t key = pack_key(0, cx + dx, cy + dy, cz + dz, ok);
+                        if (!ok) continue;
+                        const int c = hash_find(hkeys, hvals, mask, key);
+                        if (c < 0) continue;
+                        for (int q = start[c], qe = start[c + 1]; q < qe; ++q) {
+                            const T d = nn_d2(ax, ay, az, sx[3 * (int64_t)q], sx[3 * (int64_t)q + 1], sx[3 * (int64_t)q + 2]);
+                            const int32_t j = sj[q];
+                            if (d < best || (d == best && j < best_j)) { best = d; best_j = j; }
+                        }
+                    }
+                }
+            // every point of a shell beyond r is farther than r cells (minus the rounding slack of the cell assignment)
+            const T reach = (T)(0.995 * (double)r) * cell;
+            done = best < reach * reach;
+        }
+    }
+    if (done) {
+        d2[i] = best;
+        idx[i] = best_j;
+    } else {
+        left[atomicAdd(n_left, 1)] = (int32_t)i;
+    }
+}
+
+// the exhaustive search for the queries the grid did not finish: one workgroup per 256 of them, b through LDS tiles
+template <typename T>
+__global__ void grid_leftover_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t m, const int32_t* __restrict__ left,
+                                     const int32_t* __restrict__ n_left, T* __restrict__ d2, int64_t* __restrict__ idx) {
+    __shared__ T tx[kNnTile], ty[kNnTile], tz[kNnTile];
+    const int total = *n_left;
+    for (int base_q = blockIdx.x * blockDim.x; base_q < total; base_q += gridDim.x * blockDim.x) {
+        const int qi = base_q + threadIdx.x;
+        const int64_t i = qi < total ? left[qi] : -1;
+        const T ax = i >= 0 ? a[3 * i] : (T)0, ay = i >= 0 ? a[3 * i + 1] : (T)0, az = i >= 0 ? a[3 * i + 2] : (T)0;
+        T best = (T)INFINITY;
+        int32_t best_j = 0;
+        for (int64_t base = 0; base < m; base += kNnTile) {
+            const int cnt = (int)min((int64_t)kNnTile, m - base);
+            __syncthreads();
+            for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+                tx[t] = b[3 * (base + t)]; ty[t] = b[3 * (base + t) + 1]; tz[t] = b[3 * (base + t) + 2];
+            }
+            __syncthreads();
+            for (int t = 0; t < cnt; ++t) {
+                const T d = nn_d2(ax, ay, az, tx[t], ty[t], tz[t]);
+                if (d < best) { best = d; best_j = (int32_t)(base + t); }
+            }
+        }
+        if (i >= 0) { d2[i] = best; idx[i] = best_j; }
+    }
+}
+
+struct GridWs {            // workspace layout of lidiff_nn_dist_grid (all offsets 16-byte aligned)
+    int32_t* cells; uint64_t* hkeys; int32_t* hvals; int32_t* uniq; int32_t* cell_of; int32_t* unique_ws; int32_t* start;
+    int32_t* cursor; int32_t* sj; int32_t* left; int32_t* head; void* sx; int64_t cap, bytes;
+};
+
+static GridWs grid_ws(void* ws, int64_t n, int64_t m, int eb) {
+    GridWs w{};
+    char* p = (char*)ws;
+    auto take = [&](int64_t bytes) { char* q = p; p += (bytes + 15) / 16 * 16; return q; };
+    w.cap = 1024;
+    while (w.cap < 2 * m) w.cap <<= 1;
+    w.head = (int32_t*)take(64);                                   // [0] cells, [1] leftover queries, [2] status
+    w.cells = (int32_t*)take(m * 16);
+    w.hkeys = (uint64_t*)take(w.cap * 8);
+    w.hvals = (int32_t*)take(w.cap * 4);
+    w.uniq = (int32_t*)take(m * 16);
+    w.cell_of = (int32_t*)take(m * 4);
+    w.unique_ws = (int32_t*)take((m + ceil_div(m > 0 ? m : 1, kBlock) + 16) * 4);
+    w.start = (int32_t*)take((m + 2) * 4);
+    w.cursor = (int32_t*)take((m + 1) * 4);
+    w.sj = (int32_t*)take(m * 4);
+    w.left = (int32_t*)take(n * 4);
+    w.sx = (void*)take(m * 3 * eb);
+    w.bytes = p - (char*)ws;
+    return w;
+}
+
+template <typename T>
+static int nn_dist_grid_launch(const void* a, int64_t n, const void* b, int64_t m, double cell, void* d2, int64_t* idx, void* ws,
+                               hipStream_t st) {
+    GridWs w = grid_ws(ws, n, m, (int)sizeof(T));
+    const T inv_cell = (T)(1.0 / cell);
+    LIDIFF_CHECK_HIP(hipMemsetAsync(w.head, 0, 64, st));
+    grid_cells_kernel<T><<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>((const T*)b, m, inv_cell, w.cells);
+    const int rc = run_unique(w.cells, m, nullptr, 1, w.hkeys, w.hvals, w.cap, w.uniq, nullptr, w.cell_of, false, w.head, w.head + 2,
+                              w.unique_ws, st);
+    if (rc != 0) return rc;
+    // cell sizes -> slice starts (over the bound m: cells behind the count are empty) -> points in cell order
+    LIDIFF_CHECK_HIP(hipMemsetAsync(w.start, 0, (size_t)(m + 2) * 4, st));
+    LIDIFF_CHECK_HIP(hipMemsetAsync(w.cursor, 0, (size_t)(m + 1) * 4, st));
+    grid_count_kernel<<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>(w.cell_of, m, w.start);
+    scan_i32_kernel<<<1, 1024, 0, st>>>(w.start, m + 1);
+    grid_fill_kernel<T><<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>((const T*)b, w.cell_of, m, w.start, w.cursor, (T*)w.sx, w.sj);
+    grid_query_kernel<T><<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>((const T*)a, n, (T)cell, inv_cell, w.hkeys, w.hvals,
+                                                                          (uint32_t)(w.cap - 1), w.start, (const T*)w.sx, w.sj,
+                                                                          w.head + 2, (T*)d2, idx, w.left, w.head + 1);
+    grid_leftover_kernel<T><<<256, kBlock, 0, st>>>((const T*)a, (const T*)b, m, w.left, w.head + 1, (T*)d2, idx);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
 }
 
 static int nn_dist_splits(int64_t n, int64_t m) {
@@ -1659,6 +1829,21 @@ int lidiff_nn_dist(const void* a, int64_t n, const void* b, int64_t m, int32_t e
     else nn_dist_launch<double>(a, n, b, m, d2, idx, workspace, (hipStream_t)stream);
     LIDIFF_CHECK_LAUNCH();
     return 0;
+}
+
+int64_t lidiff_nn_dist_grid_workspace_bytes(int64_t n, int64_t m, int32_t elem_bytes) {
+    return grid_ws(nullptr, n > 0 ? n : 1, m > 0 ? m : 1, elem_bytes).bytes + 64;
+}
+
+int lidiff_nn_dist_grid(const void* a, int64_t n, const void* b, int64_t m, int32_t elem_bytes, double cell, void* d2, int64_t* idx,
+                        void* workspace, void* stream) {
+    LIDIFF_CHECK_ARG(elem_bytes == 4 || elem_bytes == 8, "elem_bytes must be 4 (float) or 8 (double)");
+    LIDIFF_CHECK_ARG(m >= 1 && m < (int64_t)1 << 30 && n < (int64_t)1 << 31, "cloud sizes");
+    LIDIFF_CHECK_ARG(cell > 0.0, "cell edge must be positive");
+    LIDIFF_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "workspace must be 16-byte aligned");
+    if (n == 0) return 0;
+    if (elem_bytes == 4) return nn_dist_grid_launch<float>(a, n, b, m, cell, d2, idx, workspace, (hipStream_t)stream);
+    return nn_dist_grid_launch<double>(a, n, b, m, cell, d2, idx, workspace, (hipStream_t)stream);
 }
 
 }  // extern "C"

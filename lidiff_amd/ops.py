@@ -1439,10 +1439,17 @@ def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
     return sel
 
 
-def nn_dist(a: torch.Tensor, b: torch.Tensor):
+# nn_dist goes through the uniform grid (lidiff_nn_dist_grid: same results, bit for bit) from this many point pairs on
+NN_GRID_MIN_PAIRS = int(float(os.environ.get("LIDIFF_NN_GRID_MIN_PAIRS", "2e8")))
+NN_GRID_CELL = 0.5          # metres (LiDiff's clouds): ~25 surface points per cell at the scans' density; results do not depend on it
+
+
+def nn_dist(a: torch.Tensor, b: torch.Tensor, grid: bool | None = None, cell: float | None = None):
     """Squared distance and row index of the nearest point of b [M,3] for every point of a [N,3] (float32 or
     float64, lowest index on ties): open3d compute_point_cloud_distance (utils/metrics.py:68,128-129) and the
-    K=1 search of pytorch3d chamfer_distance (models_refine.py:72).  Returns (d2 [N], idx int64 [N])."""
+    K=1 search of pytorch3d chamfer_distance (models_refine.py:72).  Returns (d2 [N], idx int64 [N]).
+    grid: search through a uniform grid over b (cells of edge `cell`) instead of scanning all of b -- exact, identical results;
+    None = from NN_GRID_MIN_PAIRS point pairs on."""
     require_device(a, b)
     if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.float64):
         raise TypeError("nn_dist needs two float32 or two float64 clouds")
@@ -1453,6 +1460,12 @@ def nn_dist(a: torch.Tensor, b: torch.Tensor):
     n, m, eb = a.shape[0], b.shape[0], a.element_size()
     d2 = torch.empty(n, dtype=a.dtype, device=a.device)
     idx = torch.empty(n, dtype=torch.int64, device=a.device)
+    if grid is None:
+        grid = n * m >= NN_GRID_MIN_PAIRS
+    if grid and m >= 1 and n >= 1:
+        ws = torch.empty(_lib.load().lidiff_nn_dist_grid_workspace_bytes(n, m, eb), dtype=torch.uint8, device=a.device)
+        call("lidiff_nn_dist_grid", ptr(a), n, ptr(b), m, eb, float(cell or NN_GRID_CELL), ptr(d2), ptr(idx), ptr(ws), stream_ptr())
+        return d2, idx
     ws = torch.empty(_lib.load().lidiff_nn_dist_workspace_bytes(n, m, eb), dtype=torch.uint8, device=a.device)
     call("lidiff_nn_dist", ptr(a), n, ptr(b), m, eb, ptr(d2), ptr(idx), ptr(ws), stream_ptr())
     return d2, idx

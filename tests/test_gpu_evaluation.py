@@ -128,3 +128,50 @@ def test_chamfer_loss_value_and_gradient(device):
     ref = (d.min(dim=2).values.mean(dim=1) + d.min(dim=1).values.mean(dim=1)).mean()
     ref.backward()
     assert torch.allclose(pred.grad, ref_in.grad, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_nn_dist_grid_is_bit_identical_to_the_exhaustive_search(device, fps_scan, dtype):
+    """lidiff_nn_dist_grid (uniform grid over the searched cloud, shells of cells nearest first) against
+    lidiff_nn_dist: the same d2 BITS and the same indices -- on a scan-like pair at the refinement loss's scale (216 000
+    predicted against 120 000 target points), uniform clouds, queries far from every target point (the exhaustive leftover
+    pass), exact ties (integer lattices: the lowest index must win across cells and shells), cells far too small (cell indices
+    leave the key range: everything falls back) and far too large (one cell), one target point, NaN queries."""
+    from lidiff_amd import ops
+    rng = np.random.default_rng(3)
+    base = np.tile(fps_scan[:12000], (10, 1))
+    target = base + rng.normal(0, 0.03, base.shape)
+    pred = np.repeat(base[::10][:, None, :] + 0.0, 18, axis=1).reshape(-1, 3) + rng.normal(0, 0.2, (18 * 12000, 3))
+    lattice_a = rng.integers(-6, 7, (5000, 3)).astype(np.float64)
+    lattice_b = rng.integers(-6, 7, (4000, 3)).astype(np.float64)
+    far = np.concatenate([rng.normal(0, 5, (3000, 3)), rng.normal(0, 5, (300, 3)) + 400.0])
+    nan_q = rng.normal(0, 5, (100, 3))
+    nan_q[7, 1] = np.nan
+    cases = [("scan", pred, target, 0.5), ("scan small cells", pred[:20000], target, 0.1), ("uniform", rng.uniform(-30, 30, (50000, 3)),
+             rng.uniform(-30, 30, (40000, 3)), 0.5), ("far queries", far, rng.normal(0, 5, (20000, 3)), 0.5),
+             ("ties", lattice_a, lattice_b, 1.0), ("ties, cell 2.5", lattice_a, lattice_b, 2.5),
+             ("key range", rng.normal(0, 5, (2000, 3)), rng.normal(0, 5, (3000, 3)), 1e-5),
+             ("one cell", rng.normal(0, 5, (2000, 3)), rng.normal(0, 5, (3000, 3)), 1e4),
+             ("one target", rng.normal(0, 5, (500, 3)), rng.normal(0, 5, (1, 3)), 0.5), ("nan", nan_q, rng.normal(0, 5, (900, 3)), 0.5)]
+    for name, a, b, cell in cases:
+        ta, tb = torch.from_numpy(a).to(dtype).to(device), torch.from_numpy(b).to(dtype).to(device)
+        want_d, want_i = ops.nn_dist(ta, tb, grid=False)
+        got_d, got_i = ops.nn_dist(ta, tb, grid=True, cell=cell)
+        assert torch.equal(got_i, want_i), (name, int((got_i != want_i).sum()))
+        assert torch.equal(got_d.view(torch.int32 if dtype == torch.float32 else torch.int64),
+                           want_d.view(torch.int32 if dtype == torch.float32 else torch.int64)), name
+    # the loss itself at >= 100k points: same value bit for bit whichever search runs, gradient included
+    from lidiff_amd.diffusion import chamfer_distance
+    p = torch.from_numpy(pred[None, :108000]).float().to(device).requires_grad_(True)
+    t = torch.from_numpy(target[None]).float().to(device)
+    outs = []
+    for min_pairs in (1, 1 << 62):
+        ops.NN_GRID_MIN_PAIRS, keep = min_pairs, ops.NN_GRID_MIN_PAIRS
+        try:
+            p.grad = None
+            loss = chamfer_distance(p, t)
+            loss.backward()
+            outs.append((loss.detach().clone(), p.grad.clone()))
+        finally:
+            ops.NN_GRID_MIN_PAIRS = keep
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

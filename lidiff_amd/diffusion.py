@@ -230,7 +230,8 @@ def train_loop(module, batches, steps: int, sync_bn: bool = True, transport_dtyp
         sched, interval, frequency = sched["scheduler"], sched.get("interval", "epoch"), sched.get("frequency", 1)
     if steps_per_epoch is None:
         steps_per_epoch = max(1, len(batches) // world)
-    reducer = ldist.GradAllReducer(module.parameters(), transport_dtype=transport_dtype)
+    # gradients live in the reducer's flat buckets (views), each bucket is all-reduced in place as soon as backward has filled it
+    reducer = ldist.GradAllReducer(module.parameters(), transport_dtype=transport_dtype, attach=True, overlap=True)
     module.train()
     losses, pending = [], []
 
@@ -245,7 +246,7 @@ def train_loop(module, batches, steps: int, sync_bn: bool = True, transport_dtyp
 
     for step in range(steps):
         loss = module.training_step(batches[(step * world + rank) % len(batches)], step)
-        opt.zero_grad(set_to_none=True)
+        reducer.zero_grad()
         loss.backward()
         reducer.all_reduce()
         opt.step()

@@ -47,6 +47,18 @@ def _worker(rank, world, port, result_q):
     model(x).pow(2).sum().backward()
     ldist.GradAllReducer(model.parameters(), transport_dtype=torch.bfloat16).all_reduce()
     out["avg_bf16"] = [p.grad.clone() for p in model.parameters()]
+    # attached + overlapped (what train_loop uses): gradients ARE views into the flat buckets, every bucket is all-reduced in
+    # place from a post-accumulate hook as soon as backward has filled it -- same averages, bit for bit, and the views survive
+    red = ldist.GradAllReducer(model.parameters(), bucket_bytes=64, attach=True, overlap=True)
+    for _ in range(2):                                             # twice: the per-step state is reset
+        red.zero_grad()
+        model(x).pow(2).sum().backward()
+        launched_in_backward = red._next
+        red.all_reduce()
+    out["avg_overlap"] = [p.grad.clone() for p in model.parameters()]
+    out["overlap_views"] = all(p.grad.data_ptr() == v.data_ptr() for b in red.buckets for p, v in zip(b.params, b.views))
+    out["overlap_launched_in_backward"] = launched_in_backward
+    out["overlap_buckets"] = len(red.buckets)
     # train_loop: rank r takes batch (step * world + r) mod len -- disjoint data per rank (DistributedSampler), the
     # LR follows Lightning's {'interval': 'epoch', 'frequency': 5} (models.py:340-344), losses are read back lazily
     from lidiff_amd.diffusion import train_loop
@@ -114,6 +126,9 @@ def test_two_rank_gloo():
             assert torch.allclose(torch.tensor(got), torch.tensor(want), atol=1e-6)
             assert torch.allclose(torch.tensor(got16), torch.tensor(want), rtol=2e-2, atol=2e-2)
     assert results[0]["avg"] == results[1]["avg"]
+    for r in (0, 1):
+        assert results[r]["avg_overlap"] == results[r]["avg"] and results[r]["overlap_views"]
+        assert results[r]["overlap_buckets"] > 1 and results[r]["overlap_launched_in_backward"] == results[r]["overlap_buckets"]
 
 
 def test_single_process_is_a_noop():

@@ -830,7 +830,15 @@ def _two_rank_syncbn_one_gpu_worker(rank, world, port, q):
     for k, v in sorted(mod2.state_dict().items()):                # parameters AND BatchNorm running statistics
         h.update(v.detach().cpu().numpy().tobytes())
     n_sync2 = sum(type(m) is ops.SyncBatchNorm1d for m in mod2.modules())
-    q.put((rank, n_sync, eps.cpu().numpy(), grads, stats, losses, h.hexdigest(), n_sync2))
+    # (3) the same loop in config 5's transport: bf16 convolution operands, bf16 gradient buckets on the wire
+    from lidiff_amd.diffusion import DiffusionPoints
+    torch.manual_seed(300 + rank)
+    mod3 = DiffusionPoints(device=dev, precision="bf16")
+    losses3 = train_loop(mod3, batches, steps=2, sync_bn=True, transport_dtype=torch.bfloat16)
+    h3 = hashlib.sha1()
+    for k, v in sorted(mod3.state_dict().items()):
+        h3.update(v.detach().cpu().numpy().tobytes())
+    q.put((rank, n_sync, eps.cpu().numpy(), grads, stats, losses, h.hexdigest(), n_sync2, losses3, h3.hexdigest()))
     tdist.barrier()
     tdist.destroy_process_group()
 
@@ -862,6 +870,8 @@ def test_two_rank_sync_batchnorm_on_one_gpu_over_gloo(device):
     # (2) the ranks of the real loop agree bit for bit, running statistics included
     assert np.isfinite(res[0][4]).all() and len(res[0][4]) == 2
     assert res[0][5] == res[1][5], "ranks hold different weights / running statistics after 2 sync-BN steps"
+    assert np.isfinite(res[0][7]).all() and len(res[0][7]) == 2 and res[0][8] == res[1][8], \
+        "ranks diverged in the bf16 loop (bf16 operands, bf16 gradient transport, synchronised BatchNorm)"
     # (1) against one process on the concatenated batch
     batches = _a18_batches()
     n_total = sum(b["pcd_full"].shape[0] * b["pcd_full"].shape[1] for b in batches[:2])

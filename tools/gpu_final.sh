@@ -1,7 +1,8 @@
 #!/bin/bash
-# The closing GPU session of a round: the whole GPU suite with the achieved parity errors, the driver's bench command, the
-# rocprofv3 kernel statistics / idle gaps / step-boundary window of that command, the PMC passes (traffic on the driver's command,
-# MFMA occupancy per layer class), the per-layer table, the full-trajectory and whole-scan bench forms.
+# The closing GPU session of a round: the whole GPU suite with the achieved parity errors, the driver's bench command, its
+# A/B twin with a host read per pyramid, the rocprofv3 kernel statistics / idle gaps / step-boundary window of that command, the
+# host-lead probe and the GPU-clock marks of a step (no profiler), the PMC passes (traffic on the driver's command, MFMA occupancy
+# per layer class), the per-layer table, the full-trajectory and whole-scan bench forms, the training step by kernel class.
 #   usage: bash tools/gpu_final.sh [tag]     -> gpurun_out/<tag>/ (copy what is to be judged into profiles/)
 T=${1:-final}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -10,19 +11,22 @@ cd $R
 LIDIFF_PARITY_LOG=$O/parity_errors.jsonl timeout 2400 python -m pytest tests -m gpu -q -rs > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
 python tools/parity_report.py $O/parity_errors.jsonl > $O/parity_errors.txt 2>&1
 python bench.py --steps 20 --warmup 5 --layer-table $O/layer_table.txt > $O/bench_default.json 2> $O/bench_default.err; cut -c1-200 $O/bench_default.json
-python bench.py --steps 20 --warmup 5 --no-kernel-events --no-cpu-baseline --no-train --no-alt --no-closed-loop --no-coords-roofline > $O/bench_no_events.json 2>> $O/bench_default.err
+NOEV="--no-kernel-events --no-cpu-baseline --no-train --no-alt --no-closed-loop --no-coords-roofline"
+python bench.py --steps 20 --warmup 5 $NOEV > $O/bench_no_events.json 2>> $O/bench_default.err
+LIDIFF_READ_FREE=0 python bench.py --steps 20 --warmup 5 $NOEV > $O/bench_no_events_host_reads.json 2>> $O/bench_default.err
+LIDIFF_PYRAMID_LANES=0 python bench.py --steps 20 --warmup 5 $NOEV > $O/bench_no_events_one_chain.json 2>> $O/bench_default.err
 python bench.py --steps 50 --warmup 5 --cached-condition --no-cpu-baseline --no-train --no-closed-loop > $O/bench_steps50.json 2>> $O/bench_default.err
 python bench.py --pipeline --scans 2 > $O/bench_pipeline.json 2>> $O/bench_default.err
-cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python $R/bench.py --steps 20 --warmup 5 --no-kernel-events --no-cpu-baseline --no-train --no-alt --no-closed-loop --no-coords-roofline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
-cd $R
-DB=$(find $O/prof -name "*results.db" | head -1)
-python tools/rocpd_stats.py $DB --top 45 > $O/rocprofv3_kernel_stats.md 2>&1
-python tools/rocpd_gaps.py $DB --last-ms 760 --top 15 > $O/idle_gaps.txt 2>&1
-python tools/rocpd_main_queue.py $DB --last-ms 760 > $O/main_queue.txt 2>&1
-python tools/rocpd_window.py $DB --nth 3 --ms 3.0 > $O/step_boundary_window.txt 2>&1
-rm -rf $O/prof
+for f in bench_no_events bench_no_events_host_reads bench_no_events_one_chain bench_steps50 bench_pipeline; do echo "$f: $(cut -c50-130 $O/$f.json)"; done
+python tools/debug/lead_probe.py 2>&1 | grep -v amdgpu.ids > $O/host_lead_probe.txt
+python tools/debug/unet_marks.py 2>&1 | grep -v amdgpu.ids > $O/step_marks_gpu_clock.txt
+python tools/host_profile.py --steps 10 2>&1 | grep -v amdgpu.ids | head -40 > $O/host_profile.txt
+bash tools/gpu_window.sh $T/window > /dev/null 2>&1
+for f in rocprofv3_kernel_stats.md idle_gaps.txt main_queue.txt step_boundary_window.txt bench_under_rocprof.json; do cp $O/window/$f $O/ 2>/dev/null; done
+bash tools/gpu_train_profile.sh $T/train bf16 > /dev/null 2>&1
+bash tools/gpu_train_profile.sh $T/train32 32 > /dev/null 2>&1
+cp $O/train/train_kernel_classes_bf16.txt $O/train/train_kernel_stats_bf16.md $O/train/train_kernel_classes_bf16.json $O/ 2>/dev/null
+cp $O/train32/train_kernel_classes_32.txt $O/train32/train_kernel_classes_32.json $O/ 2>/dev/null
 PMC_STEPS=20 PMC_WARMUP=5 bash tools/pmc_bench.sh > $O/pmc_bench.log 2>&1; cp gpurun_out/pmc_bench/traffic.json $O/pmc_traffic.json
 bash tools/pmc_mfma.sh > $O/pmc_mfma.log 2>&1; cp gpurun_out/pmc_mfma/summary.txt $O/pmc_mfma.txt; cp gpurun_out/pmc_mfma/summary.json $O/pmc_mfma.json
-python tools/closed_loop_sensitivity.py 2>&1 | grep -v amdgpu > $O/closed_loop_sensitivity.txt
-ls $O; head -5 $O/main_queue.txt; cat $O/closed_loop_sensitivity.txt
+ls $O; head -5 $O/main_queue.txt

@@ -310,3 +310,16 @@ def test_closed_loop_c2_chamfer_vs_oracle(device, fps_scan, gpu_rounding):
           f"(step: share <= 0.1 mm, share <= 1 mm, median, max) {along}; post-filter rows {post.shape[0]} vs {post_o.shape[0]}")
     assert cd_diff <= 1e-3, cd_diff
     assert cd_ref <= 1e-3, cd_ref
+    # Per point.  Measured in round 5 against BOTH fixtures: Chamfer 1.33e-5 / 1.34e-5 m; after step 1 EVERY point
+    # within 3.8e-6 m; at the end 99.88 % of the points within 0.1 mm (212 / 207 beyond it), 99.99 % within 1 mm, worst 7.2 mm --
+    # the same numbers with the CPU's rounding and with the device's (the two oracles themselves differ in 27 points): what moves
+    # the remaining points is not the rounding rule but fp32 summation order (|eps| errors ~5e-7, positions ~1e-6 m per step)
+    # carrying a point across a voxel boundary on one side only -- from there the point's, and through the convolutions its
+    # neighbours', inputs differ.  No float64 oracle can be matched point for point by ANY fp32 execution of a closed loop
+    # (tools/closed_loop_sensitivity.py: the device against itself from x_T + 1e-6 m ends at the same Chamfer distance).  The bars
+    # below are 10x tighter than north_star's on the cloud and bound every point; a kernel fault that touches a few hundred
+    # points (0.2 % of them) fails the 0.1 mm share.
+    assert cd_diff <= 1e-4 and cd_ref <= 1e-4, (cd_diff, cd_ref)
+    assert along[1][3] <= 1e-5, along[1]                               # one step: every point
+    assert along[5][0] >= 0.9999 and along[10][0] >= 0.9998, along
+    assert np.mean(err <= 1e-4) >= 0.998 and np.mean(err <= 1e-3) >= 0.9995 and err.max() <= 2e-2, (np.mean(err <= 1e-4), err.max())

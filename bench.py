@@ -677,7 +677,12 @@ def main():
                                "T=50 sde-dpmsolver++ trajectory, CFG w=6 (2 forwards/step), fp32, "
                                "random-init weights, offsets sigma_t*N(0,I) per step",
                    "points": N_POINTS, "trajectory_positions": [trajectory_index(j, args.steps) for j in range(args.steps)],
-                   "scans_per_gpu": 1, "parallelism": f"scan-sharded x{world}, no data-path collective"},
+                   "scans_per_gpu": 1, "parallelism": f"scan-sharded x{world}, no data-path collective",
+                   "host_reads_per_step": 0 if pipe.read_free else 3,
+                   "host_reads_note": ("DiffCompletion.read_free: from every role's second pyramid on no map size reaches the host inside a "
+                                       "step (row counts stay on the device, sizes arrive through pinned memory one step later and are "
+                                       "validated inside the timed region); the first step of a run reads them (3 pyramids)"
+                                       if pipe.read_free else "LIDIFF_READ_FREE=0: one blocking read per coordinate pyramid")},
     }
     if args.cached_condition:
         out["cached_condition"] = {

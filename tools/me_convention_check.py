@@ -72,6 +72,9 @@ def run_oracle(kind):
     return table
 
 
+CO = 16        # output channels of the one-hot convolutions (every channel carries the same value; lidiff_amd's kernels want 16 | C_out)
+
+
 def run_me_api(ME, kind, device):
     """The same through an ME-compatible module tree (the real MinkowskiEngine, or lidiff_amd's shim on a GPU)."""
     table = {}
@@ -81,21 +84,21 @@ def run_me_api(ME, kind, device):
     for k in range(27 if kind == "k3s1" else 8):
         x = ME.SparseTensor(features=feats, coordinates=coords, device=device)
         if kind == "k3s1":
-            conv = ME.MinkowskiConvolution(1, 1, kernel_size=3, stride=1, dimension=3).to(device)
+            conv = ME.MinkowskiConvolution(1, CO, kernel_size=3, stride=1, dimension=3).to(device)
         else:
-            conv = ME.MinkowskiConvolution(1, 1, kernel_size=2, stride=2, dimension=3).to(device)
+            conv = ME.MinkowskiConvolution(1, CO, kernel_size=2, stride=2, dimension=3).to(device)
         with torch.no_grad():
             conv.kernel.zero_()
-            conv.kernel[k, 0, 0] = 1.0
+            conv.kernel[k, 0, :] = 1.0
             y = conv(x)
             if kind == "k2s2T":
                 # feed the coarse map back up through the transposed convolution: one-hot at k there, all-ones below
                 conv.kernel.fill_(0.0)
-                conv.kernel[:, 0, 0] = 1.0
+                conv.kernel[:, 0, :] = 1.0
                 y = conv(x)
-                up = ME.MinkowskiConvolutionTranspose(1, 1, kernel_size=2, stride=2, dimension=3).to(device)
+                up = ME.MinkowskiConvolutionTranspose(1, CO, kernel_size=2, stride=2, dimension=3).to(device)
                 up.kernel.zero_()
-                up.kernel[k, 0, 0] = 1.0
+                up.kernel[k, 0, :] = 1.0
                 cf = (1.0 + torch.arange(y.F.shape[0], dtype=torch.float32, device=device))[:, None]
                 if hasattr(y, "coordinate_map_key"):          # the real ME
                     y_in = ME.SparseTensor(features=cf, coordinate_map_key=y.coordinate_map_key, coordinate_manager=y.coordinate_manager)

@@ -818,6 +818,29 @@ def main():
                         "seeded random-init weights -- the offsets do not contract as with trained weights (they grow to ~1 / alpha_T), "
                         "so the maps are sparser than on the metric's sigma_t trajectory; parity of this loop against the oracle: "
                         "tests/test_gpu_baseline.py::test_closed_loop_c2_chamfer_vs_oracle"}
+        # the same scan with the per-step kernel sequence captured as a HIP graph (DiffCompletion.graph_steps: conditions encoded
+        # once per scan, the step body replayed while its kernel choices hold), and -- for a like-for-like eager number -- with the
+        # conditions cached but every step queued by the host.  Beside the metric, never `value`.
+        variants = {}
+        with torch.no_grad():
+            for name, flags in (("eager_cached_conditions", {"cache_condition": True}), ("graph_steps", {"graph_steps": True})):
+                keep = {k: getattr(pipe, k) for k in flags}
+                for k, v in flags.items():
+                    setattr(pipe, k, v)
+                try:
+                    pipeline_leg(pipe, device, [5000], warm=False)            # (first use: captures / allocator growth, untimed)
+                    per, ph, _ = pipeline_leg(pipe, device, [5000], warm=False)
+                    variants[name] = {"s_per_scan": per[0], "ms_per_denoising_step": 1e3 * ph["denoise_s"] / T_STEPS}
+                    if name == "graph_steps":
+                        variants[name]["steps"] = dict(pipe.graph_stats or {})
+                finally:
+                    for k, v in keep.items():
+                        setattr(pipe, k, v)
+        out["closed_loop"]["variants"] = variants
+        out["closed_loop"]["variants_note"] = (
+            "graph_steps: SURVEY 8(f) row 1 (step-invariant caching + the per-step kernel sequence as a HIP graph) -- bit-identical to "
+            "the eager loop with cached conditions (tests/test_gpu_readfree.py); `steps` = how many of the T steps ran eagerly / were "
+            "captures / replays (a graph holds while the kernel choices, which follow the previous step's map sizes, stand still)")
     if world == 1 and not args.no_train:
         del pipe
         torch.cuda.empty_cache()

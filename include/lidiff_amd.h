@@ -181,6 +181,11 @@ int lidiff_tail_map_fill_bounded(const int32_t* nbr, int32_t k_vol, int64_t m_bo
 int lidiff_host_device_pointer(void* host_ptr, void** dev_ptr);
 int lidiff_publish_words(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* host_mapped, int32_t seq,
                          void* stream);
+/* ... with the sequence number on the device (*d_seq is incremented by the launch) and the record's slot -- ring_mapped +
+ * (seq % slots) * slot_words -- derived from it: no per-record argument, so a captured HIP graph that holds the launch can be
+ * replayed for every step of a trajectory. */
+int lidiff_publish_words_seq(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* ring_mapped, int32_t slots,
+                             int32_t slot_words, int32_t* d_seq, void* stream);
 
 /* Weight layout of the sparse convolution.  MinkowskiConvolution.kernel is [K, c_in, c_out] row-major
  * (minkunet.py:17,36,53,61; [c_in, c_out] for kernel_size 1, :72).  The HIP kernel consumes it in MFMA
@@ -407,6 +412,16 @@ int lidiff_cfg_dpm_step(const float* eps_cond, const float* eps_uncond, float w,
                         const double* m_prev, const double* noise, float sigma_t, double inv_alpha_t, double c_sample, double c_m0,
                         double c_d1, double inv_r0, double c_noise, float inv_resolution, int64_t n_points, int64_t n_per_batch,
                         int32_t scale_batch_column, double* x0_out, float* feats_out, int32_t* coords_out, void* stream);
+/* lidiff_cfg_dpm_step with everything that changes from step to step read from DEVICE memory: row *d_step of coef_table [T][8]
+ * doubles (sigma_t, 1 / alpha_t, c_sample, c_m0, c_d1, 1 / r0, c_noise, second-order flag: the scalars of lidiff_cfg_dpm_step) and
+ * of noise_table [T][3 n_points] (nullable: no noise term); m_prev must point at a buffer (read only when the row's flag is set).
+ * The same arithmetic, operation by operation; no per-step argument, so ONE captured HIP graph serves every step of a trajectory
+ * (DiffCompletion.graph_steps; SURVEY 8(f) row 1: "HIP-graph the per-step kernel sequence"). */
+int lidiff_cfg_dpm_step_table(const float* eps_cond, const float* eps_uncond, float w, const float* x_t, const double* x_init,
+                              const double* m_prev, const double* noise_table, const double* coef_table, const int32_t* d_step,
+                              float inv_resolution, int64_t n_points, int64_t n_per_batch, int32_t scale_batch_column, double* x0_out,
+                              float* feats_out, int32_t* coords_out, void* stream);
+
 /* points_to_tensor alone (pipeline:68-84; models.py:162-178 with scale_batch_column = 0): [B, n, 3] points, fp64 (is_f64 != 0)
  * or fp32 -> fp32 features [B n, 3] and int32 voxel coordinates [B n, 4], one launch. */
 int lidiff_points_to_field(const void* points, int32_t is_f64, float inv_resolution, int64_t n_points, int64_t n_per_batch,

@@ -169,9 +169,33 @@ class SizeFeed:
             if sizes[i] > top:
                 self.bad = f"record {seq}: word {i} = {sizes[i]} exceeds the bound {top} the host sized a buffer by"
 
+    # device-side sequence numbers (enable_device_seq): the publishing launch takes no per-record argument -- it increments a
+    # device counter and derives the ring slot from it -- so it can sit inside a captured HIP graph that is replayed step
+    # after step (DiffCompletion.graph_steps); the host mirrors the numbering (announce() per replay)
+    dev_seq = None
+
+    def enable_device_seq(self):
+        if self.dev_base is None:
+            raise RuntimeError("SizeFeed: device-side sequence numbers need the pinned ring mapped into the device's address space")
+        if self.dev_seq is None:
+            self.dev_seq = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.dev_seq.fill_(self.seq)
+
+    def announce(self, n_words: int):
+        """Host bookkeeping of a record that a REPLAYED graph will publish (the launch itself is inside the graph)."""
+        self.seq += 1
+        prev = self.slot_owner.get(self.seq % self.SLOTS)
+        if prev is not None and prev in self.n_words:
+            self.get(prev)
+        self.slot_owner[self.seq % self.SLOTS] = self.seq
+        self.n_words[self.seq] = int(n_words)
+        return self.seq
+
     def push_host(self, sizes, status: int = 0):
         self.seq += 1
         self.done[self.seq] = (int(status), [int(v) for v in sizes])
+        if self.dev_seq is not None:
+            self.dev_seq.fill_(self.seq)
         self._trim()
         return self.seq
 
@@ -184,7 +208,10 @@ class SizeFeed:
             self.get(prev)                             # the slot's previous record has not been consumed yet: do it now
         self.slot_owner[self.seq % self.SLOTS] = self.seq
         self.n_words[self.seq] = counts.numel()
-        if self.dev_base is not None:
+        if self.dev_seq is not None:
+            call("lidiff_publish_words_seq", ptr(counts), counts.numel(), ptr(status), self.dev_base, self.SLOTS, self.WORDS,
+                 ptr(self.dev_seq), stream_ptr())
+        elif self.dev_base is not None:
             call("lidiff_publish_words", ptr(counts), counts.numel(), ptr(status), self.dev_base + 4 * self.WORDS * (self.seq % self.SLOTS),
                  self.seq, stream_ptr())
         else:
@@ -1411,6 +1438,41 @@ def cfg_dpm_step(e_cond, e_uncond, w: float, x_t, x_init, plan: dict, noise, res
     call("lidiff_cfg_dpm_step", ptr(e_cond), ptr(e_uncond), float(w), ptr(x_t), ptr(x_init), ptr(m_prev), ptr(noise),
          float(np.float32(plan["sigma_t"])), 1.0 / plan["alpha_t"], plan["c_sample"], plan["c_m0"], plan["c_d1"], plan["inv_r0"],
          plan["c_noise"], _inv_resolution(resolution), n, max(1, n_per), int(bool(scale_batch_column)), ptr(x0), ptr(feats),
+         ptr(coords), stream_ptr())
+    return x0, feats, coords
+
+
+def step_coefficient_table(plans, device) -> torch.Tensor:
+    """[T, 8] float64 on the device from DPMSolverMultistepScheduler.plan_table(): the rows lidiff_cfg_dpm_step_table reads
+    (sigma_t as the float32 it is multiplied in, 1 / alpha_t, c_sample, c_m0, c_d1, 1 / r0, c_noise, second-order flag)."""
+    import numpy as np
+    rows = [[float(np.float32(p["sigma_t"])), 1.0 / p["alpha_t"], p["c_sample"], p["c_m0"], p["c_d1"], p["inv_r0"], p["c_noise"],
+             1.0 if p["second"] else 0.0] for p in plans]
+    return torch.tensor(rows, dtype=torch.float64).to(device)
+
+
+def cfg_dpm_step_table(e_cond, e_uncond, w: float, x_t, x_init, m_prev, noise_table, coef_table, d_step, resolution: float,
+                       scale_batch_column: bool = True):
+    """cfg_dpm_step with the step's scalars and noise read from device tables at row d_step[0] (lidiff_cfg_dpm_step_table): no
+    per-step argument -- the launch can be replayed from a captured graph.  m_prev [B, n, 3] float64 (read when the row's
+    second-order flag is set), noise_table [T, B n 3] float64 or None, coef_table step_coefficient_table(), d_step int32 [1]."""
+    require_device(e_cond, e_uncond, x_t, x_init, m_prev, noise_table, coef_table, d_step)
+    b, n_per = x_init.shape[0], x_init.shape[1]
+    n = b * n_per
+    e_cond, e_uncond, x_t, x_init = (v.contiguous() for v in (e_cond, e_uncond, x_t, x_init))
+    if not (e_cond.dtype == e_uncond.dtype == x_t.dtype == torch.float32 and x_init.dtype == m_prev.dtype == torch.float64
+            and e_cond.numel() == e_uncond.numel() == x_t.numel() == x_init.numel() == m_prev.numel() == 3 * n):
+        raise ValueError("cfg_dpm_step_table: float32 eps / points [B, n, 3], float64 x_init / m_prev [B, n, 3] expected")
+    assert coef_table.dtype == torch.float64 and coef_table.dim() == 2 and coef_table.shape[1] == 8 and coef_table.is_contiguous()
+    assert d_step.dtype == torch.int32 and m_prev.is_contiguous()
+    if noise_table is not None:
+        assert noise_table.dtype == torch.float64 and noise_table.is_contiguous() and noise_table.shape[0] == coef_table.shape[0] \
+            and noise_table.numel() == coef_table.shape[0] * 3 * n
+    x0 = torch.empty((b, n_per, 3), dtype=torch.float64, device=x_init.device)
+    feats = torch.empty((n, 3), dtype=torch.float32, device=x_init.device)
+    coords = torch.empty((n, 4), dtype=torch.int32, device=x_init.device)
+    call("lidiff_cfg_dpm_step_table", ptr(e_cond), ptr(e_uncond), float(w), ptr(x_t), ptr(x_init), ptr(m_prev), ptr(noise_table),
+         ptr(coef_table), ptr(d_step), _inv_resolution(resolution), n, max(1, n_per), int(bool(scale_batch_column)), ptr(x0), ptr(feats),
          ptr(coords), stream_ptr())
     return x0, feats, coords
 

@@ -334,6 +334,30 @@ def test_step_plan_is_pure_until_commit():
         broken.step_plan(ts[4])
 
 
+@pytest.mark.parametrize("steps", [50, 10])
+def test_plan_table_is_the_step_plan_sequence(steps):
+    """plan_table() (the coefficient rows a captured step reads by a device counter, DiffCompletion.graph_steps) holds exactly the
+    scalars step_plan() hands out when the trajectory is walked with commits -- first step first order, second order after, and
+    (under 15 steps) the last one first order again -- and leaves the scheduler's multistep state alone."""
+    from lidiff_amd.schedulers import DPMSolverMultistepScheduler
+    mk = lambda: DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_start=3.5e-5, beta_end=0.007, beta_schedule="linear",
+                                             algorithm_type="sde-dpmsolver++", solver_order=2)
+    s, walk = mk(), mk()
+    s.set_timesteps(steps), walk.set_timesteps(steps)
+    s.commit(torch.ones(1))                                          # some state the table must not disturb
+    before = (list(s.model_outputs), s.lower_order_nums)
+    rows = s.plan_table()
+    assert (list(s.model_outputs), s.lower_order_nums) == before
+    assert len(rows) == steps
+    for i, t in enumerate(walk.host_timesteps):
+        plan = walk.step_plan(t)
+        assert rows[i]["second"] == (plan["m_prev"] is not None)
+        assert {k: v for k, v in plan.items() if k != "m_prev"} == {k: v for k, v in rows[i].items() if k != "second"}
+        walk.commit(torch.full((1,), float(i)))
+    assert not rows[0]["second"] and rows[1]["second"]
+    assert rows[-1]["second"] == (steps >= 15)
+
+
 @pytest.mark.parametrize("source", ["spconv_bf16.hip"])
 def test_asm_kernel_isa_never_reads_an_in_flight_register(tmp_path, source):
     """spconv_bf16.hip requests its LDS fragments with inline asm and waits for them with counted s_waitcnt, so the

@@ -36,6 +36,7 @@ extern "C" {
                                        steps, lidiff_tail_map_fill_bounded): nothing was overrun, the results of the step are void */
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
 #define LIDIFF_CONV_TILE_128 16     /* 64-column layers on 128-row tiles as well (default: 256-row tiles for large maps; A/B measurements) */
+#define LIDIFF_CONV_PERSIST 32      /* tile kernels as resident workgroups that pull tile slots from per-XCD counters (A/B measurements) */
 #define LIDIFF_CONV_TILE_ONLY 8     /* identity maps (nbr == NULL) through the tile kernel as well, not the row kernel (A/B measurements, tests) */
 
 int lidiff_abi_version(void);

@@ -31,6 +31,8 @@
 //
 // Replaces ME's ConvolutionForwardGPU (gather -> GEMM -> atomic scatter per offset) behind
 // MinkowskiConvolution / MinkowskiConvolutionTranspose; call sites in include/lidiff_amd.h.
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -68,8 +70,22 @@ struct ConvCfg {
     }
 };
 
+// LIDIFF_CONV_PERSIST: the next tile slot of a resident workgroup.  Slots keep their XCD (slot & 7 -- the column tiles of a row
+// tile and their gathers stay in one L2): a workgroup serves its own XCD's queue first and the others' when that is empty.
+__device__ __forceinline__ int next_tile_slot(const ConvParams& p) {
+    const int groups = p.bids >> 3, home = blockIdx.x & 7;
+    for (int j = 0; j < 8; ++j) {
+        const int q = (home + j) & 7;
+        if (j > 0 && __atomic_load_n(&p.queue[q], __ATOMIC_RELAXED) >= groups) continue;
+        const int g = atomicAdd(&p.queue[q], 1);
+        if (g < groups) return 8 * g + q;
+    }
+    return -1;
+}
+
+// One tile slot `bid` of the launch: everything from the pair lists to the epilogue.
 template <int BM, int WN, int WM, int KS, bool VEC>
-__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p_launch) {
+__device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int bid) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
     ConvParams p = p_launch;                     // per-replica view (pointers moved below)
     constexpr int BN = Cfg::BN, NT = Cfg::NT, NW = Cfg::NW, RBW = Cfg::RBW, AF = Cfg::A_FLOATS;
@@ -111,7 +127,6 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 
     // XCD-aware tile mapping: the column tiles of one row tile share an XCD (their gathers hit the
     // same L2), consecutive row tiles round-robin over the 8 XCDs.
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, g = bid >> 3;
     const int tn = g % p.tiles_n;
     const int tiles_all = p.tiles_m * p.replicas;
@@ -696,11 +711,49 @@ __global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvPara
 #ifdef LIDIFF_CONV_PROBE
     if (p.timeline != nullptr && lane == 0 && (wave == 0 || wave == NW / 2)) {   // the two waves of SIMD 0
         STAMP(t_end);
-        long long* d = p.timeline + ((int64_t)blockIdx.x * 2 + (wave != 0)) * 10;
+        long long* d = p.timeline + ((int64_t)bid * 2 + (wave != 0)) * 10;
         d[0] = t_loop - t_start; d[1] = t_epi - t_loop; d[2] = t_end - t_epi; d[3] = t_barrier; d[4] = t_flush;
         d[5] = packed ? (nwork + SEG - 1) / SEG : nwork; d[6] = nslab; d[7] = __builtin_amdgcn_s_memrealtime() - rt_start; d[8] = t_issue; d[9] = t_mma;
     }
 #endif
+}
+
+template <int BM, int WN, int WM, int KS, bool VEC>
+__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p_launch) {
+    conv_tile<BM, WN, WM, KS, VEC>(p_launch, blockIdx.x);
+}
+
+// LIDIFF_CONV_PERSIST: as many workgroups as the chip holds at once, each pulling tile slots until none is left.  Every tile
+// re-reads the parameter block from the kernel-argument segment (scalar loads through a pointer the compiler cannot see through):
+// kept alive across the tile beside the tile's own moved copy it cost 120 more spilled SGPRs and 56 VGPRs; as a CALL with the block
+// behind a reference its fields arrived in vector registers and every buffer descriptor became a waterfall loop (10-30 % slower).
+template <int BM, int WN, int WM, int KS, bool VEC>
+__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_persist_kernel(const ConvParams p_launch) {
+    typedef __attribute__((address_space(4))) const uint32_t* KernArg;
+    constexpr int NWORD = sizeof(ConvParams) / 4;
+    static_assert(sizeof(ConvParams) % 4 == 0, "ConvParams");
+    __shared__ int s_slot;
+    for (;;) {
+        uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();     // the block is the first (only) argument
+        asm volatile("" : "+s"(ka));
+        union { ConvParams p; uint32_t w[NWORD]; } blk;
+#pragma unroll
+        for (int i = 0; i < NWORD; ++i) blk.w[i] = ((KernArg)ka)[i];
+        const ConvParams& pl = blk.p;
+        if (threadIdx.x == 0) s_slot = next_tile_slot(pl);
+        __syncthreads();
+        const int bid = s_slot;
+        if (bid < 0) break;
+        conv_tile<BM, WN, WM, KS, VEC>(pl, bid);
+        __syncthreads();                         // the tile's LDS and s_slot are free again
+    }
+    if (threadIdx.x == 0) {                      // the last workgroup to leave zeroes the counters for the next launch
+        __threadfence();
+        if (atomicAdd(&p_launch.queue[8], 1) == (int)gridDim.x - 1) {
+            for (int q = 0; q < 9; ++q) __atomic_store_n(&p_launch.queue[q], 0, __ATOMIC_RELAXED);
+            __threadfence();
+        }
+    }
 }
 
 // W [K, c_in, c_out] row-major  ->  [K][slab32][c_out/16][j 0..1][lane 0..63][e 0..3]  with
@@ -721,15 +774,40 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int k_vol, int 
     wp[idx] = kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f;
 }
 
+// Tile counters of the LIDIFF_CONV_PERSIST launches: a ring of zeroed 16-word sets per device; a launch takes the next set and its
+// last workgroup zeroes it again (launches on different streams run side by side: every one needs counters of its own; a set comes
+// round again after 4096 launches).
+static int32_t* tile_queue() {
+    constexpr int kSets = 4096, kDevs = 16;
+    static int32_t* ring[kDevs] = {};
+    static std::mutex mu;
+    static std::atomic<unsigned> next{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) return nullptr;
+    if (ring[dev] == nullptr) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (ring[dev] == nullptr) {
+            int32_t* q = nullptr;
+            if (hipMalloc(&q, (size_t)kSets * 16 * sizeof(int32_t)) != hipSuccess) return nullptr;
+            if (hipMemset(q, 0, (size_t)kSets * 16 * sizeof(int32_t)) != hipSuccess) return nullptr;
+            ring[dev] = q;
+        }
+    }
+    return ring[dev] + (size_t)(next.fetch_add(1) % kSets) * 16;
+}
+
 template <int BM, int WN, int WM, int KS, bool VEC>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
     const size_t lds = Cfg::lds_bytes(p.k_vol);
     LIDIFF_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded");
     auto kern = spconv_fwd_kernel<BM, WN, WM, KS, VEC>;
+    auto kern_p = spconv_fwd_persist_kernel<BM, WN, WM, KS, VEC>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_p),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
@@ -737,6 +815,27 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     q.tiles_m = (int)ceil_div(p.m_out, BM);
     q.tiles_n = p.c_out / Cfg::BN;
     const unsigned grid = (unsigned)(ceil_div((int64_t)q.tiles_m * q.replicas, 8) * 8 * q.tiles_n);
+    if (p.flags & LIDIFF_CONV_PERSIST) {
+        // resident workgroups -- as many as the chip holds at once -- pull tile slots from per-XCD counters
+        static thread_local size_t occ_lds = ~(size_t)0;
+        static thread_local int occ = 0, cus = 0;
+        if (occ_lds != lds) {
+            int dev = 0;
+            LIDIFF_CHECK_HIP(hipGetDevice(&dev));
+            LIDIFF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            LIDIFF_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern_p), Cfg::NT, lds));
+            occ_lds = lds;
+        }
+        const unsigned resident = (unsigned)(cus * (occ > 0 ? occ : 1)) & ~7u;
+        if (resident >= 8 && grid > resident) {
+            q.queue = tile_queue();
+            LIDIFF_CHECK_ARG(q.queue != nullptr, "no tile queue");
+            q.bids = (int)grid;
+            hipLaunchKernelGGL(kern_p, dim3(resident), dim3(Cfg::NT), lds, st, q);
+            LIDIFF_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), lds, st, q);
     LIDIFF_CHECK_LAUNCH();
     return 0;

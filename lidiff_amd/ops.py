@@ -748,6 +748,8 @@ PROFILER: ConvProfiler | None = None
 DETERMINISTIC_DW = True
 # extra lidiff_spconv_fwd flag bits (include/lidiff_amd.h LIDIFF_CONV_*), e.g. 8 = LIDIFF_CONV_TILE_ONLY
 CONV_FLAGS = int(os.environ.get("LIDIFF_CONV_FLAGS", "0"))
+# resident workgroups (LIDIFF_CONV_PERSIST) for the dense layers of >= this many input channels (0: never)
+PERSIST_MIN_CIN = int(os.environ.get("LIDIFF_PERSIST_MIN_CIN", "0"))
 
 
 def conv_variant(c_out: int, kernel_id: int = 0) -> str:
@@ -816,7 +818,8 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     row_order: int32 permutation of the output rows (tile_order()); `nbr` must then hold its columns in that
     order (nbr[:, row_order]).  Results do not depend on it.
     kernel: "tile_only" keeps identity maps off the row kernel (spconv_rows.hip); "tile128" keeps 64-column layers on 128-row
-    tiles (large maps take 256-row tiles by default).
+    tiles (large maps take 256-row tiles by default); "persist" runs the tile kernels as resident workgroups that pull their tiles
+    from per-XCD counters (LIDIFF_CONV_PERSIST; bit-identical results).
     d_rows: int32 [1] on the device -- the number of VALID output rows when m_out is only their bound (a step without host reads):
     m_out still shapes the result, the table's pitch and the replica pitch; tiles behind the count leave at once.  rows_hint: the
     row count the host BELIEVES (an earlier step's): it alone picks the tile size where the bound would pick another one.
@@ -862,7 +865,9 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert t_rows.shape == (replicas * n_tail, c_out) and t_rows.is_contiguous() and t_rows.dtype == torch.float32
         assert t_ptr.dtype == torch.int32 and t_ptr.shape == (m_out + 1,) and t_idx.dtype == torch.int32
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
-    flags = int(bool(sparse_map)) | {"tile": 0, "tile_only": 8, "tile128": 16}[kernel or "tile"] | CONV_FLAGS
+    flags = int(bool(sparse_map)) | {"tile": 0, "tile_only": 8, "tile128": 16, "persist": 32}[kernel or "tile"] | CONV_FLAGS
+    if PERSIST_MIN_CIN and c_in >= PERSIST_MIN_CIN and c_out % 128 == 0 and not sparse_map and k > 1:
+        flags |= 32
     if rows_hint is not None and rows_hint * replicas < 256 * 512:
         flags |= 16                 # the exact-size path would keep 128-row tiles for this map: the same choice under a bound
     prof = PROFILER

@@ -702,6 +702,45 @@ def test_spconv_256_row_tiles_vs_128_row_tiles_and_oracle(device, cin, split, co
         assert torch.allclose(got[:m][rows].cpu().double(), want, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("cin,split,cout,hint", [(128, 0, 128, False), (256, 0, 256, False), (64, 0, 64, False), (32, 0, 32, True),
+                                                 (96, 64, 96, True), (128, 0, 256, False)])
+def test_spconv_resident_workgroups_equal_the_plain_launch(device, cin, split, cout, hint):
+    """LIDIFF_CONV_PERSIST: the tile kernels launched as resident workgroups (as many as the chip holds) that pull tile slots from
+    per-XCD counters -- the same tiles, each computed exactly as in the plain launch: bit-identical, on a map with many more tiles
+    than the chip holds workgroups, with the CFG pair stacked, a ragged last tile, a device-side row count, and launch after
+    launch on the same counters (the last workgroup out zeroes them)."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(11 + cin)
+    cloud = random_cloud(150000, 36, 71)
+    uniq, _, _ = me.voxelize(cloud)
+    nbr = dev_i32(me.kernel_map(uniq, uniq, 3, 1), device)
+    m = uniq.shape[0]
+    reps = 2
+    x = torch.randn(reps * m, cin, generator=g).to(device)
+    w = (torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)).to(device)
+    a = x[:, :split].contiguous() if split else x
+    kw = dict(in_b=x[:, split:].contiguous() if split else None, scale=(torch.rand(cout, generator=g) + 0.5).to(device),
+              shift=torch.randn(cout, generator=g).to(device), residual=torch.randn(reps * m, cout, generator=g).to(device),
+              relu=True, replicas=reps, sparse_map=hint)
+    ref = ops.spconv_fwd(a, w, nbr, m, **kw)
+    for _ in range(3):
+        assert torch.equal(ops.spconv_fwd(a, w, nbr, m, kernel="persist", **kw), ref)
+    # a device-side row count below the bound: tiles behind it leave at once, in both forms
+    rows = torch.tensor([m - 1000], dtype=torch.int32, device=device)
+    ref_d = ops.spconv_fwd(a, w, nbr, m, d_rows=rows, **kw)
+    got_d = ops.spconv_fwd(a, w, nbr, m, d_rows=rows, kernel="persist", **kw)
+    for r in range(reps):
+        assert torch.equal(got_d[r * m:r * m + m - 1000], ref_d[r * m:r * m + m - 1000])
+    # two streams side by side: every launch has counters of its own
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s1 = ops.spconv_fwd(a, w, nbr, m, kernel="persist", **kw)
+    s2 = ops.spconv_fwd(a, w, nbr, m, kernel="persist", **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(s1, ref) and torch.equal(s2, ref)
+
+
 @pytest.mark.parametrize("m,c", [(2, 32), (37, 96), (5000, 256), (120001, 64), (70000, 128), (9, 4)])
 def test_batch_norm_train_kernels_vs_torch_float64(device, m, c):
     """lidiff_bn_stats / lidiff_bn_apply / lidiff_bn_bwd (ops._BatchNormTrain: the training-mode MinkowskiBatchNorm) against

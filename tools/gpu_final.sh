@@ -18,6 +18,10 @@ LIDIFF_PYRAMID_LANES=0 python bench.py --steps 20 --warmup 5 $NOEV > $O/bench_no
 python bench.py --steps 50 --warmup 5 --cached-condition --no-cpu-baseline --no-train --no-closed-loop > $O/bench_steps50.json 2>> $O/bench_default.err
 python bench.py --pipeline --scans 2 > $O/bench_pipeline.json 2>> $O/bench_default.err
 for f in bench_no_events bench_no_events_host_reads bench_no_events_one_chain bench_steps50 bench_pipeline; do echo "$f: $(cut -c50-130 $O/$f.json)"; done
+# resident workgroups pulling tiles from per-XCD counters (LIDIFF_CONV_PERSIST = flag 32) against the plain launch, per layer, and in the step
+CASES=""; for c in "3,256,256" "4,256,256" "3,384,256" "3,128,128" "2,128,128" "2,64,128" "2,64,64" "1,32,64"; do CASES="$CASES$c,k3,-1,0;$c,k3,-1,32;"; done
+python tools/conv_probe.py --sigma 1.0 --replicas 2 --iters 30 --cases "${CASES%;}" 2>&1 | grep -v amdgpu.ids > $O/persist_probe.txt
+for v in 0 256 0 256; do echo "step, LIDIFF_PERSIST_MIN_CIN=$v: $(LIDIFF_PERSIST_MIN_CIN=$v python bench.py --steps 20 --warmup 5 $NOEV 2>/dev/null | cut -c50-130)" >> $O/persist_probe.txt; done
 python tools/debug/lead_probe.py 2>&1 | grep -v amdgpu.ids > $O/host_lead_probe.txt
 python tools/debug/unet_marks.py 2>&1 | grep -v amdgpu.ids > $O/step_marks_gpu_clock.txt
 python tools/host_profile.py --steps 10 2>&1 | grep -v amdgpu.ids | head -40 > $O/host_profile.txt

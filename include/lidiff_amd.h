@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 25
+#define LIDIFF_ABI_VERSION 26
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -301,6 +301,17 @@ int lidiff_spconv_bwd_w_bf16(const float* in_a, int32_t c_in_a, const float* in_
                              const int32_t* pairs_in, const int32_t* pairs_out, const int32_t* offset_ptr, int64_t n_pairs,
                              int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* dw, float* workspace,
                              void* stream);
+
+/* The network's last lines as one launch (head.hip): out[r n + i, :] = W2 leaky(W1 feats[r m_rows + inverse[i], :] + b1) + b2 --
+ * SparseTensor.slice(field).F followed by `self.last` = Linear(C, hidden), LeakyReLU(slope), Linear(hidden, c_out)
+ * (minkunet.py:390,497).  feats: `replicas` stacked voxel matrices of m_rows rows each (the CFG pair shares the map, hence
+ * `inverse` [n_points]); w1_t: the first Linear's weight TRANSPOSED, [C][hidden]; w2 [c_out][hidden] as torch stores it.
+ * Sums over the channels in ascending order: the same bits for any m_rows.  lidiff_slice_head_supported: the shapes it takes
+ * (C % 4 == 0, hidden 20, c_out 3 -- LiDiff's head); other heads stay on the caller's GEMMs. */
+int32_t lidiff_slice_head_supported(int32_t c, int32_t hidden, int32_t c_out);
+int lidiff_slice_head(const float* feats, const int64_t* inverse, int64_t n_points, int64_t m_rows, int32_t replicas, int32_t c,
+                      const float* w1_t, const float* b1, int32_t hidden, const float* w2, const float* b2, int32_t c_out,
+                      float slope, float* out, void* stream);
 
 /* Row gather / scatter-add -- SparseTensor.slice(field).F minkunet.py:497,619 and the
  * x_part.F[idx] of match_part_to_full minkunet.py:418; scatter-add is their backward. */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "lidiff_bn_bwd_apply": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "lidiff_slice_head_supported": (_i32, [_i32, _i32, _i32]),
+    "lidiff_slice_head": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _p, _i32, _p, _p, _i32, C.c_float, _p, _p]),
     "lidiff_gather_bias_leaky": (_i32, [_p, _p, _p, _i64, _i32, C.c_float, _p, _p]),
     "lidiff_segment_sum_workspace_bytes": (_i64, [_i64, _i32]),
     "lidiff_segment_sum_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
@@ -89,7 +91,7 @@ SIGNATURES = {
     "lidiff_nn_dist_grid": (_i32, [_p, _i64, _p, _i64, _i32, C.c_double, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 _lib = None
 
 

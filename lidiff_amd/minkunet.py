@@ -602,12 +602,17 @@ class MinkUNetDiff(_Base):
             y = _run_up(getattr(self, name), self._condition(name, y, part_feats, temp_emb), feats[3 - j])
         if _fusable(self):
             inv = x.inverse_mapping
-            if multi:
-                m0 = y.F.shape[0] // y.replicas
-                inv = torch.cat([inv + r * m0 for r in range(y.replicas)])
-            # (the head behind the slice, as the reference orders them: its GEMMs then see [points, 96] whatever the voxel count --
-            #  or its bound -- is, so the library picks the same kernels, i.e. the same summation order, in every mode)
-            out = self.last(ops.gather_rows(y.F, inv))
+            if ops.slice_head_applies(self.last):
+                # slice + head as one launch: a point reads its voxel's row and leaves three floats (head.hip) -- no [points, 96]
+                # matrix, no N = 20 / N = 3 GEMMs; the sums do not depend on the voxel count or its bound
+                out = ops.slice_head(y.F, inv, self.last, replicas=y.replicas if multi else 1)
+            else:
+                if multi:
+                    m0 = y.F.shape[0] // y.replicas
+                    inv = torch.cat([inv + r * m0 for r in range(y.replicas)])
+                # (the head behind the slice, as the reference orders them: its GEMMs then see [points, 96] whatever the voxel
+                #  count -- or its bound -- is, so the library picks the same kernels, i.e. the same summation order, in every mode)
+                out = self.last(ops.gather_rows(y.F, inv))
             return tuple(out.chunk(y.replicas, dim=0)) if multi else out
         return _run_mlp(self.last, y.slice(x).F)
 

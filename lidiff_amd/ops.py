@@ -1324,6 +1324,43 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+_HEAD_WEIGHTS: dict = {}
+
+
+def slice_head_applies(head) -> bool:
+    """`head` is Sequential(Linear(C, 20), LeakyReLU, Linear(20, 3)) on the device with C % 4 == 0 -- LiDiff's `self.last`
+    (minkunet.py:390) -- i.e. what lidiff_slice_head evaluates."""
+    mods = list(head)
+    if len(mods) != 3 or not (isinstance(mods[0], torch.nn.Linear) and isinstance(mods[1], torch.nn.LeakyReLU)
+                              and isinstance(mods[2], torch.nn.Linear)):
+        return False
+    l1, l2 = mods[0], mods[2]
+    if l1.bias is None or l2.bias is None or l1.weight.dtype != torch.float32 or not l1.weight.is_cuda:
+        return False
+    return bool(_lib.load().lidiff_slice_head_supported(l1.in_features, l1.out_features, l2.out_features))
+
+
+def slice_head(feats: torch.Tensor, inverse: torch.Tensor, head, replicas: int = 1) -> torch.Tensor:
+    """head(feats[inverse]) -- SparseTensor.slice(field).F through `self.last` (minkunet.py:390,497) -- in one launch, for the
+    `replicas` stacked voxel matrices of a CFG pair ([R * M, C] -> [R * len(inverse), 3]).  Inference only (no autograd)."""
+    require_device(feats, inverse)
+    l1, act, l2 = list(head)
+    key = id(l1)
+    ver = (l1.weight._version, l1.weight.data_ptr())
+    hit = _HEAD_WEIGHTS.get(key)
+    if hit is None or hit[0] != ver:
+        hit = _HEAD_WEIGHTS[key] = (ver, l1.weight.detach().t().contiguous())            # [C, hidden]
+    w1t = hit[1]
+    feats, inverse = feats.contiguous(), inverse.contiguous()
+    assert inverse.dtype == torch.int64 and feats.dtype == torch.float32 and feats.shape[0] % replicas == 0
+    n, c = inverse.shape[0], feats.shape[1]
+    out = torch.empty((replicas * n, l2.out_features), dtype=torch.float32, device=feats.device)
+    call("lidiff_slice_head", ptr(feats), ptr(inverse), n, feats.shape[0] // replicas, int(replicas), c, ptr(w1t),
+         ptr(l1.bias.detach()), l1.out_features, ptr(l2.weight.detach().contiguous()), ptr(l2.bias.detach()), l2.out_features,
+         float(act.negative_slope), ptr(out), stream_ptr())
+    return out
+
+
 def gather_bias_leaky(src: torch.Tensor, idx: torch.Tensor, bias: torch.Tensor, slope: float,
                       out: torch.Tensor | None = None) -> torch.Tensor:
     """leaky_relu(src[idx] + bias, slope) in one pass (conditioning MLP hidden layer, minkunet.py:424-431).

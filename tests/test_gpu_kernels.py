@@ -1209,3 +1209,32 @@ def test_spconv_bf16_training_backward_vs_oracle_autograd(device, kind, ks, stri
     (yo * r.double()).sum().backward()
     assert torch.allclose(x.F.grad.cpu().double(), xo.grad, rtol=1e-4, atol=1e-4), "dX"
     assert torch.allclose(mod.kernel.grad.cpu().double(), wo.grad, rtol=1e-4, atol=1e-3), "dW"
+
+
+@pytest.mark.parametrize("c,reps,n,m", [(96, 2, 50000, 41000), (96, 1, 777, 300), (32, 2, 1, 1), (128, 3, 9000, 9000)])
+def test_slice_and_head_in_one_launch_vs_torch_float64(device, c, reps, n, m):
+    """lidiff_slice_head: head(feats[inverse]) for `self.last` = Linear(C, 20), LeakyReLU(0.1), Linear(20, 3) (minkunet.py:390,497),
+    the replicas of a CFG pair stacked -- against the float64 evaluation of the same lines (bar 2e-6 absolute on O(1) outputs:
+    fp32 sums of C and 20 terms), equal to torch's own fp32 gather + GEMMs within the same bar, and bit-identical when the voxel
+    matrix is handed over with rows behind the ones the inverse map uses (a bound instead of the exact size)."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(3 * c + n)
+    head = torch.nn.Sequential(torch.nn.Linear(c, 20), torch.nn.LeakyReLU(0.1, inplace=True), torch.nn.Linear(20, 3)).to(device)
+    assert ops.slice_head_applies(head)
+    feats = torch.randn(reps * m, c, generator=g).to(device)
+    inv = torch.randint(0, m, (n,), generator=g).to(device)
+    got = ops.slice_head(feats, inv, head, replicas=reps)
+    assert got.shape == (reps * n, 3)
+    rows = torch.cat([feats[r * m:(r + 1) * m][inv] for r in range(reps)])
+    with torch.no_grad():
+        want64 = head.double()(rows.double())
+        head.float()
+        want32 = head(rows.clone())
+    assert torch.allclose(got.double(), want64, rtol=0, atol=2e-6), (got.double() - want64).abs().max().item()
+    assert torch.allclose(got, want32, rtol=0, atol=2e-6)
+    # the same rows inside a larger (bound-sized) voxel matrix per replica
+    pad = torch.randn(reps, m + 1000, c, generator=g).to(device)
+    for r in range(reps):
+        pad[r, :m] = feats[r * m:(r + 1) * m]
+    assert torch.equal(ops.slice_head(pad.reshape(-1, c), inv, head, replicas=reps), got)
+    assert not ops.slice_head_applies(torch.nn.Sequential(torch.nn.Linear(c, 24), torch.nn.LeakyReLU(0.1), torch.nn.Linear(24, 3)).to(device))

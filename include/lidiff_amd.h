@@ -271,14 +271,19 @@ int lidiff_spconv_fwd_pairs(const float* in_a, int32_t c_in_a, const float* in_b
  *   planes = 2, 3: fp32-accurate results from bf16 pieces (opt-in inference mode; error of a K = 6912 dot product relative to
  *               sum |x w|: 2.5e-7 / 1.3e-7 against 1.1e-7 of the native fp32 MFMA).
  * Input widths and c_out multiples of 32; same map / epilogue / replica arguments as lidiff_spconv_fwd (no row order, no
- * tail). */
+ * tail).
+ * in_bf16 (planes = 1 only): in_a / in_b point at bf16 rows -- the shadow copy of the fp32 feature matrix that its producer or
+ * lidiff_cast_bf16 left (bf16 activations in HBM, the bf16 training configuration): half the gather traffic and requests, no
+ * conversion in the kernel; the same operands, products and order of sums, i.e. bit-identical to in_bf16 = 0 on the fp32 rows.
+ * lidiff_cast_bf16: n fp32 values -> n bf16 values, round to nearest even. */
+int lidiff_cast_bf16(const float* src, int64_t n, void* dst, void* stream);
 int64_t lidiff_spconv_packed_weight_bf16_elems(int32_t k_vol, int32_t c_in, int32_t c_out, int32_t planes);
 int lidiff_spconv_pack_weights_bf16(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out, int32_t planes,
                                     void* w_packed, void* stream);
 int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b, const void* w_packed,
                            int32_t planes, const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out,
                            float* out, const float* ep_scale, const float* ep_shift, const float* residual, int32_t relu,
-                           int32_t replicas, void* stream);
+                           int32_t replicas, int32_t in_bf16, void* stream);
 
 /* Weight gradient of lidiff_spconv_fwd (training path, models.py:180-217; ME: ConvolutionBackwardGPU):
  * dw[k] += gather(in)[pairs_in of offset k]^T @ grad_out[pairs_out of offset k], in = [in_a | in_b], over the
@@ -296,11 +301,12 @@ int lidiff_spconv_bwd_w(const float* in_a, int32_t c_in_a, const float* in_b, in
                         int64_t m_in, int64_t m_out, int32_t c_out, float* dw, float* workspace, void* stream);
 /* lidiff_spconv_bwd_w with bf16 operands (bf16 training, planes = 1 of lidiff_spconv_fwd_bf16): the gathered rows of `in`
  * and `grad_out` are rounded to bf16 (nearest even) on their way into v_mfma_f32_16x16x32_bf16, sums in fp32.  Same
- * arguments, tiles, pair slices and workspace (lidiff_spconv_bwd_w_workspace_floats) as lidiff_spconv_bwd_w. */
+ * arguments, tiles, pair slices and workspace (lidiff_spconv_bwd_w_workspace_floats) as lidiff_spconv_bwd_w.
+ * in_bf16: in_a, in_b AND grad_out point at bf16 rows (see lidiff_spconv_fwd_bf16): bit-identical sums, 8-byte loads. */
 int lidiff_spconv_bwd_w_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b, const float* grad_out,
                              const int32_t* pairs_in, const int32_t* pairs_out, const int32_t* offset_ptr, int64_t n_pairs,
                              int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* dw, float* workspace,
-                             void* stream);
+                             int32_t in_bf16, void* stream);
 
 /* The network's last lines as one launch (head.hip): out[r n + i, :] = W2 leaky(W1 feats[r m_rows + inverse[i], :] + b1) + b2 --
  * SparseTensor.slice(field).F followed by `self.last` = Linear(C, hidden), LeakyReLU(slope), Linear(hidden, c_out)

@@ -493,14 +493,19 @@ class _SparseConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, kernel, nbr, nbr_swapped, m_out, flip, sparse_map=False):
-        ctx.save_for_backward(x, kernel, nbr, nbr_swapped)
         ctx.flip = flip
         w3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
         ctx.bf16 = ops.TRAIN_OPERANDS == "bf16" and ops.bf16_conv_applies(w3.shape[1], 0, w3.shape[2], sparse_map)
         # the weight-gradient kernel does not care about the map's density: bf16 operands on every eligible layer
         ctx.bf16_dw = ops.TRAIN_OPERANDS == "bf16" and w3.shape[1] % 32 == 0 and w3.shape[2] % 32 == 0
+        # bf16 activations in HBM (ops.BF16_ROWS): the kernels gather the input's bf16 shadow -- one cast per tensor, shared by
+        # this forward, the weight gradient (which keeps ONLY the shadow: half the saved bytes) and the other layers on x
+        ctx.rows16 = ops.BF16_ROWS and (ctx.bf16 or ctx.bf16_dw) and x.is_contiguous() and x.dtype == torch.float32
+        x16 = ops.cast_bf16(x) if ctx.rows16 else None
+        ctx.m_in = x.shape[0]
+        ctx.save_for_backward(x16 if ctx.rows16 and ctx.bf16_dw else x, kernel, nbr, nbr_swapped)
         if ctx.bf16:
-            return ops.spconv_fwd_bf16(x, kernel, nbr, m_out)
+            return ops.spconv_fwd_bf16(x16 if ctx.rows16 else x, kernel, nbr, m_out)
         return ops.spconv_fwd(x, kernel, nbr, m_out)
 
     @staticmethod
@@ -509,13 +514,15 @@ class _SparseConv(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = None
         w3 = kernel if kernel.dim() == 3 else kernel.unsqueeze(0)
+        need_w16 = ctx.needs_input_grad[1] and ctx.bf16_dw and x.dtype == torch.bfloat16
+        g16 = ops.cast_bf16(g) if ctx.rows16 and ((ctx.needs_input_grad[0] and ctx.bf16) or need_w16) else None
         if ctx.needs_input_grad[0] and ctx.bf16:
-            gx = ops.spconv_fwd_bf16(g, kernel, nbr_swapped, x.shape[0], transposed=True, flip=ctx.flip)
+            gx = ops.spconv_fwd_bf16(g if g16 is None else g16, kernel, nbr_swapped, ctx.m_in, transposed=True, flip=ctx.flip)
         elif ctx.needs_input_grad[0]:
             wt = (w3.flip(0) if ctx.flip else w3).transpose(1, 2).contiguous()
-            gx = ops.spconv_fwd(g, wt, nbr_swapped, x.shape[0])
+            gx = ops.spconv_fwd(g, wt, nbr_swapped, ctx.m_in)
         if ctx.needs_input_grad[1]:
-            gw = ops.spconv_bwd_w(x, g, nbr, w3.shape[0], bf16=ctx.bf16_dw).reshape(kernel.shape)
+            gw = ops.spconv_bwd_w(x, g16 if need_w16 else g, nbr, w3.shape[0], bf16=ctx.bf16_dw).reshape(kernel.shape)
         return gx, gw, None, None, None, None, None
 
 

@@ -48,10 +48,11 @@ SIGNATURES = {
                                        _i32, _p]),
     "lidiff_spconv_packed_weight_bf16_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "lidiff_spconv_pack_weights_bf16": (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p]),
-    "lidiff_spconv_fwd_bf16": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p]),
+    "lidiff_spconv_fwd_bf16": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "lidiff_cast_bf16": (_i32, [_p, _i64, _p, _p]),
     "lidiff_spconv_bwd_w_workspace_floats": (_i64, [_i32, _i32, _i32, _i64]),
     "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p]),
-    "lidiff_spconv_bwd_w_bf16": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p]),
+    "lidiff_spconv_bwd_w_bf16": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _i32, _p]),
     "lidiff_bn_workspace_bytes": (_i64, [_i32]),
     "lidiff_bn_stats": (_i32, [_p, _i64, _i32, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p, _p]),
     "lidiff_bn_apply": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),

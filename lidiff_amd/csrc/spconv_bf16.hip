@@ -54,16 +54,33 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int k_vol,
 // wr + WR j (j < RB = BM / 16 / WR) and the columns [32 wc, 32 wc + 32).  (BM = 64 -- 79 KB of LDS, two workgroups per CU --
 // was measured and takes the SAME time as BM = 128 on every layer (profiles/r02_bf16_kernel_probe.txt): the kernel is bound
 // by per-CU throughput, not by the phases of one workgroup; only BM = 128 is instantiated.)
-template <int BM, int WC, int WR, int KS, int P>
+// ABF: the feature rows are bf16 ALREADY (the shadow copy their producer -- or lidiff_cast_bf16 -- left beside the fp32 matrix):
+// half the gather requests and bytes, an image row of KS channels is KS * 2 bytes, a lane's MFMA operand (8 channels of one pair
+// row) is ONE 16-byte read and needs no conversion.  Same pairs, same products, same order of sums: bit-identical to rounding the
+// fp32 rows on the fly (planes = 1 only).
+template <int BM, int WC, int WR, int KS, int P, bool ABF = false>
 __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf16_kernel(const ConvParams p_launch) {
+    static_assert(!ABF || P == 1, "bf16 rows: one plane");
     constexpr int BN = 32 * WC, NW = WC * WR, NT = 64 * NW, RB = BM / 16 / WR;
-    constexpr int AF = BM * KS;                  // floats per A image
-    constexpr int NCHK = KS / 4, RPI = 64 / NCHK, NINST = BM / RPI, T = (NINST + NW - 1) / NW;
+    constexpr int EB = ABF ? 2 : 4;              // bytes per stored feature element
+    constexpr int AF = BM * KS * EB / 4;         // floats per A image
+    constexpr int NCHK = KS * EB / 16, RPI = 64 / NCHK, NINST = BM / RPI, T = (NINST + NW - 1) / NW;
+    static_assert(NCHK == 4 || NCHK == 8 || NCHK == 16, "image rows of 64, 128 or 256 bytes");
+    // 16-byte chunks of an image row are XOR-permuted by the row so that the 16 rows a quarter wave reads at one channel offset
+    // fall into 16 different bank groups (256 bytes of banks = 1, 2 or 4 image rows)
+    auto swz = [](int r) { return NCHK == 16 ? r & 15 : NCHK == 8 ? (r >> 1) & 7 : (r >> 2) & 3; };
     constexpr int NS = KS / 32;                  // 32-channel steps per stage
+    // ABF: the stage's W fragments ([NS steps][BN / 16 column blocks] of 1 KB) come through LDS by DMA as well, ONE copy per
+    // workgroup -- each of the WR row groups loaded its own copy into registers before: 16 instead of 32 vector-memory requests
+    // per 64-channel stage beside the 16 of the bf16 rows (the request stream is what bounds this kernel)
+    constexpr bool WLDS = ABF;
+    constexpr int WBLK = NS * (BN / 16);         // 1 KB blocks per W image
+    constexpr int WIMG = WLDS ? WBLK * 1024 : 0; // bytes per W image
     ConvParams p = p_launch;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* a_buf = reinterpret_cast<float*>(smem);                       // 2 images
-    float* acc_lds = a_buf + 2 * AF;                                     // (BM + 1) x BN
+    char* w_img = reinterpret_cast<char*>(a_buf + 2 * AF);               // 2 W images (WLDS)
+    float* acc_lds = a_buf + 2 * AF + 2 * WIMG / 4;                      // (BM + 1) x BN
     int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + (BM + 1) * BN);
     int32_t* out_list = in_list + p.k_vol * BM;                          // float index of the accumulator row
     int32_t* cnt = out_list + p.k_vol * BM;
@@ -76,8 +93,8 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
     const int tmr = (g / p.tiles_n) * 8 + xcd;
     if (tmr >= tiles_all) return;
     const int rep = tmr / p.tiles_m, tm = tmr - rep * p.tiles_m;
-    p.in_a += (int64_t)rep * p.m_in * p.c_in_a;
-    if (p.in_b) p.in_b += (int64_t)rep * p.m_in * p.c_in_b;
+    p.in_a = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in_a) + (int64_t)rep * p.m_in * p.c_in_a * EB);
+    if (p.in_b) p.in_b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in_b) + (int64_t)rep * p.m_in * p.c_in_b * EB);
     p.out += (int64_t)rep * p.m_out * p.c_out;
     if (p.residual) p.residual += (int64_t)rep * p.m_out * p.c_out;
     const int64_t row0 = (int64_t)tm * BM;
@@ -139,21 +156,35 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
 #pragma unroll
     for (int j = 0; j < T; ++j) {
         const int r = RPI * (wave + NW * j) + lane / NCHK;
-        chb[j] = 16 * ((lane % NCHK) ^ (KS == 32 ? (r >> 1) & 7 : r & 15));
+        chb[j] = 16 * ((lane % NCHK) ^ swz(r));
     }
-    // byte offsets of this lane's two 16-byte chunks (channels 32 s + 8 lq .. + 7 of image row li) per 32-channel step
+    // byte offsets of this lane's 16-byte chunks (channels 32 s + 8 lq .. + 7 of image row li: two chunks of fp32, one of bf16)
+    // per 32-channel step
     int foff[NS][2];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            foff[s][h] = 4 * (li * KS + 4 * ((8 * s + 2 * lq + h) ^ (KS == 32 ? (li >> 1) & 7 : li & 15)));
+        for (int h = 0; h < 2; ++h) {
+            const int chunk = ABF ? 4 * s + lq : 8 * s + 2 * lq + h;
+            foff[s][h] = li * (KS * EB) + 16 * (chunk ^ swz(li));
+        }
 
     struct WRegs {
         uint4 v[NS][2][P];         // [32-channel step][column block][plane]
     };
     auto issue = [&](int img, int k, int slab, int n, WRegs& w) {
         const int ws = (p.probe & 2) ? 0 : (k * nslab32 + slab * NS) * w_slab_bytes;
+        if constexpr (WLDS) {
+            char* wdst = w_img + (img ? WIMG : 0);
+#pragma unroll
+            for (int j = 0; j < (WBLK + NW - 1) / NW; ++j) {
+                const int b = wave + NW * j;                           // block b = (step b / (BN / 16), column block b % (BN / 16))
+                if (WBLK % NW == 0 || b < WBLK)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wdst + b * 1024), 16,
+                                                             (((n0 >> 4) + b % (BN / 16)) * 64 + lane) * 16,
+                                                             ws + (b / (BN / 16)) * w_slab_bytes, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -162,11 +193,12 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
                 for (int q = 0; q < P; ++q)
                     w.v[s][cb][q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                         rsrc_w, w_lane_off + (cb * P + q) * 1024, ws + s * w_slab_bytes, 0));
+        }
         const int k0 = slab * KS;
         const bool from_a = k0 < p.c_in_a;
         const float* src = from_a ? p.in_a : p.in_b;
-        const int cw4 = (from_a ? p.c_in_a : p.c_in_b) * 4;
-        const int cb4 = (from_a ? k0 : k0 - p.c_in_a) * 4;
+        const int cw4 = (from_a ? p.c_in_a : p.c_in_b) * EB;                               // row pitch in bytes
+        const int cb4 = (from_a ? k0 : k0 - p.c_in_a) * EB;
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(p.m_in * cw4), 0x00020000);
         char* dst = reinterpret_cast<char*>(a_buf) + img;
 #pragma unroll
@@ -209,6 +241,14 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int slab = 0; slab < nslab; ++slab) {
+            if constexpr (WLDS) {                                     // this stage's fragments: landed before the barrier behind us
+                const char* wsrc = w_img + (img ? WIMG : 0) + lane * 16;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        wcur.v[s][cb][0] = *reinterpret_cast<const uint4*>(wsrc + (s * (BN / 16) + 2 * wc + cb) * 1024);
+            }
             if (slab + 1 < nslab) issue(img ^ IMG, k_cur, slab + 1, n, wnext);
             else if (k_next < p.k_vol) issue(img ^ IMG, k_next, 0, cnt[k_next], wnext);
             if (NJ > 0 && !(p.probe & 4)) {
@@ -216,10 +256,15 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
                 f32x4 f[2][2];                                        // [item parity][first / second 16-byte chunk]
                 auto read = [&](int it) {
                     const int jj = it / NS, ss = it % NS;
-                    const unsigned a0 = base + (wr + WR * jj) * (16 * KS * 4);
+                    const unsigned a0 = base + (wr + WR * jj) * (16 * KS * EB);
                     const unsigned x0 = a0 + foff[ss][0], x1 = a0 + foff[ss][1];
                     f32x4 r0, r1;
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1));
+                    if constexpr (ABF) {
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(r0) : "v"(x0));
+                        r1 = r0;
+                    } else {
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1));
+                    }
                     f[it & 1][0] = r0;
                     f[it & 1][1] = r1;
                 };
@@ -229,7 +274,8 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
                     const int jj = it / NS, ss = it % NS;
                     if (it + 1 < NI) {
                         read(it + 1);
-                        asm volatile("s_waitcnt lgkmcnt(2)");
+                        if constexpr (ABF) asm volatile("s_waitcnt lgkmcnt(1)");
+                        else asm volatile("s_waitcnt lgkmcnt(2)");
                     } else {
                         asm volatile("s_waitcnt lgkmcnt(0)");
                     }
@@ -237,8 +283,9 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
                     const f32x4 lo = f[it & 1][0], hi = f[it & 1][1];
                     f32x8 rest = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     bf16x8 a[P];
+                    if constexpr (ABF) a[0] = __builtin_bit_cast(bf16x8, lo);      // the row's 8 channels as they are stored
 #pragma unroll
-                    for (int q = 0; q < P; ++q) {
+                    for (int q = 0; q < (ABF ? 0 : P); ++q) {
                         a[q] = __builtin_convertvector(rest, bf16x8);              // round to nearest even
                         if (q + 1 < P) {                                          // rest -= float(a[q]): two bit ops per packed pair
                             const uint4 pk = __builtin_bit_cast(uint4, a[q]);
@@ -262,7 +309,7 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
                 }
             }
             LIDIFF_STAGE_BARRIER();
-            wcur = wnext;
+            if constexpr (!WLDS) wcur = wnext;
             img ^= IMG;
         }
         // flush: tile[row of pair][col] += acc.  An output row occurs at most once per offset, waves of one offset own disjoint
@@ -324,11 +371,12 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
     }
 }
 
-template <int BM, int WC, int WR, int KS, int P>
+template <int BM, int WC, int WR, int KS, int P, bool ABF = false>
 static int launch_bf16(const ConvParams& p, hipStream_t st) {
     constexpr int BN = 32 * WC;
-    const size_t lds = (size_t)2 * BM * KS * 4 + (size_t)(BM + 1) * BN * 4 + (size_t)p.k_vol * BM * 8 + 32 * 4 + BM * 4;
-    auto kern = spconv_fwd_bf16_kernel<BM, WC, WR, KS, P>;
+    const size_t lds = (size_t)2 * BM * KS * (ABF ? 2 : 4) + (ABF ? (size_t)2 * (KS / 32) * (BN / 16) * 1024 : 0) +
+                       (size_t)(BM + 1) * BN * 4 + (size_t)p.k_vol * BM * 8 + 32 * 4 + BM * 4;
+    auto kern = spconv_fwd_bf16_kernel<BM, WC, WR, KS, P, ABF>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -359,6 +407,17 @@ static int dispatch_bf16(const ConvParams& p, bool ks64, hipStream_t st) {
 #undef LIDIFF_BF16
 }
 
+// bf16 feature rows (planes = 1): the same tiles and stages
+static int dispatch_bf16_rows(const ConvParams& p, bool ks64, hipStream_t st) {
+#define LIDIFF_BF16(BM, WC, WR) \
+    return ks64 ? launch_bf16<BM, WC, WR, 64, 1, true>(p, st) : launch_bf16<BM, WC, WR, 32, 1, true>(p, st)
+    if (p.c_out % 128 == 0) LIDIFF_BF16(128, 4, 2);
+    if (p.c_out % 96 == 0) LIDIFF_BF16(128, 3, 2);
+    if (p.c_out % 64 == 0) LIDIFF_BF16(128, 2, 4);
+    LIDIFF_BF16(128, 1, 8);
+#undef LIDIFF_BF16
+}
+
 // =======================================================================================
 // Weight gradient with bf16 operands (bf16 training): dW[k] = in[pairs_k]^T g[pairs_k] as in spconv.hip's
 // spconv_bwd_w_kernel -- same tiles ([16 NBI ci] x [128 CB co] of dW[k] in MFMA accumulators, wave w the co blocks
@@ -366,7 +425,8 @@ static int dispatch_bf16(const ConvParams& p, bool ks64, hipStream_t st) {
 // TRANSPOSED in LDS, a_t[ci][pair] / g_t[co][pair] (row pitch 144 B: conflict-free 16-byte reads), so the operand of
 // v_mfma_f32_16x16x32_bf16 -- 8 consecutive pairs of one channel -- is one ds_read_b128 and a chunk is 2 MFMA steps per
 // block instead of 16.  Each thread gathers one (channel quad, pair octet): 8 float4 loads, 4 ds_write_b128.
-template <int NBI, int CB, bool IDENT>
+// ABF: `in` and `g` are bf16 rows already (8-byte loads of 4 channels, no rounding here): the same operands, bit-identical sums.
+template <int NBI, int CB, bool IDENT, bool ABF = false>
 __global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __restrict__ in_a, int c_in_a,
                                                                 const float* __restrict__ in_b, int c_in_b,
                                                                 const float* __restrict__ g, const int32_t* __restrict__ pairs_in,
@@ -393,7 +453,12 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
 
-    float4 pa[NA][8], pg[NG][8];                             // the next chunk's rows, in flight
+    using Quad = std::conditional_t<ABF, uint2, float4>;     // 4 channels of one row as stored
+    auto load4 = [](const float* base, unsigned elem) {
+        if constexpr (ABF) return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + (size_t)elem * 2);
+        else return *reinterpret_cast<const float4*>(base + elem);
+    };
+    Quad pa[NA][8], pg[NG][8];                               // the next chunk's rows, in flight
     unsigned keep_a[NA], keep_g[NG];                         // bit i: pair i of the unit is real
     auto fetch = [&](int64_t base) {
         int ra[NA][8], rg[NG][8];
@@ -422,9 +487,8 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __r
             keep_a[t] = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float* src = cic < c_in_a ? in_a + (unsigned)(ra[t][i] * c_in_a + cic)
-                                                : in_b + (unsigned)(ra[t][i] * c_in_b + (cic - c_in_a));
-                pa[t][i] = *reinterpret_cast<const float4*>(src);
+                pa[t][i] = cic < c_in_a ? load4(in_a, (unsigned)(ra[t][i] * c_in_a + cic))
+                                        : load4(in_b, (unsigned)(ra[t][i] * c_in_b + (cic - c_in_a)));
                 keep_a[t] |= (u < UA && base + 8 * oct + i < s_hi && ci < c_in) ? 1u << i : 0u;
             }
         }
@@ -434,22 +498,36 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __r
             keep_g[t] = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                pg[t][i] = *reinterpret_cast<const float4*>(g + (unsigned)(rg[t][i] * c_out + min(co, c_out - 4)));
+                pg[t][i] = load4(g, (unsigned)(rg[t][i] * c_out + min(co, c_out - 4)));
                 keep_g[t] |= (u < UG && base + 8 * oct + i < s_hi && co < c_out) ? 1u << i : 0u;
             }
         }
     };
     // the unit's 8 pairs x 4 channels -> four rows of 8 bf16 (round to nearest even), zero where the pair is not real
-    auto put = [&](char* dst, const float4 (&v)[8], unsigned keep, int quad, int oct) {
-        float m[8];
+    auto put = [&](char* dst, const Quad (&v)[8], unsigned keep, int quad, int oct) {
+        if constexpr (ABF) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) m[i] = (keep >> i) & 1u ? 1.f : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                unsigned h[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x8 r;
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned word = j < 2 ? v[i].x : v[i].y;
+                    h[i] = (keep >> i) & 1u ? ((j & 1) ? word >> 16 : word & 0xffffu) : 0u;
+                }
+                *reinterpret_cast<uint4*>(dst + (4 * quad + j) * PB + 16 * oct) =
+                    make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            }
+        } else {
+            float m[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = (j == 0 ? v[i].x : j == 1 ? v[i].y : j == 2 ? v[i].z : v[i].w) * m[i];
-            *reinterpret_cast<bf16x8*>(dst + (4 * quad + j) * PB + 16 * oct) = __builtin_convertvector(r, bf16x8);
+            for (int i = 0; i < 8; ++i) m[i] = (keep >> i) & 1u ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x8 r;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[i] = (j == 0 ? v[i].x : j == 1 ? v[i].y : j == 2 ? v[i].z : v[i].w) * m[i];
+                *reinterpret_cast<bf16x8*>(dst + (4 * quad + j) * PB + 16 * oct) = __builtin_convertvector(r, bf16x8);
+            }
         }
     };
     auto stash = [&]() {
@@ -506,13 +584,13 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __r
             }
 }
 
-template <int NBI, int CB, bool IDENT>
+template <int NBI, int CB, bool IDENT, bool ABF>
 static int launch_bwd_w_bf16(const float* in_a, int c_in_a, const float* in_b, int c_in_b, const float* g,
                              const int32_t* pin, const int32_t* pout, const int32_t* off, int k_vol, int64_t m_out,
                              int64_t n_pairs, int c_out, float* dw, float* workspace, hipStream_t st) {
     constexpr int CIT = 16 * NBI, COT = 128 * CB;
     const size_t lds = (size_t)(CIT + COT) * (2 * kDwPairs + 16);
-    auto kern = spconv_bwd_w_bf16_kernel<NBI, CB, IDENT>;
+    auto kern = spconv_bwd_w_bf16_kernel<NBI, CB, IDENT, ABF>;
     static thread_local bool configured = false;
     if (!configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -539,7 +617,7 @@ using namespace lidiff;
 extern "C" int lidiff_spconv_bwd_w_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b,
                                         const float* grad_out, const int32_t* pairs_in, const int32_t* pairs_out,
                                         const int32_t* offset_ptr, int64_t n_pairs, int32_t k_vol, int64_t m_in,
-                                        int64_t m_out, int32_t c_out, float* dw, float* workspace, void* stream) {
+                                        int64_t m_out, int32_t c_out, float* dw, float* workspace, int32_t in_bf16, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && grad_out != nullptr && dw != nullptr, "null pointer");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
@@ -556,11 +634,12 @@ extern "C" int lidiff_spconv_bwd_w_bf16(const float* in_a, int32_t c_in_a, const
     hipStream_t st = (hipStream_t)stream;
     const int c_in = c_in_a + c_in_b;
     const int nbi = c_in > 128 ? 16 : c_in > 64 ? 8 : c_in > 32 ? 4 : 2;      // as lidiff_spconv_bwd_w (same workspace size)
+#define LIDIFF_DW_(NBI, CB, ID, AB)                                                                                      \
+    launch_bwd_w_bf16<NBI, CB, ID, AB>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr, k_vol, m_out,  \
+                                       n_pairs, c_out, dw, workspace, st)
 #define LIDIFF_DW(NBI, CB)                                                                                               \
-    return identity ? launch_bwd_w_bf16<NBI, CB, true>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr,  \
-                                                       k_vol, m_out, n_pairs, c_out, dw, workspace, st)                     \
-                    : launch_bwd_w_bf16<NBI, CB, false>(in_a, c_in_a, in_b, c_in_b, grad_out, pairs_in, pairs_out, offset_ptr, \
-                                                        k_vol, m_out, n_pairs, c_out, dw, workspace, st)
+    return identity ? (in_bf16 ? LIDIFF_DW_(NBI, CB, true, true) : LIDIFF_DW_(NBI, CB, true, false))                     \
+                    : (in_bf16 ? LIDIFF_DW_(NBI, CB, false, true) : LIDIFF_DW_(NBI, CB, false, false))
     if (c_out > 128) {
         if (nbi == 16) LIDIFF_DW(16, 2);
         if (nbi == 8) LIDIFF_DW(8, 2);
@@ -572,6 +651,31 @@ extern "C" int lidiff_spconv_bwd_w_bf16(const float* in_a, int32_t c_in_a, const
     if (nbi == 4) LIDIFF_DW(4, 1);
     LIDIFF_DW(2, 1);
 #undef LIDIFF_DW
+#undef LIDIFF_DW_
+}
+
+// ---------------------------------------------------------------------------------------
+// fp32 -> bf16 rows (round to nearest even): the shadow copy of a feature matrix the bf16 convolutions gather from
+__global__ void cast_bf16_kernel(const float* __restrict__ src, int64_t n8, int64_t n, __bf16* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n8) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        const lidiff::f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        reinterpret_cast<lidiff::bf16x8*>(dst)[i] = __builtin_convertvector(v, lidiff::bf16x8);
+    } else if (i == n8) {
+        for (int64_t e = 8 * n8; e < n; ++e) dst[e] = (__bf16)src[e];
+    }
+}
+
+extern "C" int lidiff_cast_bf16(const float* src, int64_t n, void* dst, void* stream) {
+    LIDIFF_CHECK_ARG(n >= 0, "negative size");
+    if (n == 0) return 0;
+    LIDIFF_CHECK_ARG(src != nullptr && dst != nullptr, "null pointer");
+    LIDIFF_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "pointers must be 16-byte aligned");
+    const int64_t n8 = n / 8;
+    cast_bf16_kernel<<<(unsigned)ceil_div(n8 + 1, 256), 256, 0, (hipStream_t)stream>>>(src, n8, n, (__bf16*)dst);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
 }
 
 
@@ -596,8 +700,9 @@ extern "C" int lidiff_spconv_pack_weights_bf16(const float* w, int32_t k_vol, in
 extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b, int32_t c_in_b, const void* w_packed,
                                       int32_t planes, const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out,
                                       int32_t c_out, float* out, const float* ep_scale, const float* ep_shift,
-                                      const float* residual, int32_t relu, int32_t replicas, void* stream) {
+                                      const float* residual, int32_t relu, int32_t replicas, int32_t in_bf16, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && w_packed != nullptr && out != nullptr, "null pointer");
+    LIDIFF_CHECK_ARG(!in_bf16 || planes == 1, "bf16 feature rows: planes must be 1");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(planes >= 1 && planes <= 3, "planes must be 1, 2 or 3");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
@@ -632,6 +737,7 @@ extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const f
     p.probe = probe;
     hipStream_t st = (hipStream_t)stream;
     const bool ks64 = c_in_a % 64 == 0 && c_in_b % 64 == 0;
+    if (in_bf16) return dispatch_bf16_rows(p, ks64, st);
     if (planes == 1) return dispatch_bf16<1>(p, ks64, st);
     if (planes == 2) return dispatch_bf16<2>(p, ks64, st);
     return dispatch_bf16<3>(p, ks64, st);

@@ -1180,6 +1180,29 @@ def packed_weights_bf16(w: torch.Tensor, transposed: bool = False, flip: bool = 
     return hit[1]
 
 
+# bf16 training: the convolutions gather bf16 SHADOW rows of their inputs (cast once per tensor, used by the forward, the input
+# gradient and the weight gradient) instead of rounding the fp32 rows inside every kernel (False: as rounds 2-4)
+BF16_ROWS = os.environ.get("LIDIFF_BF16_ROWS", "1") != "0"
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    """bf16 shadow of a contiguous fp32 matrix (round to nearest even, lidiff_cast_bf16), kept on the tensor object: the layers
+    that read the same tensor (a block's first convolution and its shortcut; a convolution's forward and its weight gradient)
+    share one copy."""
+    require_device(x)
+    hit = getattr(x, "_lidiff_bf16", None)
+    if hit is not None and hit[0] == (x.data_ptr(), x._version, tuple(x.shape)):
+        return hit[1]
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call("lidiff_cast_bf16", ptr(x), x.numel(), ptr(out), stream_ptr())
+    try:
+        x._lidiff_bf16 = ((x.data_ptr(), x._version, tuple(x.shape)), out)
+    except AttributeError:
+        pass
+    return out
+
+
 def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                     in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None, relu: bool = False,
                     replicas: int = 1, transposed: bool = False, flip: bool = False, planes: int = 1) -> torch.Tensor:
@@ -1199,7 +1222,9 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
         in_b = in_b.contiguous()
         c_b = in_b.shape[1]
     assert c_a + c_b == c_in, f"channel mismatch {c_a}+{c_b} != {c_in}"
-    assert in_a.dtype == torch.float32 and in_a.shape[0] % replicas == 0
+    rows16 = in_a.dtype == torch.bfloat16                # bf16 shadow rows (cast_bf16): planes = 1 only
+    assert (in_a.dtype == torch.float32 or (rows16 and planes == 1)) and in_a.shape[0] % replicas == 0
+    assert in_b is None or in_b.dtype == in_a.dtype
     m_in = in_a.shape[0] // replicas
     if nbr is not None:
         assert nbr.shape == (k, m_out) and nbr.dtype == torch.int32 and nbr.is_contiguous()
@@ -1216,7 +1241,7 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
         _lib.join_pending()             # (the wait for maps still being built on a side stream is not the kernel's time)
         start.record()
     call("lidiff_spconv_fwd_bf16", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), int(planes), ptr(nbr), k, m_in, m_out, c_out,
-         ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), stream_ptr())
+         ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), int(rows16), stream_ptr())
     if timed:
         end.record()
     if prof is not None:
@@ -1269,6 +1294,10 @@ def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None, bf16: bool = False) -> 
     grad_out = grad_out.contiguous()
     c_a, c_b = in_a.shape[1], 0 if in_b is None else in_b.shape[1]
     m_out, c_out = grad_out.shape
+    rows16 = in_a.dtype == torch.bfloat16                # bf16 shadow rows of BOTH operands (cast_bf16)
+    if rows16:
+        assert bf16 and grad_out.dtype == torch.bfloat16 and (in_b is None or in_b.dtype == torch.bfloat16)
+        assert c_a % 4 == 0 and c_b % 4 == 0 and c_out % 4 == 0
     if c_a % 4 == 0 and c_b % 4 == 0 and c_out % 4 == 0:
         if in_b is not None:
             in_b = in_b.contiguous()
@@ -1284,9 +1313,12 @@ def spconv_bwd_w(in_a, grad_out, nbr, k: int, in_b=None, bf16: bool = False) -> 
         if timed:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        call("lidiff_spconv_bwd_w_bf16" if bf16 else "lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out),
-             ptr(pin), ptr(pout), ptr(off),
-             n_pairs, k, in_a.shape[0], m_out, c_out, ptr(dw), ptr(ws), stream_ptr())
+        if bf16:
+            call("lidiff_spconv_bwd_w_bf16", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out), ptr(pin), ptr(pout), ptr(off),
+                 n_pairs, k, in_a.shape[0], m_out, c_out, ptr(dw), ptr(ws), int(rows16), stream_ptr())
+        else:
+            call("lidiff_spconv_bwd_w", ptr(in_a), c_a, ptr(in_b), c_b, ptr(grad_out), ptr(pin), ptr(pout), ptr(off),
+                 n_pairs, k, in_a.shape[0], m_out, c_out, ptr(dw), ptr(ws), stream_ptr())
         if timed:
             ev[1].record()
             prof.dw.append(ev)

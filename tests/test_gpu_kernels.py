@@ -1238,3 +1238,51 @@ def test_slice_and_head_in_one_launch_vs_torch_float64(device, c, reps, n, m):
         pad[r, :m] = feats[r * m:(r + 1) * m]
     assert torch.equal(ops.slice_head(pad.reshape(-1, c), inv, head, replicas=reps), got)
     assert not ops.slice_head_applies(torch.nn.Sequential(torch.nn.Linear(c, 24), torch.nn.LeakyReLU(0.1), torch.nn.Linear(24, 3)).to(device))
+
+
+@pytest.mark.parametrize("cin,split,cout,kind", [(256, 0, 256, "k3"), (128, 64, 128, "k3"), (96, 0, 96, "k3"), (32, 0, 64, "k3"),
+                                                 (64, 0, 32, "down"), (160, 96, 96, "k3"), (64, 0, 64, "k1")])
+def test_spconv_bf16_from_shadow_rows_is_bit_identical(device, cin, split, cout, kind):
+    """lidiff_spconv_fwd_bf16 / lidiff_spconv_bwd_w_bf16 with in_bf16 = 1: the feature rows arrive as bf16 (lidiff_cast_bf16:
+    round to nearest even -- the conversion the kernels otherwise apply to every gathered fp32 row).  Same operands, same
+    products, same order of sums: the forward (every tile width, 64- / 32-channel stages, split inputs, epilogue, replicas),
+    the transposed form the input gradient uses and the weight gradient equal the fp32-row form bit for bit."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(5 + cin + cout)
+    uniq, _, _ = me.voxelize(random_cloud(9000, 14, 81, batch=2))
+    if kind == "k3":
+        nbr_np = me.kernel_map(uniq, uniq, 3, 1)
+    elif kind == "down":
+        coarse, _ = me.stride_map(uniq, 2)
+        nbr_np = me.kernel_map(uniq, coarse, 2, 1)
+    else:
+        nbr_np = None
+    m_in = uniq.shape[0]
+    m_out = nbr_np.shape[1] if nbr_np is not None else m_in
+    k = nbr_np.shape[0] if nbr_np is not None else 1
+    nbr = dev_i32(nbr_np, device) if nbr_np is not None else None
+    reps = 2
+    x = torch.randn(reps * m_in, cin, generator=g).to(device)
+    w = (torch.randn(k, cin, cout, generator=g) / np.sqrt(cin * k / 3)).to(device)
+    xa = x[:, :split].contiguous() if split else x
+    xb = x[:, split:].contiguous() if split else None
+    x16 = ops.cast_bf16(x)
+    assert x16.dtype == torch.bfloat16 and torch.equal(x16, x.to(torch.bfloat16))          # torch rounds to nearest even too
+    a16 = ops.cast_bf16(xa)
+    b16 = ops.cast_bf16(xb) if xb is not None else None
+    kw = dict(scale=(torch.rand(cout, generator=g) + 0.5).to(device), shift=torch.randn(cout, generator=g).to(device),
+              residual=torch.randn(reps * m_out, cout, generator=g).to(device), relu=True, replicas=reps)
+    ref = ops.spconv_fwd_bf16(xa, w, nbr, m_out, in_b=xb, **kw)
+    got = ops.spconv_fwd_bf16(a16, w, nbr, m_out, in_b=b16, **kw)
+    assert torch.equal(got, ref), (got - ref).abs().max().item()
+    if not split and kind != "down":
+        # the input gradient's form: the transposed kernel over the (here: the same, flipped) map; and the weight gradient
+        gr = torch.randn(m_out, cout, generator=g).to(device)
+        flip = kind == "k3"
+        ref_x = ops.spconv_fwd_bf16(gr, w, nbr, m_in, transposed=True, flip=flip)
+        got_x = ops.spconv_fwd_bf16(ops.cast_bf16(gr), w, nbr, m_in, transposed=True, flip=flip)
+        assert torch.equal(got_x, ref_x)
+        x1 = x[:m_in].contiguous()
+        ref_w = ops.spconv_bwd_w(x1, gr, nbr, k, bf16=True)
+        got_w = ops.spconv_bwd_w(ops.cast_bf16(x1), ops.cast_bf16(gr), nbr, k, bf16=True)
+        assert torch.equal(got_w, ref_w), (got_w - ref_w).abs().max().item()

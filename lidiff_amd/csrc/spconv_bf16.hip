@@ -73,6 +73,10 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
     // ABF: the stage's W fragments ([NS steps][BN / 16 column blocks] of 1 KB) come through LDS by DMA as well, ONE copy per
     // workgroup -- each of the WR row groups loaded its own copy into registers before: 16 instead of 32 vector-memory requests
     // per 64-channel stage beside the 16 of the bf16 rows (the request stream is what bounds this kernel)
+    // the accumulator tile's 16-byte chunks are XOR-permuted by the row's low bits (see the flush): the largest power of two
+    // dividing the chunks per row, at most 16
+    constexpr int TCH = BN / 4;
+    constexpr int TSWZ = (TCH % 16 == 0) ? 16 : (TCH % 8 == 0) ? 8 : (TCH % 4 == 0) ? 4 : 2;
     constexpr bool WLDS = ABF;
     constexpr int WBLK = NS * (BN / 16);         // 1 KB blocks per W image
     constexpr int WIMG = WLDS ? WBLK * 1024 : 0; // bytes per W image
@@ -304,8 +308,8 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
                         for (int i = 0; i <= d; ++i)
 #pragma unroll
                             for (int cb = 0; cb < 2; ++cb)
-                                acc[jj][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    a[i], __builtin_bit_cast(bf16x8, wcur.v[ss][cb][d - i]), acc[jj][cb], 0, 0, 0);
+                                acc[jj][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(          // operands swapped: see the flush
+                                    __builtin_bit_cast(bf16x8, wcur.v[ss][cb][d - i]), a[i], acc[jj][cb], 0, 0, 0);
                 }
             }
             LIDIFF_STAGE_BARRIER();
@@ -314,20 +318,28 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
         }
         // flush: tile[row of pair][col] += acc.  An output row occurs at most once per offset, waves of one offset own disjoint
         // (row block, column) pieces, and a stage barrier lies between the flushes of two offsets.
-        const int32_t* ol = out_list + k_cur * BM + 4 * lq;
+        // The MFMAs run with the operands SWAPPED (W fragment first): the transposed product leaves in each lane four CONSECUTIVE
+        // channels (32 wc + 16 cb + 4 lq .. + 3) of ONE pair row (16 block + li) -- one 16-byte read-modify-write of the tile per
+        // (block, column block) instead of four 4-byte ones to four rows; a row's 16-byte chunks are XOR-permuted by the row so
+        // that the 16 rows a quarter wave flushes at one channel offset fall into different banks (as spconv.hip, round 4).
+        const int32_t* ol = out_list + k_cur * BM + li;
         if (p.probe & 8) return;
+        int addr[NJ > 0 ? NJ : 1][2];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int4 o = *reinterpret_cast<const int4*>(ol + 16 * (wr + WR * j));
+            const int o = ol[16 * (wr + WR * j)];                     // float index of the pair's tile row
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int col = 32 * wc + 16 * cb + li;
-                acc_lds[o.x + col] += acc[j][cb][0];
-                acc_lds[o.y + col] += acc[j][cb][1];
-                acc_lds[o.z + col] += acc[j][cb][2];
-                acc_lds[o.w + col] += acc[j][cb][3];
-            }
+            for (int cb = 0; cb < 2; ++cb) addr[j][cb] = o + 4 * ((8 * wc + 4 * cb + lq) ^ ((o / BN) & (TSWZ - 1)));
         }
+        f32x4 old[NJ > 0 ? NJ : 1][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) old[j][cb] = *reinterpret_cast<const f32x4*>(acc_lds + addr[j][cb]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4*>(acc_lds + addr[j][cb]) = old[j][cb] + acc[j][cb];
     };
 
     while (k_cur < p.k_vol) {
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
     for (int e = tid; e < rows_here * (BN / 4); e += NT) {
         const int r = e / (BN / 4), cq = e % (BN / 4);
         const int col = n0 + 4 * cq;
-        float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + cq];
+        float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + (cq ^ (r & (TSWZ - 1)))];
         if (p.scale) {
             const float4 s = *reinterpret_cast<const float4*>(p.scale + col);
             v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;

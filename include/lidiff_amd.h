@@ -380,15 +380,17 @@ int lidiff_argmin_rows_f32(const float* a, int64_t n, const float* b, int64_t m,
  *   lidiff_bn_bwd   : sum_dy[c] = sum dy, sum_dy_xmu[c] = sum dy * (x - mean) (d beta and, times invstd, d gamma), and -- unless
  *                     dx == NULL -- dx = (dy - sum_dy / m - (x - mean) * invstd^2 * sum_dy_xmu / m) * invstd * gamma.
  *                     y_relu != NULL: the forward applied ReLU and y_relu is its output -- dy counts only where y_relu > 0.
- *                     d_residual != NULL: receives that (masked) dy, the gradient of the forward's residual operand. */
+ *                     d_residual != NULL: receives that (masked) dy, the gradient of the forward's residual operand.
+ *   y_bf16 / dx_bf16 (nullable): a bf16 copy of y / dx (round to nearest even) written by the same launch -- the shadow rows
+ *                     the bf16 convolutions gather (lidiff_spconv_fwd_bf16 in_bf16), instead of a lidiff_cast_bf16 pass. */
 int64_t lidiff_bn_workspace_bytes(int32_t c);
 int lidiff_bn_stats(const float* x, int64_t m, int32_t c, float eps, float* mean, float* var, float* invstd,
                     float* running_mean, float* running_var, float momentum, void* workspace, void* stream);
 int lidiff_bn_apply(const float* x, int64_t m, int32_t c, const float* mean, const float* invstd, const float* gamma,
-                    const float* beta, const float* residual, int32_t relu, float* y, void* stream);
+                    const float* beta, const float* residual, int32_t relu, float* y, void* y_bf16, void* stream);
 int lidiff_bn_bwd(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                   const float* invstd, const float* gamma, float* sum_dy, float* sum_dy_xmu, float* dx, float* d_residual,
-                  void* workspace, void* stream);
+                  void* workspace, void* dx_bf16, void* stream);
 
 /* The same normalisation with the statistics shared over a process group -- ME.MinkowskiSyncBatchNorm, which
  * train.py:90 / train_refine.py:58 (convert_sync_batchnorm) put in place of every MinkowskiBatchNorm under DDP.  The library never
@@ -413,7 +415,7 @@ int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* y_relu, int
                        double* sums, void* workspace, void* stream);
 int lidiff_bn_bwd_apply(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                         const float* invstd, const float* gamma, const double* sums, const double* count, float* sum_dy,
-                        float* sum_dy_xmu, float* dx, float* d_residual, void* stream);
+                        float* sum_dy_xmu, float* dx, float* d_residual, void* dx_bf16, void* stream);
 
 /* The boundary between two denoising steps as one launch -- DiffCompletion.completion_loop, pipeline:148-153 (classifier-free
  * guidance), :161-163 (offsets, dpm_scheduler.step: sde-dpmsolver++) and :164 with :68-84 (points_to_tensor of the

@@ -55,8 +55,8 @@ SIGNATURES = {
     "lidiff_spconv_bwd_w_bf16": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _i32, _p]),
     "lidiff_bn_workspace_bytes": (_i64, [_i32]),
     "lidiff_bn_stats": (_i32, [_p, _i64, _i32, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p, _p]),
-    "lidiff_bn_apply": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),
-    "lidiff_bn_bwd": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "lidiff_bn_apply": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),
+    "lidiff_bn_bwd": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "lidiff_cfg_dpm_step": (_i32, [_p, _p, C.c_float, _p, _p, _p, _p, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_double, C.c_float, _i64, _i64, _i32, _p, _p, _p, _p]),
     "lidiff_points_to_field": (_i32, [_p, _i32, C.c_float, _i64, _i64, _i32, _p, _p, _p]),
@@ -65,7 +65,7 @@ SIGNATURES = {
     "lidiff_bn_sums": (_i32, [_p, _i64, _i32, _p, _p, _p]),
     "lidiff_bn_stats_from_sums": (_i32, [_p, _i32, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p]),
     "lidiff_bn_bwd_sums": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
-    "lidiff_bn_bwd_apply": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "lidiff_bn_bwd_apply": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "lidiff_morton_keys": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_gather_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "lidiff_slice_head_supported": (_i32, [_i32, _i32, _i32]),

@@ -150,10 +150,19 @@ __global__ void bn_bwd_from_sums_kernel(const double* __restrict__ sums, int c, 
     sum_dy_xmu[ch] = (float)sums[c + ch];
 }
 
+// four floats -> four bf16 (round to nearest even), as lidiff_cast_bf16 rounds
+__device__ __forceinline__ uint2 pack_bf16x4(const float4 v) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t f = {v.x, v.y, v.z, v.w};
+    return __builtin_bit_cast(uint2, __builtin_convertvector(f, bf16x4_t));
+}
+
 template <bool RELU>
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ residual, int64_t total4, int cq, float* __restrict__ y) {
+                                const float* __restrict__ residual, int64_t total4, int cq, float* __restrict__ y,
+                                uint2* __restrict__ y16 = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     const int q = (int)(i % cq);
@@ -171,6 +180,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     }
     if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     reinterpret_cast<float4*>(y)[i] = o;
+    if (y16) y16[i] = pack_bf16x4(o);                     // the bf16 shadow the next convolution gathers (bf16 training)
 }
 
 template <bool RELU>
@@ -179,7 +189,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ gamma, const float* __restrict__ sum_dy,
                                     const float* __restrict__ sum_dy_xmu, int64_t total4, int cq, float inv_m,
                                     float* __restrict__ dx, float* __restrict__ d_residual,
-                                    const double* __restrict__ d_count = nullptr) {
+                                    const double* __restrict__ d_count = nullptr, uint2* __restrict__ dx16 = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     if (d_count) inv_m = (float)(1.0 / *d_count);         // SyncBatchNorm: the all-reduced row count stays on the device
@@ -204,6 +214,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     o.x = one(g.x, xv.x, mu.x, is.x, sd.x, sx.x, w.x); o.y = one(g.y, xv.y, mu.y, is.y, sd.y, sx.y, w.y);
     o.z = one(g.z, xv.z, mu.z, is.z, sd.z, sx.z, w.z); o.w = one(g.w, xv.w, mu.w, is.w, sd.w, sx.w, w.w);
     reinterpret_cast<float4*>(dx)[i] = o;
+    if (dx16) dx16[i] = pack_bf16x4(o);                   // ... and of the gradient the convolution in front of this layer gathers
 }
 
 static int bn_blocks(int64_t m, int c, int64_t* per) {
@@ -291,7 +302,7 @@ extern "C" int lidiff_bn_bwd_sums(const float* dy, const float* x, const float* 
 
 extern "C" int lidiff_bn_bwd_apply(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                                    const float* invstd, const float* gamma, const double* sums, const double* count,
-                                   float* sum_dy, float* sum_dy_xmu, float* dx, float* d_residual, void* stream) {
+                                   float* sum_dy, float* sum_dy_xmu, float* dx, float* d_residual, void* dx_bf16, void* stream) {
     LIDIFF_CHECK_ARG(mean && invstd && sums && count && sum_dy && sum_dy_xmu && ((dy && x) || m == 0), "null pointer");
     LIDIFF_CHECK_ARG(m >= 0 && bn_shape_ok(m > 0 ? m : 1, c), "need m >= 0 and c a multiple of 4 in [4, 1024]");
     hipStream_t st = (hipStream_t)stream;
@@ -299,8 +310,8 @@ extern "C" int lidiff_bn_bwd_apply(const float* dy, const float* x, const float*
     if (m > 0 && (dx != nullptr || d_residual != nullptr)) {
         const int64_t total4 = m * (c / 4);
         const unsigned grid = (unsigned)ceil_div(total4, 256);
-        if (y_relu) bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(dy, x, y_relu, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, 0.f, dx, d_residual, count);
-        else bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(dy, x, nullptr, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, 0.f, dx, d_residual, count);
+        if (y_relu) bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(dy, x, y_relu, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, 0.f, dx, d_residual, count, (uint2*)dx_bf16);
+        else bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(dy, x, nullptr, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, 0.f, dx, d_residual, count, (uint2*)dx_bf16);
     }
     LIDIFF_CHECK_LAUNCH();
     return 0;
@@ -308,22 +319,22 @@ extern "C" int lidiff_bn_bwd_apply(const float* dy, const float* x, const float*
 
 extern "C" int lidiff_bn_apply(const float* x, int64_t m, int32_t c, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, const float* residual, int32_t relu, float* y,
-                               void* stream) {
+                               void* y_bf16, void* stream) {
     LIDIFF_CHECK_ARG(mean && invstd && ((x && y) || m == 0), "null pointer");
     LIDIFF_CHECK_ARG(m >= 0 && bn_shape_ok(m > 0 ? m : 1, c), "need m >= 0 and c a multiple of 4 in [4, 1024]");
     if (m == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total4 = m * (c / 4);
     const unsigned grid = (unsigned)ceil_div(total4, 256);
-    if (relu) bn_apply_kernel<true><<<grid, 256, 0, st>>>(x, mean, invstd, gamma, beta, residual, total4, c / 4, y);
-    else bn_apply_kernel<false><<<grid, 256, 0, st>>>(x, mean, invstd, gamma, beta, residual, total4, c / 4, y);
+    if (relu) bn_apply_kernel<true><<<grid, 256, 0, st>>>(x, mean, invstd, gamma, beta, residual, total4, c / 4, y, (uint2*)y_bf16);
+    else bn_apply_kernel<false><<<grid, 256, 0, st>>>(x, mean, invstd, gamma, beta, residual, total4, c / 4, y, (uint2*)y_bf16);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int lidiff_bn_bwd(const float* dy, const float* x, const float* y_relu, int64_t m, int32_t c, const float* mean,
                              const float* invstd, const float* gamma, float* sum_dy, float* sum_dy_xmu, float* dx,
-                             float* d_residual, void* workspace, void* stream) {
+                             float* d_residual, void* workspace, void* dx_bf16, void* stream) {
     LIDIFF_CHECK_ARG(dy && x && mean && invstd && sum_dy && sum_dy_xmu && workspace, "null pointer");
     LIDIFF_CHECK_ARG(bn_shape_ok(m, c), "need m >= 1 and c a multiple of 4 in [4, 1024]");
     hipStream_t st = (hipStream_t)stream;
@@ -337,8 +348,8 @@ extern "C" int lidiff_bn_bwd(const float* dy, const float* x, const float* y_rel
         const int64_t total4 = m * (c / 4);
         const unsigned grid = (unsigned)ceil_div(total4, 256);
         const float inv_m = 1.0f / (float)m;
-        if (y_relu) bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(dy, x, y_relu, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, inv_m, dx, d_residual);
-        else bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(dy, x, nullptr, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, inv_m, dx, d_residual);
+        if (y_relu) bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(dy, x, y_relu, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, inv_m, dx, d_residual, nullptr, (uint2*)dx_bf16);
+        else bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(dy, x, nullptr, mean, invstd, gamma, sum_dy, sum_dy_xmu, total4, c / 4, inv_m, dx, d_residual, nullptr, (uint2*)dx_bf16);
     }
     LIDIFF_CHECK_LAUNCH();
     return 0;

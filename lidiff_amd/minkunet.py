@@ -264,6 +264,8 @@ def _run_up(up, x, skip):
 
 # training path: the conditioning MLPs' row-wise Linears in front of the gather (see MinkUNetDiff._condition)
 _COMMUTE_TRAIN = os.environ.get("LIDIFF_COMMUTE_TRAIN", "1") != "0"
+# ... and the rest of the conditioning MLP on the (part row, batch) pair table (see MinkUNetDiff._condition)
+_PAIR_TABLE_TRAIN = os.environ.get("LIDIFF_PAIR_TABLE_TRAIN", "1") != "0"
 
 
 def _run_mlp(mlp, x):
@@ -349,7 +351,9 @@ class _RepeatSegments(torch.autograd.Function):
 class _BatchRows(torch.autograd.Function):
     """t[b] for every row of a coordinate map (b = the row's batch index): the same values as _RepeatSegments, from the
     batch column itself -- no host read of the rows per batch (torch.unique(...).tolist() is a device -> host sync per level
-    and step).  Backward: one masked column sum per batch (B is 2 in LiDiff's training), deterministic."""
+    and step).  Backward: the column sums per batch as ONE segment sum over the rows sorted by batch (ops.scatter_add_rows: fixed
+    order, deterministic; the sort is cached on the batch-index tensor, which a level keeps for the step) -- rounds 2-4 ran a
+    masked broadcast product and a reduction per batch, 4 ms of a 130 ms step."""
 
     @staticmethod
     def forward(ctx, t, bidx):
@@ -360,6 +364,8 @@ class _BatchRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (bidx,) = ctx.saved_tensors
+        if g.is_cuda and g.dtype == torch.float32:
+            return ops.scatter_add_rows(g, bidx, ctx.nb), None
         return torch.stack([(g * (bidx == b).unsqueeze(1)).sum(dim=0) for b in range(ctx.nb)]), None
 
 
@@ -449,12 +455,16 @@ class MinkUNetDiff(_Base):
         by ascending batch index, so row r takes t[batch of r]: a gather through the map's batch column, without reading the
         rows per batch back to the host; the backward is one masked column sum per batch (torch's own backward of
         repeat_interleave is an index_add of M_l x C atomics into B rows: 5 ms per call at 360k rows)."""
+        return _BatchRows.apply(t, self._batch_index(x))
+
+    @staticmethod
+    def _batch_index(x):
         aux = x.coordinate_manager.aux                  # lives and dies with the step's coordinate manager
         key = ("batch_index", x.tensor_stride)
         bidx = aux.get(key)
         if bidx is None:
             bidx = aux[key] = x.C[:, 0].long()
-        return _BatchRows.apply(t, bidx)
+        return bidx
 
     def _condition_terms(self, name, part_feats, temp_emb):
         """The two summands of lin1(cat(latent(match), temp)) before the gather (fused plan): the row-wise MLPs run on
@@ -555,8 +565,24 @@ class MinkUNetDiff(_Base):
                    else contextlib.nullcontext())
             with amp:
                 h_p, h_t = self._condition_terms(name, part.F, temp_emb)
-            hidden = TF.leaky_relu(ME._GatherRows.apply(h_p.float(), self.match_index(x, part))
-                                   + self._per_batch_rows(h_t.float(), x), 0.1)
+            idx = self.match_index(x, part)
+            nb, m_p = h_t.shape[0], h_p.shape[0]
+            if _PAIR_TABLE_TRAIN and 2 * m_p * nb <= x.F.shape[0]:
+                # Round 5: row i's weight depends on i only through the PAIR (matched part row idx[i], batch b(i)) -- at most
+                # M_p x B distinct values (23 000 at B = 2) for the M_l rows of x (360 000 on the fine levels).  So the activation
+                # and the second Linear run on the [M_p x B] pair table as well and w is a gather of it: the [M_l, 256] hidden
+                # matrix of every level, its GEMM, the GEMM's weight gradient over K = M_l and a dozen elementwise passes over it
+                # are gone.  Same function of the same inputs as the reference order (no assumption that a row's match lies in
+                # its own batch element); autograd: the gather's segment sum, then the small MLP.
+                hid = TF.leaky_relu(h_p.float().unsqueeze(1) + h_t.float().unsqueeze(0), 0.1)       # [M_p, B, h]
+                table = _run_mlp(lin2, hid.reshape(m_p * nb, -1))                                     # [M_p B, C]
+                aux = x.coordinate_manager.aux
+                key = ("pair_index", x.tensor_stride, id(part.coordinate_manager), part.tensor_stride)
+                comb = aux.get(key)
+                if comb is None:                      # (kept for the step: the backward's sort by destination is cached on it)
+                    comb = aux[key] = idx * nb + self._batch_index(x)
+                return x * ME._GatherRows.apply(table, comb)
+            hidden = TF.leaky_relu(ME._GatherRows.apply(h_p.float(), idx) + self._per_batch_rows(h_t.float(), x), 0.1)
             return x * _run_mlp(lin2, hidden)
         latent, temp, latemp = (getattr(self, f"latent_{name}"), getattr(self, f"{name}_temp"),
                                 getattr(self, f"latemp_{name}"))

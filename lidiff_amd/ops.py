@@ -999,8 +999,13 @@ class _BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
+        # bf16 training: the layer's output goes into a convolution next -- its bf16 shadow is written by the same launch
+        ctx.shadow = TRAIN_OPERANDS == "bf16" and BF16_ROWS and c % 32 == 0
+        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=dev) if ctx.shadow else None
         call("lidiff_bn_apply", ptr(x), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(b), ptr(residual), int(bool(relu)), ptr(y),
-             stream_ptr())
+             ptr(y16), stream_ptr())
+        if y16 is not None:
+            y._lidiff_bf16 = ((y.data_ptr(), y._version, tuple(y.shape)), y16)
         if running_mean is not None and rm is None:              # running estimates of another dtype: torch's own arithmetic
             with torch.no_grad():
                 cnt = float(m) if count is None else count
@@ -1020,13 +1025,14 @@ class _BatchNormTrain(torch.autograd.Function):
         m, c = x.shape
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if dx is not None and ctx.shadow else None
         dres = None
         if ctx.has_residual and ctx.needs_input_grad[8]:
             dres = torch.empty_like(x) if ctx.relu else dy      # without ReLU the residual's gradient is dy itself
         ws = torch.empty(_lib.load().lidiff_bn_workspace_bytes(c), dtype=torch.uint8, device=x.device)
         if ctx.group is None:
             call("lidiff_bn_bwd", ptr(dy), ptr(x), ptr(y), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(sums[0]), ptr(sums[1]),
-                 ptr(dx), ptr(dres) if ctx.relu else None, ptr(ws), stream_ptr())
+                 ptr(dx), ptr(dres) if ctx.relu else None, ptr(ws), ptr(dx16), stream_ptr())
             local = sums
         else:
             import torch.distributed as tdist
@@ -1035,7 +1041,9 @@ class _BatchNormTrain(torch.autograd.Function):
             local = dsums.float().view(2, c)                     # THIS rank's sums: d beta / d gamma (the gradient all-reduce averages them)
             tdist.all_reduce(dsums, op=tdist.ReduceOp.SUM, group=ctx.group)
             call("lidiff_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(dsums), ptr(count),
-                 ptr(sums[0]), ptr(sums[1]), ptr(dx), ptr(dres) if ctx.relu else None, stream_ptr())
+                 ptr(sums[0]), ptr(sums[1]), ptr(dx), ptr(dres) if ctx.relu else None, ptr(dx16), stream_ptr())
+        if dx16 is not None:         # (the gradient of the convolution in front of this layer: it gathers the shadow)
+            dx._lidiff_bf16 = ((dx.data_ptr(), dx._version, tuple(dx.shape)), dx16)
         dw = local[1] * stats[2] if ctx.has_affine[0] and ctx.needs_input_grad[1] else None
         db = local[0].clone() if ctx.has_affine[1] and ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None, None, None, None, dres, None
@@ -1145,10 +1153,11 @@ class train_operands:
         TRAIN_OPERANDS = self.prev
 
 
-# The bf16 kernel has no packed stages: on low-density maps (the managers' sparse-map hint) the fp32 tile kernel is the
-# faster one (profiles/r02_bf16_conv_sweep.txt), so those layers keep it unless this is set (parity tests set it to pin
-# the whole step to the oracle's every-eligible-layer emulation).
-BF16_SPARSE_MAPS = False
+# The bf16 kernel has no packed stages.  Rounds 2-4: on low-density maps (the managers' sparse-map hint) the fp32 tile kernel was
+# the faster one (profiles/r02_bf16_conv_sweep.txt) and those layers kept it.  Round 5: with bf16 shadow rows, W fragments through
+# LDS and the 16-byte flush the bf16 kernel wins there too in aggregate (training step 120.3 -> 117.9 ms), so EVERY eligible layer
+# runs in bf16 -- which is also what the oracle's emulation of the bf16 step assumes ("0": the former rule).
+BF16_SPARSE_MAPS = os.environ.get("LIDIFF_BF16_SPARSE_MAPS", "1") == "1"
 
 
 def bf16_conv_applies(c_a: int, c_b: int, c_out: int, sparse_map: bool = False) -> bool:

@@ -1181,6 +1181,7 @@ def test_spconv_bf16_training_backward_vs_oracle_autograd(device, kind, ks, stri
     takes_bf16 = ops.bf16_conv_applies(cin, 0, cout)
     prof = ops.ConvProfiler()
     ops.PROFILER = prof
+    sparse_prev = ops.BF16_SPARSE_MAPS
     ops.BF16_SPARSE_MAPS = True                 # this small cloud's maps carry the sparse hint
     try:
         with ops.train_operands("bf16"):
@@ -1189,7 +1190,7 @@ def test_spconv_bf16_training_backward_vs_oracle_autograd(device, kind, ks, stri
             (y.F * r.to(device)).sum().backward()
     finally:
         ops.PROFILER = None
-        ops.BF16_SPARSE_MAPS = False
+        ops.BF16_SPARSE_MAPS = sparse_prev
     assert [v for v, *_ in prof.launches].count("bf16") == (2 if takes_bf16 else 0)
     coarse, _ = me.stride_map(uniq, 2)
     if kind == "tconv":

@@ -45,9 +45,11 @@ def main():
         torch.cuda.synchronize()
     rows = []
     for e in prof.key_averages(group_by_input_shape=True):
-        dt = getattr(e, "self_device_time_total", None)
+        if not e.key.startswith("aten::"):
+            continue
+        dt = getattr(e, "device_time_total", None)          # inclusive: the kernels an operator launched
         if dt is None:
-            dt = e.self_cuda_time_total
+            dt = e.cuda_time_total
         if dt > 0:
             rows.append((dt / 2e3, e.count // 2, e.key, str(e.input_shapes)[:110]))
     rows.sort(reverse=True)

@@ -996,7 +996,9 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
     const int64_t p_lo = IDENT ? 0 : offset_ptr[k], p_hi = IDENT ? m_out : offset_ptr[k + 1];
     const int64_t per = (((p_hi - p_lo + slices - 1) / slices + kDwPairs - 1) / kDwPairs) * kDwPairs;
     const int64_t s_lo = p_lo + (int64_t)blockIdx.z * per, s_hi = min(p_hi, s_lo + per);
-    if (s_lo >= s_hi) return;
+    // (a slice without pairs: nothing to add to dw -- but its tile of the slice workspace is written all the same, with zeros,
+    //  so that the workspace needs no clearing pass: up to 38 slices x 27 x 256 x 256 floats = 269 MB per 256-channel layer)
+    if (s_lo >= s_hi && part == nullptr) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
     for (int b = 0; b < NBI; ++b)
 #pragma unroll
         for (int c = 0; c < CB; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    fetch(s_lo);
+    if (s_lo < s_hi) fetch(s_lo);
     for (int64_t base = s_lo; base < s_hi; base += kDwPairs) {
         __syncthreads();                                  // the previous chunk has been multiplied
         stash();
@@ -1132,7 +1134,6 @@ static int launch_bwd_w(const float* in_a, int c_in_a, const float* in_b, int c_
     const int64_t slices = dw_slices(c_in, c_out, k_vol, n_pairs, CIT, COT);
     const int64_t n = (int64_t)k_vol * c_in * c_out;
     float* part = (workspace != nullptr && slices > 1) ? workspace : nullptr;
-    if (part) LIDIFF_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)slices * n * sizeof(float), st));
     hipLaunchKernelGGL(kern, dim3((unsigned)k_vol, (unsigned)tiles, (unsigned)slices), dim3(512), lds, st, in_a, c_in_a,
                        in_b, c_in_b, g, pin, pout, off, m_out, c_out, (int)slices, dw, part, k_vol);
     if (part) dw_reduce_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(part, n, (int)slices, dw);

@@ -1110,8 +1110,11 @@ __global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n, int 
 
 int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot) {
     const int tiles = (int)(ceil_div(c_in, cit) * ceil_div(c_out, cot));
-    // pair slices: a few workgroups per CU, but at least 4 chunks each (pairs spread evenly over the offsets)
-    int64_t slices = ceil_div((int64_t)1024, (int64_t)tiles * k_vol);
+    // pair slices: several workgroups per CU slot -- the offsets' pair counts differ widely (the centre offset holds every row), so
+    // many short slices balance better than few long ones: 2 048 workgroups measured best on the bf16 step (1 024: 104.7 ms,
+    // 2 048: 102.0-103.1, 4 096: 103.4, 8 192: 107.1; LIDIFF_DW_TARGET) -- but at least 4 chunks each
+    static const int64_t target = [] { const char* e = getenv("LIDIFF_DW_TARGET"); return e ? (int64_t)atoi(e) : (int64_t)2048; }();
+    int64_t slices = ceil_div(target, (int64_t)tiles * k_vol);
     const int64_t max_slices = max((int64_t)1, n_pairs / k_vol / (4 * kDwPairs));
     return max((int64_t)1, min(slices, max_slices));
 }

@@ -272,7 +272,8 @@ int lidiff_spconv_fwd_pairs(const float* in_a, int32_t c_in_a, const float* in_b
  *               sum |x w|: 2.5e-7 / 1.3e-7 against 1.1e-7 of the native fp32 MFMA).
  * Input widths and c_out multiples of 32; same map / epilogue / replica arguments as lidiff_spconv_fwd (no row order, no
  * tail).
- * in_bf16 (planes = 1 only): in_a / in_b point at bf16 rows -- the shadow copy of the fp32 feature matrix that its producer or
+ * in_bf16 != 0 (planes = 1 only; 1 = the library picks the kernel, 2 / 3 force the ring / the two-stage kernel -- bit-identical,
+ * for A/B measurements and tests): in_a / in_b point at bf16 rows -- the shadow copy of the fp32 feature matrix that its producer or
  * lidiff_cast_bf16 left (bf16 activations in HBM, the bf16 training configuration): half the gather traffic and requests, no
  * conversion in the kernel; the same operands, products and order of sums, i.e. bit-identical to in_bf16 = 0 on the fp32 rows.
  * lidiff_cast_bf16: n fp32 values -> n bf16 values, round to nearest even. */

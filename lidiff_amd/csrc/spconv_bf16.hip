@@ -419,8 +419,295 @@ static int dispatch_bf16(const ConvParams& p, bool ks64, hipStream_t st) {
 #undef LIDIFF_BF16
 }
 
+
+// ---------------------------------------------------------------------------------------
+// bf16 rows, a RING of stages (round 5).  The kernel above issues a stage's requests one stage ahead and waits for all of them at
+// the stage's barrier; with bf16 rows a stage is shorter than a memory latency, so every stage waits for its own data (ablations:
+// requests, flush and barrier removed, 414 of 739 us remain on 256 -> 256).  Here a stage is 32 channels (8 KB of rows + the
+// [BN / 16] KB of W fragments), four of them live in LDS at once -- the same 64 KB as two 64-channel stages -- and the requests of
+// stage s + 3 are issued while stage s is multiplied: the barrier of a stage waits only until the two newest stages' requests are
+// the ones still in flight (s_waitcnt vmcnt(2 x requests per stage): every wave issues the same number of requests per stage, the
+// surplus ones of narrow tiles repeat a block).  The LDS-DMA is issued from inline asm: the compiler does not see LDS being written
+// behind its back, so it does not put a full `s_waitcnt vmcnt(0)` in front of every LDS read while requests are in flight (which
+// is what it does for the builtin, and what the counted waits of the kernel above work around) -- ordering is by the stage
+// barriers alone.  Same pairs, products and order of sums per accumulator as the kernel above: bit-identical results.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma16_to_lds(const i32x4 rsrc, const unsigned lds_addr, const int voff, const int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <int BM, int WC, int WR>
+__global__ __launch_bounds__(64 * WC * WR) void spconv_fwd_bf16_ring_kernel(const ConvParams p_launch) {
+    constexpr int KS = 32, R = 4, D = 3;                    // channels per stage, stages in LDS, stages the requests run ahead
+    constexpr int BN = 32 * WC, NW = WC * WR, NT = 64 * NW, RB = BM / 16 / WR;
+    constexpr int ABYTES = BM * KS * 2;                     // rows of a stage: 64 bytes each
+    constexpr int NCHK = 4, RPI = 16, NINST = BM / RPI, T = (NINST + NW - 1) / NW;
+    constexpr int WBLK = BN / 16, WBYTES = WBLK * 1024, TW = (WBLK + NW - 1) / NW;
+    constexpr int PER_STAGE = T + TW;                       // requests per wave and stage
+    static_assert((D - 1) * PER_STAGE <= 63, "vmcnt range");
+    constexpr int TCH = BN / 4;
+    constexpr int TSWZ = (TCH % 16 == 0) ? 16 : (TCH % 8 == 0) ? 8 : (TCH % 4 == 0) ? 4 : 2;
+    ConvParams p = p_launch;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_ring = smem;
+    char* w_ring = smem + R * ABYTES;
+    float* acc_lds = reinterpret_cast<float*>(smem + R * (ABYTES + WBYTES));
+    int32_t* in_list = reinterpret_cast<int32_t*>(acc_lds + (BM + 1) * BN);
+    int32_t* out_list = in_list + p.k_vol * BM;
+    int32_t* cnt = out_list + p.k_vol * BM;
+    int32_t* orow = cnt + 32;
+    int32_t* act = orow + BM;                               // the offsets that have pairs, ascending; act[31] = how many
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, g = bid >> 3;
+    const int tn = g % p.tiles_n;
+    const int tmr = (g / p.tiles_n) * 8 + xcd;
+    if (tmr >= p.tiles_m * p.replicas) return;
+    const int rep = tmr / p.tiles_m, tm = tmr - rep * p.tiles_m;
+    p.in_a = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in_a) + (int64_t)rep * p.m_in * p.c_in_a * 2);
+    if (p.in_b) p.in_b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in_b) + (int64_t)rep * p.m_in * p.c_in_b * 2);
+    p.out += (int64_t)rep * p.m_out * p.c_out;
+    if (p.residual) p.residual += (int64_t)rep * p.m_out * p.c_out;
+    const int64_t row0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave % WC, wr = wave / WC;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // ---- pair lists (as the kernel above) -------------------------------------------------------------------
+    for (int e = tid; e < (BM + 1) * BN / 4; e += NT) reinterpret_cast<float4*>(acc_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = tid; r < rows_here; r += NT) orow[r] = (int32_t)(row0 + r);
+    if (p.nbr == nullptr) {
+        for (int r = tid; r < BM; r += NT) {
+            in_list[r] = (int32_t)min(row0 + r, p.m_out - 1);
+            out_list[r] = r < rows_here ? r * BN : BM * BN;
+        }
+        if (tid == 0) cnt[0] = rows_here;
+    } else {
+        int32_t* raw = reinterpret_cast<int32_t*>(a_ring);
+        static_assert(27 * BM * 4 <= R * (ABYTES + WBYTES), "raw neighbour block must fit in the rings");
+        for (int e = tid; e < p.k_vol * BM; e += NT) {
+            const int k = e / BM, r = e % BM;
+            raw[e] = r < rows_here ? p.nbr[(int64_t)k * p.m_out + row0 + r] : -1;
+        }
+        __syncthreads();
+        for (int k = wave; k < p.k_vol; k += NW) {
+            int pos = 0;
+#pragma unroll
+            for (int c = 0; c < BM; c += 64) {
+                const int r = c + lane;
+                const int v = raw[k * BM + r];
+                const bool valid = v >= 0;
+                const unsigned long long m = __ballot(valid);
+                if (valid) {
+                    const int q = pos + popc_below(m);
+                    in_list[k * BM + q] = v;
+                    out_list[k * BM + q] = r * BN;
+                }
+                pos += __popcll(m);
+            }
+#pragma unroll
+            for (int c = 0; c < BM; c += 64)
+                if (c + lane >= pos) out_list[k * BM + c + lane] = BM * BN;      // dummy row
+            if (lane == 0) cnt[k] = pos;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                                        // the active offsets, in order
+        const bool on = lane < p.k_vol && cnt[lane] > 0;
+        const unsigned long long m = __ballot(on);
+        if (on) act[popc_below(m)] = lane;
+        if (lane == 0) act[31] = __popcll(m);
+    }
+    __syncthreads();
+    const int nact = __builtin_amdgcn_readfirstlane(act[31]);
+    const int nslab = (p.c_in + KS - 1) / KS;
+    const int nst = nact * nslab;                           // stages of this tile
+    const int nt16 = p.c_out >> 4;
+    const int w_slab_bytes = nt16 * 1024;
+    // raw buffer descriptors (base, stride 0, bytes, the flags __builtin_amdgcn_make_buffer_rsrc is given elsewhere), wave-uniform
+    auto rsrc = [](const void* base, int64_t bytes) {
+        const uint64_t a = (uint64_t)(uintptr_t)base;
+        i32x4 d = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_readfirstlane(d[i]);
+        return d;
+    };
+    const i32x4 rsrc_w = rsrc(p.wp, (int64_t)p.k_vol * nslab * w_slab_bytes);
+    const i32x4 rsrc_a = rsrc(p.in_a, p.m_in * p.c_in_a * 2);
+    const i32x4 rsrc_b = p.in_b ? rsrc(p.in_b, p.m_in * p.c_in_b * 2) : rsrc_a;
+    auto swz = [](int r) { return (r >> 2) & 3; };          // four 64-byte rows per 256 bytes of banks
+    int tblk[T], chb[T];                                    // this lane's row block / chunk of every request (surplus ones repeat)
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        tblk[j] = (wave + NW * j) % NINST;
+        const int r = RPI * tblk[j] + lane / NCHK;
+        chb[j] = 16 * ((lane % NCHK) ^ swz(r));
+    }
+    const int foff = li * (KS * 2) + 16 * (lq ^ swz(li));   // this lane's 16-byte chunk (channels 8 lq .. + 7 of image row li)
+    const unsigned a_base = (unsigned)(uintptr_t)(lds_ptr_t)a_ring, w_base = (unsigned)(uintptr_t)(lds_ptr_t)w_ring;
+
+    // requests of stage `sg` = (offset act[i_oi], slab i_slab) into ring slot sg mod R; stages behind the last one request nothing
+    // real (rows out of range: zero fill) so that every stage has the same number of requests
+    int i_oi = 0, i_slab = 0;
+    auto issue = [&](int sg) {
+        const bool live = sg < nst;
+        const int k = live ? act[i_oi] : 0;
+        const int n = live ? cnt[k] : 0;
+        const int slab = live ? i_slab : 0;
+        const int slot = sg & (R - 1);
+        const int ws = (k * nslab + slab) * w_slab_bytes;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int b = (wave + NW * j) % WBLK;
+            dma16_to_lds(rsrc_w, w_base + slot * WBYTES + b * 1024, (((n0 >> 4) + b) * 64 + lane) * 16, ws);
+        }
+        const int k0 = slab * KS;
+        const bool from_a = k0 < p.c_in_a;
+        const int cw = (from_a ? p.c_in_a : p.c_in_b) * 2;
+        const int cb = (from_a ? k0 : k0 - p.c_in_a) * 2;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int r = RPI * tblk[j] + lane / NCHK;
+            const int row = r < n ? in_list[k * BM + r] : -1;
+            const int voff = row >= 0 ? row * cw + chb[j] : (int)0x80000000;          // out of range -> zero fill
+            dma16_to_lds(from_a ? rsrc_a : rsrc_b, a_base + slot * ABYTES + tblk[j] * 1024, voff, cb);
+        }
+        if (++i_slab == nslab) { i_slab = 0; ++i_oi; }
+    };
+    // all requests of stage sg + 1 have landed (for every wave) and are visible; the slot of stage sg is free again
+#define LIDIFF_RING_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((D - 1) * PER_STAGE) : "memory")
+
+    int sg = 0;                                             // the stage being multiplied
+    for (int s = 0; s < D; ++s) issue(s);
+    LIDIFF_RING_BARRIER();
+
+    auto run_offset = [&](auto nj_tag, int k_cur) {
+        constexpr int NJ = decltype(nj_tag)::value;
+        f32x4 acc[NJ > 0 ? NJ : 1][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int slab = 0; slab < nslab; ++slab, ++sg) {
+            const int slot = sg & (R - 1);
+            const char* wsrc = w_ring + slot * WBYTES + lane * 16;
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wsrc + (2 * wc) * 1024);
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wsrc + (2 * wc + 1) * 1024);
+            issue(sg + D);
+            const char* asrc = a_ring + slot * ABYTES + foff;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(asrc + (wr + WR * j) * (16 * KS * 2));
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a, acc[j][0], 0, 0, 0);     // operands swapped: see the flush
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a, acc[j][1], 0, 0, 0);
+            }
+            LIDIFF_RING_BARRIER();
+        }
+        // flush: one 16-byte read-modify-write of the bank-swizzled tile per (block, column block), as the kernel above
+        const int32_t* ol = out_list + k_cur * BM + li;
+        int addr[NJ > 0 ? NJ : 1][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int o = ol[16 * (wr + WR * j)];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) addr[j][cb] = o + 4 * ((8 * wc + 4 * cb + lq) ^ ((o / BN) & (TSWZ - 1)));
+        }
+        f32x4 old[NJ > 0 ? NJ : 1][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) old[j][cb] = *reinterpret_cast<const f32x4*>(acc_lds + addr[j][cb]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4*>(acc_lds + addr[j][cb]) = old[j][cb] + acc[j][cb];
+    };
+
+    for (int oi = 0; oi < nact; ++oi) {
+        const int k_cur = act[oi];
+        const int nb = (cnt[k_cur] + 15) >> 4;
+        const int nj = nb > wr ? (nb - wr + WR - 1) / WR : 0;          // this wave's active row blocks: wr + WR j < nb
+        if (RB >= 8 && nj > 4) {
+            if (nj == 8) run_offset(ic<(RB >= 8 ? 8 : 0)>{}, k_cur);
+            else if (nj == 7) run_offset(ic<(RB >= 8 ? 7 : 0)>{}, k_cur);
+            else if (nj == 6) run_offset(ic<(RB >= 8 ? 6 : 0)>{}, k_cur);
+            else run_offset(ic<(RB >= 8 ? 5 : 0)>{}, k_cur);
+        }
+        else if (RB >= 4 && nj == 4) run_offset(ic<(RB >= 4 ? 4 : 0)>{}, k_cur);
+        else if (RB >= 4 && nj == 3) run_offset(ic<(RB >= 4 ? 3 : 0)>{}, k_cur);
+        else if (RB >= 2 && nj == 2) run_offset(ic<(RB >= 2 ? 2 : 0)>{}, k_cur);
+        else if (nj == 1) run_offset(ic<1>{}, k_cur);
+        else run_offset(ic<0>{}, k_cur);
+    }
+#undef LIDIFF_RING_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus requests of the last stages
+    __syncthreads();                                       // ... and the last flush
+
+    // ---- epilogue (as the kernel above) --------------------------------------------------------------------------
+    for (int e = tid; e < rows_here * (BN / 4); e += NT) {
+        const int r = e / (BN / 4), cq = e % (BN / 4);
+        const int col = n0 + 4 * cq;
+        float4 v = reinterpret_cast<const float4*>(acc_lds)[r * (BN / 4) + (cq ^ (r & (TSWZ - 1)))];
+        if (p.scale) {
+            const float4 s = *reinterpret_cast<const float4*>(p.scale + col);
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+        }
+        if (p.shift) {
+            const float4 s = *reinterpret_cast<const float4*>(p.shift + col);
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        const int64_t o = (int64_t)orow[r] * p.c_out + col;
+        if (p.residual) {
+            const float4 s = *reinterpret_cast<const float4*>(p.residual + o);
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        if (p.relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(p.out + o) = v;
+    }
+}
+
+template <int BM, int WC, int WR>
+static int launch_bf16_ring(const ConvParams& p, hipStream_t st) {
+    constexpr int BN = 32 * WC;
+    const size_t lds = (size_t)4 * (BM * 32 * 2 + (BN / 16) * 1024) + (size_t)(BM + 1) * BN * 4 + (size_t)p.k_vol * BM * 8 +
+                       32 * 4 + BM * 4 + 32 * 4;
+    auto kern = spconv_fwd_bf16_ring_kernel<BM, WC, WR>;
+    static thread_local size_t configured = 0;
+    if (lds > configured) {
+        LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    ConvParams q = p;
+    q.tiles_m = (int)ceil_div(p.m_out, BM);
+    q.tiles_n = p.c_out / BN;
+    const unsigned grid = (unsigned)(ceil_div((int64_t)q.tiles_m * q.replicas, 8) * 8 * q.tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WC * WR), lds, st, q);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
 // bf16 feature rows (planes = 1): the same tiles and stages
-static int dispatch_bf16_rows(const ConvParams& p, bool ks64, hipStream_t st) {
+static int dispatch_bf16_rows(const ConvParams& p, bool ks64, int mode, hipStream_t st) {
+    // measured (tools/conv_probe.py --kernel bf16 --rows16, bench scan at sigma 1; us two-stage -> ring): 256 -> 256 at stride 8
+    // 744 -> 770, at stride 16 295 -> 326, 384 -> 256 990 -> 1054, 128 -> 128 at stride 8 241 -> 253, at stride 4 307 -> 300,
+    // 64 -> 64 183 -> 184, 96 -> 96 at stride 2 302 -> 247: both kernels move the same 6.3 GB per 256 -> 256 launch between L2 and
+    // the CUs (8.4 TB/s: half of it W fragments, re-read by every tile), which is what bounds them once the latency is hidden --
+    // the ring wins where stages are nearly empty (few pairs per offset, 32-channel slabs anyway): the 96-column tiles take it
+    // (LIDIFF_BF16_RING = 1: every tile width, 0: none)
+    static const int ring_default = [] { const char* e = getenv("LIDIFF_BF16_RING"); return e ? atoi(e) : -1; }();
+    const bool ring = mode == 2 || (mode == 1 && (ring_default > 0 || (ring_default < 0 && p.c_out % 128 != 0 && p.c_out % 96 == 0)));
+    // (in_bf16: 1 = this rule, 2 = ring, 3 = two stages)
+    if (ring) {
+        if (p.c_out % 128 == 0) return launch_bf16_ring<128, 4, 2>(p, st);
+        if (p.c_out % 96 == 0) return launch_bf16_ring<128, 3, 2>(p, st);
+        if (p.c_out % 64 == 0) return launch_bf16_ring<128, 2, 4>(p, st);
+        return launch_bf16_ring<128, 1, 8>(p, st);
+    }
 #define LIDIFF_BF16(BM, WC, WR) \
     return ks64 ? launch_bf16<BM, WC, WR, 64, 1, true>(p, st) : launch_bf16<BM, WC, WR, 32, 1, true>(p, st)
     if (p.c_out % 128 == 0) LIDIFF_BF16(128, 4, 2);
@@ -715,7 +1002,7 @@ extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const f
                                       int32_t c_out, float* out, const float* ep_scale, const float* ep_shift,
                                       const float* residual, int32_t relu, int32_t replicas, int32_t in_bf16, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && w_packed != nullptr && out != nullptr, "null pointer");
-    LIDIFF_CHECK_ARG(!in_bf16 || planes == 1, "bf16 feature rows: planes must be 1");
+    LIDIFF_CHECK_ARG(in_bf16 >= 0 && in_bf16 <= 3 && (!in_bf16 || planes == 1), "bf16 feature rows: in_bf16 in 0..3, planes must be 1");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(planes >= 1 && planes <= 3, "planes must be 1, 2 or 3");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
@@ -750,7 +1037,7 @@ extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const f
     p.probe = probe;
     hipStream_t st = (hipStream_t)stream;
     const bool ks64 = c_in_a % 64 == 0 && c_in_b % 64 == 0;
-    if (in_bf16) return dispatch_bf16_rows(p, ks64, st);
+    if (in_bf16) return dispatch_bf16_rows(p, ks64, in_bf16, st);
     if (planes == 1) return dispatch_bf16<1>(p, ks64, st);
     if (planes == 2) return dispatch_bf16<2>(p, ks64, st);
     return dispatch_bf16<3>(p, ks64, st);

@@ -1194,6 +1194,9 @@ def packed_weights_bf16(w: torch.Tensor, transposed: bool = False, flip: bool = 
 BF16_ROWS = os.environ.get("LIDIFF_BF16_ROWS", "1") != "0"
 
 
+BF16_ROWS_KERNEL = {None: 1, "ring": 2, "two_stage": 3}
+
+
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     """bf16 shadow of a contiguous fp32 matrix (round to nearest even, lidiff_cast_bf16), kept on the tensor object: the layers
     that read the same tensor (a block's first convolution and its shortcut; a convolution's forward and its weight gradient)
@@ -1214,8 +1217,10 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
 
 def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int,
                     in_b: torch.Tensor | None = None, scale=None, shift=None, residual=None, relu: bool = False,
-                    replicas: int = 1, transposed: bool = False, flip: bool = False, planes: int = 1) -> torch.Tensor:
+                    replicas: int = 1, transposed: bool = False, flip: bool = False, planes: int = 1,
+                    kernel: str | None = None) -> torch.Tensor:
     """spconv_fwd with bf16 matrix operands and fp32 accumulation (lidiff_spconv_fwd_bf16; include/lidiff_amd.h).
+    kernel (bf16 rows only): "ring" / "two_stage" force one of the two bit-identical kernels (default: the library's choice).
     planes = 1: operands rounded to bf16 (mixed-precision training); planes = 2 / 3: every operand cut into 2 / 3 bf16
     pieces, 3 / 6 MFMAs per block, fp32-accurate results.
     transposed: convolve with w[::-1 if flip].transpose(1, 2) -- the input gradient over the swapped map."""
@@ -1250,7 +1255,8 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
         _lib.join_pending()             # (the wait for maps still being built on a side stream is not the kernel's time)
         start.record()
     call("lidiff_spconv_fwd_bf16", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), int(planes), ptr(nbr), k, m_in, m_out, c_out,
-         ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), int(rows16), stream_ptr())
+         ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas),
+         (BF16_ROWS_KERNEL.get(kernel, 1) if rows16 else 0), stream_ptr())
     if timed:
         end.record()
     if prof is not None:

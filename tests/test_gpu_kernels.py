@@ -1274,15 +1274,16 @@ def test_spconv_bf16_from_shadow_rows_is_bit_identical(device, cin, split, cout,
     kw = dict(scale=(torch.rand(cout, generator=g) + 0.5).to(device), shift=torch.randn(cout, generator=g).to(device),
               residual=torch.randn(reps * m_out, cout, generator=g).to(device), relu=True, replicas=reps)
     ref = ops.spconv_fwd_bf16(xa, w, nbr, m_out, in_b=xb, **kw)
-    got = ops.spconv_fwd_bf16(a16, w, nbr, m_out, in_b=b16, **kw)
-    assert torch.equal(got, ref), (got - ref).abs().max().item()
+    for kern in ("two_stage", "ring", None):           # the two kernels for bf16 rows, and the library's own choice between them
+        got = ops.spconv_fwd_bf16(a16, w, nbr, m_out, in_b=b16, kernel=kern, **kw)
+        assert torch.equal(got, ref), (kern, (got - ref).abs().max().item())
     if not split and kind != "down":
         # the input gradient's form: the transposed kernel over the (here: the same, flipped) map; and the weight gradient
         gr = torch.randn(m_out, cout, generator=g).to(device)
         flip = kind == "k3"
         ref_x = ops.spconv_fwd_bf16(gr, w, nbr, m_in, transposed=True, flip=flip)
-        got_x = ops.spconv_fwd_bf16(ops.cast_bf16(gr), w, nbr, m_in, transposed=True, flip=flip)
-        assert torch.equal(got_x, ref_x)
+        for kern in ("two_stage", "ring"):
+            assert torch.equal(ops.spconv_fwd_bf16(ops.cast_bf16(gr), w, nbr, m_in, transposed=True, flip=flip, kernel=kern), ref_x)
         x1 = x[:m_in].contiguous()
         ref_w = ops.spconv_bwd_w(x1, gr, nbr, k, bf16=True)
         got_w = ops.spconv_bwd_w(ops.cast_bf16(x1), ops.cast_bf16(gr), nbr, k, bf16=True)

@@ -691,6 +691,195 @@ static int launch_bf16_ring(const ConvParams& p, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// bf16 rows, WIDE tiles with the accumulators in registers (round 5).  The two kernels above move 6.3 GB between the caches and
+// the CUs per 256 -> 256 launch (8.4 TB/s: every 128 x 128 tile re-reads all of W and gathers its rows once per column tile) -- that
+// traffic, not the matrix pipe (busy ~15 %), bounds them, and their tile cannot grow: its accumulators live in LDS because a pair
+// list scatters an offset's products over the tile's rows.  With bf16 the MFMAs are cheap enough to drop the pair lists instead: a
+// tile multiplies ALL of its rows for every offset -- rows without a neighbour are gathered as zeros (an out-of-range request
+// moves no bytes) -- so every product lands in a fixed accumulator and the accumulators can stay in registers: a 256-row x
+// BN-column tile (BN = 256 or 128) in 8 waves, wave (rg, cg) = 128 rows x BN / 4 columns = 8 x BN / 64 MFMA blocks.  Bytes per
+// output element fall by half (W once per 256 rows, rows once per 256 / 128 columns); no accumulator tile, no pair lists, no flush
+// in LDS -- only the ring of four 32-channel stages (rows 16 KB + W fragments BN / 16 KB each) and the tile's block of the
+// neighbour table.  One fp32 sum per output over all offsets and channels (the kernels above sum per offset first): equal up to
+// the order of the fp32 additions.
+template <int BN>
+__global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvParams p_launch) {
+    constexpr int BM = 256, KS = 32, R = 4, D = 3, NW = 8, NT = 512;
+    constexpr int CBW = BN / 64;                            // column blocks per wave
+    constexpr int ABYTES = BM * KS * 2;                     // 16 KB
+    constexpr int NCHK = 4, RPI = 16, NINST = BM / RPI, T = NINST / NW;          // 2 row requests per wave and stage
+    constexpr int WBLK = BN / 16, WBYTES = WBLK * 1024, TW = WBLK / NW;          // 2 (BN = 256) or 1 W requests
+    constexpr int PER_STAGE = T + TW;
+    static_assert(BN == 256 || BN == 128, "BN");
+    ConvParams p = p_launch;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_ring = smem;
+    char* w_ring = smem + R * ABYTES;
+    int32_t* raw = reinterpret_cast<int32_t*>(smem + R * (ABYTES + WBYTES));       // [k_vol][BM] of the neighbour table
+    int32_t* act = raw + p.k_vol * BM;                                           // offsets with a neighbour in the tile; act[31] = count
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, g = bid >> 3;
+    const int tn = g % p.tiles_n;
+    const int tmr = (g / p.tiles_n) * 8 + xcd;
+    if (tmr >= p.tiles_m * p.replicas) return;
+    const int rep = tmr / p.tiles_m, tm = tmr - rep * p.tiles_m;
+    p.in_a = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in_a) + (int64_t)rep * p.m_in * p.c_in_a * 2);
+    if (p.in_b) p.in_b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in_b) + (int64_t)rep * p.m_in * p.c_in_b * 2);
+    p.out += (int64_t)rep * p.m_out * p.c_out;
+    if (p.residual) p.residual += (int64_t)rep * p.m_out * p.c_out;
+    const int64_t row0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave >> 2, cg = wave & 3;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // ---- the tile's block of the neighbour table; which offsets occur ---------------------------------------------
+    if (tid < 32) act[tid] = 0;
+    __syncthreads();
+    for (int k = wave; k < p.k_vol; k += NW) {
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < BM; c += 64) {
+            const int r = c + lane;
+            int v = -1;
+            if (r < rows_here) v = p.nbr ? p.nbr[(int64_t)k * p.m_out + row0 + r] : (int32_t)(row0 + r);
+            raw[k * BM + r] = v;
+            any |= v >= 0;
+        }
+        if (__ballot(any) != 0ull && lane == 0) act[k] = 1;          // (flags first, compacted below)
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool on = lane < p.k_vol && act[lane] != 0;
+        const unsigned long long m = __ballot(on);          // (one wave, in lockstep: every flag is read before any is overwritten)
+        if (on) act[popc_below(m)] = lane;
+        if (lane == 0) act[31] = __popcll(m);
+    }
+    __syncthreads();
+    const int nact = __builtin_amdgcn_readfirstlane(act[31]);
+    const int nslab = (p.c_in + KS - 1) / KS;
+    const int nst = nact * nslab;
+    const int nt16 = p.c_out >> 4;
+    const int w_slab_bytes = nt16 * 1024;
+    auto rsrc = [](const void* base, int64_t bytes) {
+        const uint64_t a = (uint64_t)(uintptr_t)base;
+        i32x4 d = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_readfirstlane(d[i]);
+        return d;
+    };
+    const i32x4 rsrc_w = rsrc(p.wp, (int64_t)p.k_vol * nslab * w_slab_bytes);
+    const i32x4 rsrc_a = rsrc(p.in_a, p.m_in * p.c_in_a * 2);
+    const i32x4 rsrc_b = p.in_b ? rsrc(p.in_b, p.m_in * p.c_in_b * 2) : rsrc_a;
+    auto swz = [](int r) { return (r >> 2) & 3; };
+    int chb[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) chb[j] = 16 * ((lane % NCHK) ^ swz(RPI * (wave + NW * j) + lane / NCHK));
+    const int foff = li * (KS * 2) + 16 * (lq ^ swz(li));
+    const unsigned a_base = (unsigned)(uintptr_t)(lds_ptr_t)a_ring, w_base = (unsigned)(uintptr_t)(lds_ptr_t)w_ring;
+
+    int i_oi = 0, i_slab = 0;
+    auto issue = [&](int sg) {
+        const bool live = sg < nst;
+        const int k = live ? act[i_oi] : 0;
+        const int slab = live ? i_slab : 0;
+        const int slot = sg & (R - 1);
+        const int ws = (k * nslab + slab) * w_slab_bytes;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int b = wave + NW * j;
+            dma16_to_lds(rsrc_w, w_base + slot * WBYTES + b * 1024, (((n0 >> 4) + b) * 64 + lane) * 16, ws);
+        }
+        const int k0 = slab * KS;
+        const bool from_a = k0 < p.c_in_a;
+        const int cw = (from_a ? p.c_in_a : p.c_in_b) * 2;
+        const int cb = (from_a ? k0 : k0 - p.c_in_a) * 2;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int t = wave + NW * j;
+            const int row = live ? raw[k * BM + RPI * t + lane / NCHK] : -1;
+            const int voff = row >= 0 ? row * cw + chb[j] : (int)0x80000000;          // no neighbour: zeros, no bytes moved
+            dma16_to_lds(from_a ? rsrc_a : rsrc_b, a_base + slot * ABYTES + t * 1024, voff, cb);
+        }
+        if (++i_slab == nslab) { i_slab = 0; ++i_oi; }
+    };
+#define LIDIFF_RING_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((D - 1) * PER_STAGE) : "memory")
+
+    f32x4 acc[8][CBW];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < D; ++s) issue(s);
+    LIDIFF_RING_BARRIER();
+    for (int sg = 0; sg < nst; ++sg) {
+        const int slot = sg & (R - 1);
+        const char* wsrc = w_ring + slot * WBYTES + (CBW * cg) * 1024 + lane * 16;
+        const char* asrc = a_ring + slot * ABYTES + (8 * rg) * (16 * KS * 2) + foff;
+        bf16x8 w[CBW], a[8];
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) w[c] = *reinterpret_cast<const bf16x8*>(wsrc + c * 1024);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const bf16x8*>(asrc + j * (16 * KS * 2));
+        issue(sg + D);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < CBW; ++c)
+                acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c], a[j], acc[j][c], 0, 0, 0);     // swapped: 4 channels of one row per lane
+        LIDIFF_RING_BARRIER();
+    }
+#undef LIDIFF_RING_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus requests of the last stages
+
+    // ---- epilogue straight from the registers: lane (li, lq) holds channels n0 + 16 (CBW cg + c) + 4 lq .. + 3 of row 128 rg + 16 j + li
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+        const int col = n0 + 16 * (CBW * cg + c) + 4 * lq;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + col);
+        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + col);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 128 * rg + 16 * j + li;
+            if (r >= rows_here) continue;
+            const int64_t o = (row0 + r) * p.c_out + col;
+            float4 v = make_float4(acc[j][c][0], acc[j][c][1], acc[j][c][2], acc[j][c][3]);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (p.residual) {
+                const float4 s = *reinterpret_cast<const float4*>(p.residual + o);
+                v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+            }
+            if (p.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(p.out + o) = v;
+        }
+    }
+}
+
+template <int BN>
+static int launch_bf16_wide(const ConvParams& p, hipStream_t st) {
+    const size_t lds = (size_t)4 * (256 * 32 * 2 + (BN / 16) * 1024) + (size_t)p.k_vol * 256 * 4 + 32 * 4;
+    auto kern = spconv_fwd_bf16_wide_kernel<BN>;
+    static thread_local size_t configured = 0;
+    if (lds > configured) {
+        LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    ConvParams q = p;
+    q.tiles_m = (int)ceil_div(p.m_out, 256);
+    q.tiles_n = p.c_out / BN;
+    const unsigned grid = (unsigned)(ceil_div((int64_t)q.tiles_m * q.replicas, 8) * 8 * q.tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, q);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
 // bf16 feature rows (planes = 1): the same tiles and stages
 static int dispatch_bf16_rows(const ConvParams& p, bool ks64, int mode, hipStream_t st) {
     // measured (tools/conv_probe.py --kernel bf16 --rows16, bench scan at sigma 1; us two-stage -> ring): 256 -> 256 at stride 8
@@ -701,7 +890,12 @@ static int dispatch_bf16_rows(const ConvParams& p, bool ks64, int mode, hipStrea
     // (LIDIFF_BF16_RING = 1: every tile width, 0: none)
     static const int ring_default = [] { const char* e = getenv("LIDIFF_BF16_RING"); return e ? atoi(e) : -1; }();
     const bool ring = mode == 2 || (mode == 1 && (ring_default > 0 || (ring_default < 0 && p.c_out % 128 != 0 && p.c_out % 96 == 0)));
-    // (in_bf16: 1 = this rule, 2 = ring, 3 = two stages)
+    // (in_bf16: 1 = this rule, 2 = ring, 3 = two stages, 4 = wide register tiles where the width allows)
+    static const int wide_default = [] { const char* e = getenv("LIDIFF_BF16_WIDE"); return e ? atoi(e) : 0; }();
+    if (mode == 4 || (mode == 1 && wide_default)) {
+        if (p.c_out % 256 == 0) return launch_bf16_wide<256>(p, st);
+        if (p.c_out % 128 == 0) return launch_bf16_wide<128>(p, st);
+    }
     if (ring) {
         if (p.c_out % 128 == 0) return launch_bf16_ring<128, 4, 2>(p, st);
         if (p.c_out % 96 == 0) return launch_bf16_ring<128, 3, 2>(p, st);
@@ -1002,7 +1196,7 @@ extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const f
                                       int32_t c_out, float* out, const float* ep_scale, const float* ep_shift,
                                       const float* residual, int32_t relu, int32_t replicas, int32_t in_bf16, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && w_packed != nullptr && out != nullptr, "null pointer");
-    LIDIFF_CHECK_ARG(in_bf16 >= 0 && in_bf16 <= 3 && (!in_bf16 || planes == 1), "bf16 feature rows: in_bf16 in 0..3, planes must be 1");
+    LIDIFF_CHECK_ARG(in_bf16 >= 0 && in_bf16 <= 4 && (!in_bf16 || planes == 1), "bf16 feature rows: in_bf16 in 0..4, planes must be 1");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
     LIDIFF_CHECK_ARG(planes >= 1 && planes <= 3, "planes must be 1, 2 or 3");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");

@@ -121,7 +121,7 @@ def main():
         elif args.kernel == "bf16" and ops.bf16_conv_applies(cin, 0, cout):
             xin = ops.cast_bf16(x) if args.rows16 else x
             conv = lambda: ops.spconv_fwd_bf16(xin, w, nbr, m_out, planes=args.planes, replicas=args.replicas,
-                                               kernel={0: None, 2: "ring", 3: "two_stage"}.get(args.flags))
+                                               kernel={0: None, 2: "ring", 3: "two_stage", 4: "wide"}.get(args.flags))
         else:
             conv = lambda: ops.spconv_fwd(x, w, nbr, m_out, sparse_map=hint, row_order=order, replicas=args.replicas)
         for _ in range(3):

@@ -353,9 +353,14 @@ int lidiff_gather_bias_leaky(const float* src, const int64_t* idx, const float* 
 /* MinkUNetDiff.match_part_to_full -- minkunet.py:403-418 (pykeops argKmin(1)): for every
  * full row the index of the nearest part row by squared L2 over (b*scale, x, y, z), ties to
  * the lowest index. scale = 2 * (*d_max_coord) as in the reference (d_max_coord: device int32,
- * the max over ALL columns of full). */
+ * the max over ALL columns of full).
+ * d_gate (nullable; one device int32 of the caller's): batches of several scans (training, models.py:180-217) -- every row is
+ * first matched against the part rows of its OWN batch element only (part rows grouped by ascending batch index, as a
+ * voxelised batch is); a winner closer than scale^2, the batch term alone of every other element's rows, is final.  A check
+ * kernel sets *d_gate when some row's winner is not (or the part rows are not grouped) and the unrestricted search then runs over
+ * the same idx[]: the same indices as with d_gate == NULL in every case, B-fold less work in the usual one. */
 int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
-                    const int32_t* d_max_coord, int64_t* idx, void* stream);
+                    const int32_t* d_max_coord, int64_t* idx, int32_t* d_gate, void* stream);
 /* The same search for a map whose row count is still on the device (a coordinate pyramid before its one host read,
  * lidiff_map_stride_dev): full has room for m_full_bound rows, the first *d_m_full are valid; d_max_coord [1] is computed here
  * (max over all columns of the valid rows) and idx [m_full_bound] written for the valid rows only.  Lets the five part -> full

@@ -74,7 +74,7 @@ SIGNATURES = {
     "lidiff_segment_sum_workspace_bytes": (_i64, [_i64, _i32]),
     "lidiff_segment_sum_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "lidiff_gather_mul_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
-    "lidiff_nn_match": (_i32, [_p, _i64, _p, _i64, _p, _p, _p]),
+    "lidiff_nn_match": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p]),
     "lidiff_nn_match_dev": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _p]),
     "lidiff_argmin_rows_f32": (_i32, [_p, _i64, _p, _i64, _p, _p]),
     "lidiff_fps_workspace_bytes": (_i64, [_i64]),

@@ -864,8 +864,11 @@ template <bool SPLIT, bool F32IN = false>
 __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full,
                                 const int32_t* __restrict__ part, int64_t m_part, int64_t part_per_split,
                                 const int32_t* __restrict__ d_max_coord, int64_t* __restrict__ idx,
-                                const int32_t* __restrict__ d_m_full = nullptr) {
+                                const int32_t* __restrict__ d_m_full = nullptr, const int32_t* __restrict__ d_gate = nullptr,
+                                int by_batch = 0) {
     __shared__ float4 tile[kMatchTile];
+    __shared__ int seg[4];
+    if (d_gate != nullptr && *d_gate == 0) return;        // the unrestricted pass behind a by-batch one: only when that asked for it
     if (d_m_full != nullptr) {                            // row count still on the device (a pyramid before its host read):
         m_full = *d_m_full;                               // the grid covers the bound, workgroups beyond the count leave at once
         if ((int64_t)blockIdx.x * blockDim.x * kMatchPt >= m_full) return;
@@ -889,8 +892,37 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
         }
         best[q] = INFINITY; best_j[q] = 0;
     }
-    const int64_t lo = SPLIT ? (int64_t)blockIdx.y * part_per_split : 0;
-    const int64_t hi = SPLIT ? min(m_part, lo + part_per_split) : m_part;
+    int64_t lo = SPLIT ? (int64_t)blockIdx.y * part_per_split : 0;
+    int64_t hi = SPLIT ? min(m_part, lo + part_per_split) : m_part;
+    if (by_batch && !F32IN) {
+        // by-batch pass: only the part rows of the batch elements this workgroup's rows belong to (part rows grouped by ascending
+        // batch index: lower / upper bound of the batch column).  Conclusive for a row whose best distance stays below scale^2 --
+        // the batch term alone of any other element's row; lidiff_nn_match checks that (and the grouping) and runs the
+        // unrestricted pass over the same idx[] when it is not.
+        if (threadIdx.x == 0) { seg[0] = INT32_MAX; seg[1] = INT32_MIN; }
+        __syncthreads();
+        int bmin = INT32_MAX, bmax = INT32_MIN;
+#pragma unroll
+        for (int q = 0; q < kMatchPt; ++q) {
+            const int b = reinterpret_cast<const int4*>(full)[min(i0 + (int64_t)q * blockDim.x, m_full - 1)].x;
+            bmin = min(bmin, b); bmax = max(bmax, b);
+        }
+        for (int off = kWave / 2; off > 0; off >>= 1) { bmin = min(bmin, __shfl_down(bmin, off)); bmax = max(bmax, __shfl_down(bmax, off)); }
+        if (lane_id() == 0) { atomicMin(&seg[0], bmin); atomicMax(&seg[1], bmax); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int b0 = seg[0], b1 = seg[1];
+            int64_t a = 0, z = m_part;                    // first row with batch >= b0
+            while (a < z) { const int64_t mid = (a + z) >> 1; if (reinterpret_cast<const int4*>(part)[mid].x < b0) a = mid + 1; else z = mid; }
+            seg[2] = (int)a;
+            z = m_part;                                   // first row with batch > b1
+            while (a < z) { const int64_t mid = (a + z) >> 1; if (reinterpret_cast<const int4*>(part)[mid].x <= b1) a = mid + 1; else z = mid; }
+            seg[3] = (int)a;
+        }
+        __syncthreads();
+        lo = max(lo, (int64_t)seg[2]);
+        hi = min(hi, (int64_t)seg[3]);
+    }
     for (int64_t base = lo; base < hi; base += kMatchTile) {
         const int cnt = (int)min((int64_t)kMatchTile, hi - base);
         __syncthreads();
@@ -924,6 +956,21 @@ __global__ void nn_match_kernel(const int32_t* __restrict__ full, int64_t m_full
             idx[i] = best_j[q];
         }
     }
+}
+
+// behind a by-batch pass: is every row's winner conclusive (distance below scale^2, the batch term of any other element's rows),
+// and are the part rows grouped by ascending batch index at all?  *d_gate = 1 otherwise: the unrestricted pass runs.
+__global__ void nn_match_check_kernel(const int64_t* __restrict__ idx, int64_t m_full, const int32_t* __restrict__ part, int64_t m_part,
+                                      const int32_t* __restrict__ d_max_coord, int32_t* __restrict__ d_gate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float scale = 2.0f * (float)(*d_max_coord);
+    bool bad = false;
+    if (i < m_full) {
+        const unsigned long long v = (unsigned long long)idx[i];
+        bad = v == ~0ull || !(__uint_as_float((unsigned)(v >> 32)) < scale * scale);
+    }
+    if (i + 1 < m_part) bad |= reinterpret_cast<const int4*>(part)[i].x > reinterpret_cast<const int4*>(part)[i + 1].x;
+    if (__ballot(bad) != 0ull && lane_id() == 0) atomicOr(d_gate, 1);
 }
 
 __global__ void nn_match_finish_kernel(int64_t* __restrict__ idx, int64_t m_full, const int32_t* __restrict__ d_m_full = nullptr) {
@@ -1369,10 +1416,27 @@ static void nn_dist_launch(const void* a, int64_t n, const void* b, int64_t m, v
 
 template <bool F32IN>
 static int nn_match_launch(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
-                           const int32_t* d_max_coord, int64_t* idx, hipStream_t st, const int32_t* d_m_full = nullptr) {
+                           const int32_t* d_max_coord, int64_t* idx, hipStream_t st, const int32_t* d_m_full = nullptr,
+                           int32_t* d_gate = nullptr) {
     // (d_m_full: m_full is only a BOUND of the row count, which the kernels read from the device)
     const int64_t blocks = ceil_div(m_full, (int64_t)kBlock * kMatchPt);
     const int64_t splits = min(ceil_div((int64_t)2048, blocks), ceil_div(m_part, (int64_t)kMatchTile));
+    if (d_gate != nullptr && !F32IN && d_m_full == nullptr) {
+        // by batch element first (d_gate: one device word of the caller's): every row against its own element's part rows; then
+        // the unrestricted pass over the same idx[] -- its workgroups leave at once unless the check asked for it
+        const int64_t sp = max((int64_t)1, splits);
+        const int64_t per = ceil_div(ceil_div(m_part, sp), (int64_t)kMatchTile) * kMatchTile;
+        LIDIFF_CHECK_HIP(hipMemsetAsync(idx, 0xff, (size_t)m_full * 8, st));
+        LIDIFF_CHECK_HIP(hipMemsetAsync(d_gate, 0, sizeof(int32_t), st));
+        nn_match_kernel<true, F32IN><<<dim3((unsigned)blocks, (unsigned)sp), kBlock, 0, st>>>(
+            full, m_full, part, m_part, per, d_max_coord, idx, nullptr, nullptr, 1);
+        nn_match_check_kernel<<<(unsigned)ceil_div(max(m_full, m_part), kBlock), kBlock, 0, st>>>(idx, m_full, part, m_part, d_max_coord, d_gate);
+        nn_match_kernel<true, F32IN><<<dim3((unsigned)blocks, (unsigned)sp), kBlock, 0, st>>>(
+            full, m_full, part, m_part, per, d_max_coord, idx, nullptr, d_gate, 0);
+        nn_match_finish_kernel<<<(unsigned)ceil_div(m_full, kBlock), kBlock, 0, st>>>(idx, m_full, nullptr);
+        LIDIFF_CHECK_LAUNCH();
+        return 0;
+    }
     if (splits <= 1) {
         nn_match_kernel<false, F32IN><<<(unsigned)blocks, kBlock, 0, st>>>(full, m_full, part, m_part, 0, d_max_coord, idx, d_m_full);
     } else {
@@ -1746,11 +1810,11 @@ int lidiff_segment_sum_rows(const float* src, const int64_t* order, const int64_
 }
 
 int lidiff_nn_match(const int32_t* full, int64_t m_full, const int32_t* part, int64_t m_part,
-                    const int32_t* d_max_coord, int64_t* idx, void* stream) {
+                    const int32_t* d_max_coord, int64_t* idx, int32_t* d_gate, void* stream) {
     LIDIFF_CHECK_ARG(m_part >= 1, "part tensor has no rows");
     if (m_full == 0) return 0;
     LIDIFF_CHECK_ARG(m_part < (int64_t)1 << 31, "part tensor too large for 32-bit row indices");
-    return nn_match_launch<false>(full, m_full, part, m_part, d_max_coord, idx, (hipStream_t)stream);
+    return nn_match_launch<false>(full, m_full, part, m_part, d_max_coord, idx, (hipStream_t)stream, nullptr, d_gate);
 }
 
 int lidiff_nn_match_dev(const int32_t* full, int64_t m_full_bound, const int32_t* d_m_full, const int32_t* part, int64_t m_part,

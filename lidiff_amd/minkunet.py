@@ -435,7 +435,9 @@ class MinkUNetDiff(_Base):
         # it beats the lattice-shell search of lidiff_nn_match_grid (0.44 vs 1.1 ms at 180k x 5.8k rows)
         x_full.coordinate_manager._acquire(x_full.tensor_stride)
         d_full = x_full.coordinate_manager.count(x_full.tensor_stride)
-        idx = ops.nn_match(x_full.C, x_part.C) if d_full is None else ops.nn_match_dev(x_full.C, d_full, x_part.C)
+        # (training batches hold several scans: every row against its own batch element's part rows first -- the same indices)
+        idx = (ops.nn_match(x_full.C, x_part.C, by_batch=torch.is_grad_enabled()) if d_full is None
+               else ops.nn_match_dev(x_full.C, d_full, x_part.C))
         done = None
         if ahead:                                              # the consumer's stream joins when it first asks (above)
             done = torch.cuda.Event()

@@ -1626,15 +1626,19 @@ def nn_dist(a: torch.Tensor, b: torch.Tensor, grid: bool | None = None, cell: fl
     return d2, idx
 
 
-def nn_match(full_c: torch.Tensor, part_c: torch.Tensor) -> torch.Tensor:
-    """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416): exhaustive scan of the part rows."""
+def nn_match(full_c: torch.Tensor, part_c: torch.Tensor, by_batch: bool = False) -> torch.Tensor:
+    """MinkUNetDiff.match_part_to_full index part (minkunet.py:403-416): exhaustive scan of the part rows.
+    by_batch: batches of several scans -- every row against its own batch element's part rows first, the unrestricted scan only
+    if a check on the device finds a row whose winner that does not settle (lidiff_nn_match d_gate): the same indices."""
     require_device(full_c, part_c)
     full_c = full_c.contiguous()
     part_c = part_c.contiguous()
     assert full_c.dtype == torch.int32 and part_c.dtype == torch.int32
     max_coord = full_c.max().to(torch.int32).reshape(1)
     idx = torch.empty(full_c.shape[0], dtype=torch.int64, device=full_c.device)
-    call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord), ptr(idx), stream_ptr())
+    gate = torch.empty(1, dtype=torch.int32, device=full_c.device) if by_batch else None
+    call("lidiff_nn_match", ptr(full_c), full_c.shape[0], ptr(part_c), part_c.shape[0], ptr(max_coord), ptr(idx), ptr(gate),
+         stream_ptr())
     return idx
 
 

@@ -475,6 +475,24 @@ def test_nn_match(device):
     f = np.array([[0, 0, 0, 0]], np.int32)                             # exact tie -> lowest index
     p = np.array([[0, 2, 0, 0], [0, -2, 0, 0], [0, 0, 2, 0]], np.int32)
     assert ops.nn_match(dev_i32(f, device), dev_i32(p, device)).item() == 0
+    # by batch element first (training batches, lidiff_nn_match d_gate): the same winners -- part rows grouped by batch (a
+    # voxelised batch: the usual case, the restricted pass is final), interleaved batches (the check sees that the rows are not
+    # grouped: the unrestricted pass runs), rows farther from every part row of their own element than the batch term (not
+    # conclusive: unrestricted pass; the winner may sit in ANOTHER element, exactly as pykeops would find it), a batch element
+    # without part rows, three elements
+    def grouped(rows):
+        return rows[np.argsort(rows[:, 0], kind="stable")]
+    cases = [(grouped(random_cloud(70000, 60, 31, batch=2)), grouped(part)),
+             (grouped(random_cloud(70000, 60, 32, batch=3)), grouped(me.voxelize(me.floor_to_stride(random_cloud(4000, 60, 33, batch=3), 8))[0])),
+             (random_cloud(9000, 60, 34, batch=2), part_dup),                                   # not grouped at all
+             (grouped(random_cloud(9000, 60, 35, batch=2)), grouped(part)[grouped(part)[:, 0] == 0])]    # element 1 has no part row
+    far = grouped(random_cloud(3000, 60, 36, batch=2))
+    far[::7, 1] += 4000                                                                          # rows far away from everything
+    cases.append((far, grouped(part)))
+    for fc, pc in cases:
+        got = ops.nn_match(dev_i32(fc, device), dev_i32(pc, device), by_batch=True).cpu().numpy()
+        assert np.array_equal(got, me.argmin_match(fc, pc)), (fc.shape, pc.shape)
+        assert np.array_equal(got, ops.nn_match(dev_i32(fc, device), dev_i32(pc, device)).cpu().numpy())
     # row count on the device (the matches queued inside a pyramid chain, lidiff_nn_match_dev): a buffer sized for a BOUND whose
     # rows beyond the count hold garbage (larger coordinates than any valid row: they must not enter max_coord) -- same winners
     for n_full, n_bound in ((300, 5000), (5000, 5000), (70000, 180000), (1, 64)):

@@ -703,15 +703,17 @@ static int launch_bf16_ring(const ConvParams& p, hipStream_t st) {
 // in LDS -- only the ring of four 32-channel stages (rows 16 KB + W fragments BN / 16 KB each) and the tile's block of the
 // neighbour table.  One fp32 sum per output over all offsets and channels (the kernels above sum per offset first): equal up to
 // the order of the fp32 additions.
-template <int BN>
+// (narrower layers: the 8 waves as RG row groups x 8 / RG column groups -- 96 columns: 4 x 2, a wave 64 rows x 48 columns)
+template <int BN, int RG = 2>
 __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvParams p_launch) {
     constexpr int BM = 256, KS = 32, R = 4, D = 3, NW = 8, NT = 512;
-    constexpr int CBW = BN / 64;                            // column blocks per wave
+    constexpr int CG = NW / RG, RBW = (BM / 16) / RG;       // column groups; row blocks per wave
+    constexpr int CBW = (BN / 16) / CG;                     // column blocks per wave
+    static_assert(CBW * CG * 16 == BN && RBW * RG * 16 == BM, "wave grid");
     constexpr int ABYTES = BM * KS * 2;                     // 16 KB
     constexpr int NCHK = 4, RPI = 16, NINST = BM / RPI, T = NINST / NW;          // 2 row requests per wave and stage
-    constexpr int WBLK = BN / 16, WBYTES = WBLK * 1024, TW = WBLK / NW;          // 2 (BN = 256) or 1 W requests
+    constexpr int WBLK = BN / 16, WBYTES = WBLK * 1024, TW = (WBLK + NW - 1) / NW;   // W requests (surplus ones repeat a block)
     constexpr int PER_STAGE = T + TW;
-    static_assert(BN == 256 || BN == 128, "BN");
     ConvParams p = p_launch;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* a_ring = smem;
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvPar
     const int rows_here = (int)min((int64_t)BM, p.m_out - row0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave >> 2, cg = wave & 3;
+    const int rg = wave / CG, cg = wave % CG;
     const int li = lane & 15, lq = lane >> 4;
 
     // ---- the tile's block of the neighbour table; which offsets occur ---------------------------------------------
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvPar
         const int ws = (k * nslab + slab) * w_slab_bytes;
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
-            const int b = wave + NW * j;
+            const int b = (wave + NW * j) % WBLK;
             dma16_to_lds(rsrc_w, w_base + slot * WBYTES + b * 1024, (((n0 >> 4) + b) * 64 + lane) * 16, ws);
         }
         const int k0 = slab * KS;
@@ -809,9 +811,9 @@ __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvPar
     };
 #define LIDIFF_RING_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((D - 1) * PER_STAGE) : "memory")
 
-    f32x4 acc[8][CBW];
+    f32x4 acc[RBW][CBW];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < RBW; ++j)
 #pragma unroll
         for (int c = 0; c < CBW; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < D; ++s) issue(s);
@@ -819,15 +821,15 @@ __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvPar
     for (int sg = 0; sg < nst; ++sg) {
         const int slot = sg & (R - 1);
         const char* wsrc = w_ring + slot * WBYTES + (CBW * cg) * 1024 + lane * 16;
-        const char* asrc = a_ring + slot * ABYTES + (8 * rg) * (16 * KS * 2) + foff;
-        bf16x8 w[CBW], a[8];
+        const char* asrc = a_ring + slot * ABYTES + (RBW * rg) * (16 * KS * 2) + foff;
+        bf16x8 w[CBW], a[RBW];
 #pragma unroll
         for (int c = 0; c < CBW; ++c) w[c] = *reinterpret_cast<const bf16x8*>(wsrc + c * 1024);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const bf16x8*>(asrc + j * (16 * KS * 2));
+        for (int j = 0; j < RBW; ++j) a[j] = *reinterpret_cast<const bf16x8*>(asrc + j * (16 * KS * 2));
         issue(sg + D);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < RBW; ++j)
 #pragma unroll
             for (int c = 0; c < CBW; ++c)
                 acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c], a[j], acc[j][c], 0, 0, 0);     // swapped: 4 channels of one row per lane
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvPar
 #undef LIDIFF_RING_BARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus requests of the last stages
 
-    // ---- epilogue straight from the registers: lane (li, lq) holds channels n0 + 16 (CBW cg + c) + 4 lq .. + 3 of row 128 rg + 16 j + li
+    // ---- epilogue straight from the registers: lane (li, lq) holds channels n0 + 16 (CBW cg + c) + 4 lq .. + 3 of row 16 (RBW rg + j) + li
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
         const int col = n0 + 16 * (CBW * cg + c) + 4 * lq;
@@ -844,8 +846,8 @@ __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvPar
         if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + col);
         if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + col);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = 128 * rg + 16 * j + li;
+        for (int j = 0; j < RBW; ++j) {
+            const int r = 16 * (RBW * rg + j) + li;
             if (r >= rows_here) continue;
             const int64_t o = (row0 + r) * p.c_out + col;
             float4 v = make_float4(acc[j][c][0], acc[j][c][1], acc[j][c][2], acc[j][c][3]);
@@ -862,10 +864,10 @@ __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvPar
     }
 }
 
-template <int BN>
+template <int BN, int RG = 2>
 static int launch_bf16_wide(const ConvParams& p, hipStream_t st) {
     const size_t lds = (size_t)4 * (256 * 32 * 2 + (BN / 16) * 1024) + (size_t)p.k_vol * 256 * 4 + 32 * 4;
-    auto kern = spconv_fwd_bf16_wide_kernel<BN>;
+    auto kern = spconv_fwd_bf16_wide_kernel<BN, RG>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -895,6 +897,9 @@ static int dispatch_bf16_rows(const ConvParams& p, bool ks64, int mode, hipStrea
     if (mode == 4 || (mode == 1 && wide_default)) {
         if (p.c_out % 256 == 0) return launch_bf16_wide<256>(p, st);
         if (p.c_out % 128 == 0) return launch_bf16_wide<128>(p, st);
+        if (p.c_out % 96 == 0) return launch_bf16_wide<96, 4>(p, st);
+        if (p.c_out % 64 == 0) return launch_bf16_wide<64, 4>(p, st);
+        return launch_bf16_wide<32, 4>(p, st);
     }
     if (ring) {
         if (p.c_out % 128 == 0) return launch_bf16_ring<128, 4, 2>(p, st);

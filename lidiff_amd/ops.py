@@ -1195,9 +1195,10 @@ BF16_ROWS = os.environ.get("LIDIFF_BF16_ROWS", "1") != "0"
 
 
 BF16_ROWS_KERNEL = {None: 1, "ring": 2, "two_stage": 3, "wide": 4}
-# bf16 rows: layers of 128-multiple output width on the wide register-tile kernel (256-row tiles, no pair lists, one fp32 sum per
-# output over all offsets and channels: 256 -> 256 at stride 8 738 -> 378 us); False: the two-stage / ring kernels, whose sums --
-# per offset first -- are bit-identical to the fp32-row form
+# bf16 rows: kernel_size-3 and kernel_size-1 layers on the wide register-tile kernel (256-row tiles, no pair lists, one fp32 sum
+# per output over all offsets and channels: 256 -> 256 at stride 8 738 -> 378 us, 96 -> 96 at stride 2 201 -> 102, 32 -> 64 120 ->
+# 45); the stride-2 maps (8 offsets, 1-2.6 pairs per row: 22 vs 28 us, 55 vs 64) keep the pair-list kernels.  False: the two-stage /
+# ring kernels everywhere, whose sums -- per offset first -- are bit-identical to the fp32-row form
 BF16_WIDE = os.environ.get("LIDIFF_BF16_WIDE", "1") != "0"
 
 
@@ -1260,7 +1261,7 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
         start.record()
     call("lidiff_spconv_fwd_bf16", ptr(in_a), c_a, ptr(in_b), c_b, ptr(wp), int(planes), ptr(nbr), k, m_in, m_out, c_out,
          ptr(out), ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas),
-         ((4 if kernel is None and BF16_WIDE and c_out % 128 == 0 else BF16_ROWS_KERNEL[kernel]) if rows16 else 0), stream_ptr())
+         ((4 if kernel is None and BF16_WIDE and k != 8 else BF16_ROWS_KERNEL[kernel]) if rows16 else 0), stream_ptr())
     if timed:
         end.record()
     if prof is not None:

@@ -15,6 +15,8 @@ CASES=(
  "s4_128_128_k27|--level 2 --cin 128 --cout 128"
  "s4_64_64_k27|--level 2 --cin 64 --cout 64"
  "s1_96_96_k1_rows|--level 0 --cin 96 --cout 96 --kind k1"
+ "s8_256_256_k27_bf16_wide|--level 3 --cin 256 --cout 256 --kernel bf16 --rows16"
+ "s4_128_128_k27_bf16_wide|--level 2 --cin 128 --cout 128 --kernel bf16 --rows16"
 )
 for c in "${CASES[@]}"; do
   tag=${c%%|*}; args=${c#*|}

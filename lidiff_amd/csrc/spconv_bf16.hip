@@ -68,7 +68,10 @@ __global__ __launch_bounds__(64 * WC * WR, BM == 64 ? 2 : 1) void spconv_fwd_bf1
     static_assert(NCHK == 4 || NCHK == 8 || NCHK == 16, "image rows of 64, 128 or 256 bytes");
     // 16-byte chunks of an image row are XOR-permuted by the row so that the 16 rows a quarter wave reads at one channel offset
     // fall into 16 different bank groups (256 bytes of banks = 1, 2 or 4 image rows)
-    auto swz = [](int r) { return NCHK == 16 ? r & 15 : NCHK == 8 ? (r >> 1) & 7 : (r >> 2) & 3; };
+    // (64-byte rows: ds_read_b128 serves lanes {0-3, 12-15, 20-27} -- not 16 consecutive ones -- in one LDS cycle, i.e. rows
+    // {0-3, 12-15} at channel group lq and rows {4-11} at lq + 1: XOR by (r >> 2) & 2 keeps them apart, (r >> 2) & 3 does not
+    // -- SQ_LDS_BANK_CONFLICT 37 % of the LDS cycles of the wide kernel with the latter)
+    auto swz = [](int r) { return NCHK == 16 ? r & 15 : NCHK == 8 ? (r >> 1) & 7 : (r >> 2) & 2; };
     constexpr int NS = KS / 32;                  // 32-channel steps per stage
     // ABF: the stage's W fragments ([NS steps][BN / 16 column blocks] of 1 KB) come through LDS by DMA as well, ONE copy per
     // workgroup -- each of the WR row groups loaded its own copy into registers before: 16 instead of 32 vector-memory requests
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(64 * WC * WR) void spconv_fwd_bf16_ring_kernel(cons
     const i32x4 rsrc_w = rsrc(p.wp, (int64_t)p.k_vol * nslab * w_slab_bytes);
     const i32x4 rsrc_a = rsrc(p.in_a, p.m_in * p.c_in_a * 2);
     const i32x4 rsrc_b = p.in_b ? rsrc(p.in_b, p.m_in * p.c_in_b * 2) : rsrc_a;
-    auto swz = [](int r) { return (r >> 2) & 3; };          // four 64-byte rows per 256 bytes of banks
+    auto swz = [](int r) { return (r >> 2) & 2; };          // four 64-byte rows per 256 bytes of banks; see the kernel above
     int tblk[T], chb[T];                                    // this lane's row block / chunk of every request (surplus ones repeat)
 #pragma unroll
     for (int j = 0; j < T; ++j) {
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_bf16_wide_kernel(const ConvPar
     const i32x4 rsrc_w = rsrc(p.wp, (int64_t)p.k_vol * nslab * w_slab_bytes);
     const i32x4 rsrc_a = rsrc(p.in_a, p.m_in * p.c_in_a * 2);
     const i32x4 rsrc_b = p.in_b ? rsrc(p.in_b, p.m_in * p.c_in_b * 2) : rsrc_a;
-    auto swz = [](int r) { return (r >> 2) & 3; };
+    auto swz = [](int r) { return (r >> 2) & 2; };          // (ds_read_b128's lane groups: see spconv_fwd_bf16_kernel)
     int chb[T];
 #pragma unroll
     for (int j = 0; j < T; ++j) chb[j] = 16 * ((lane % NCHK) ^ swz(RPI * (wave + NW * j) + lane / NCHK));

@@ -111,7 +111,8 @@ class DiffusionPoints(nn.Module):
         with torch.cuda.stream(side), torch.no_grad():
             part = ME.SparseTensor(empty, tensor_stride=top, coordinate_manager=mgr_p)
             for ts in sorted(mgr_f.maps):
-                self.model.match_index(ME.SparseTensor(empty, tensor_stride=ts, coordinate_manager=mgr_f), part, ahead=True)
+                self.model.match_index(ME.SparseTensor(empty, tensor_stride=ts, coordinate_manager=mgr_f), part, ahead=True,
+                                       by_batch=True)           # (a training batch: every row against its own scan's part rows first)
             self._matches_done = torch.cuda.Event()
             self._matches_done.record(side)
 

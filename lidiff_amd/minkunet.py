@@ -418,7 +418,7 @@ class MinkUNetDiff(_Base):
         return emb
 
     # -- minkunet.py:403-418 --------------------------------------------------------------
-    def match_index(self, x_full, x_part, ahead: bool = False):
+    def match_index(self, x_full, x_part, ahead: bool = False, by_batch: bool | None = None):
         """argmin_j ||C_full[i] - C_part[j]||^2 (batch column scaled by 2*max coord), cached per
         (full map, part tensor): decoder levels reuse the encoder's maps."""
         cache = x_full.coordinate_manager.aux
@@ -436,7 +436,9 @@ class MinkUNetDiff(_Base):
         x_full.coordinate_manager._acquire(x_full.tensor_stride)
         d_full = x_full.coordinate_manager.count(x_full.tensor_stride)
         # (training batches hold several scans: every row against its own batch element's part rows first -- the same indices)
-        idx = (ops.nn_match(x_full.C, x_part.C, by_batch=torch.is_grad_enabled()) if d_full is None
+        if by_batch is None:
+            by_batch = torch.is_grad_enabled()
+        idx = (ops.nn_match(x_full.C, x_part.C, by_batch=by_batch) if d_full is None
                else ops.nn_match_dev(x_full.C, d_full, x_part.C))
         done = None
         if ahead:                                              # the consumer's stream joins when it first asks (above)

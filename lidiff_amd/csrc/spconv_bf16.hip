@@ -6,9 +6,12 @@
 //               x = x1 + x2 (+ x3) and w = w1 + w2 (+ w3) in bf16, all products x_i w_j with i + j <= planes + 1 (3 or 6
 //               MFMAs) -- measured error of a K = 6912 dot product relative to sum |x w|: 2.5e-7 (two planes), 1.3e-7
 //               (three planes), native fp32 MFMA 1.1e-7 (profiles/r01_bf16_split_micro.txt).
-// Features stay fp32 in HBM (BatchNorm, the loss, the optimizer and every consumer are fp32): the gathered rows are split /
+// Features are fp32 in HBM (BatchNorm, the loss, the optimizer and every consumer are fp32): the gathered rows are split /
 // rounded (nearest even, v_cvt_pk_bf16_f32) on their way from the LDS image into the MFMA operand, the weights once per
-// weight version when they are packed.
+// weight version when they are packed.  Round 5 (planes = 1, the training step): the rows may arrive as bf16 ALREADY -- the
+// shadow copy their producer left beside the fp32 matrix (in_bf16) -- and three kernels serve them: the two-stage kernel
+// below, a ring of four 32-channel stages, and (the default of kernel_size-3 / -1 layers) 256-row tiles with the accumulators in
+// registers and no pair lists.
 //
 // Same decomposition as spconv.hip -- a workgroup owns 128 output rows x BN output channels, accumulator tile in LDS, pairs
 // compacted per offset by wave ballot, gathered rows DMA'd into a source-swizzled LDS image, 16-pair row blocks -- but the

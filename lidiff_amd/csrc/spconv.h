@@ -58,7 +58,24 @@ __device__ __forceinline__ int64_t valid_rows(const ConvParams& p) {
 // weight gradient (spconv.hip, spconv_bf16.hip): pairs per chunk, pair slices per offset, the slice-ordered reduction
 constexpr int kDwPairs = 64;
 int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot);
-__global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n, int slices, float* __restrict__ dw);
+// The slices x k_vol workgroups of a launch (per tile of dW) are SLOTS handed to the offsets in proportion to their pair counts:
+// a slot is `per` pairs of one offset (whole chunks), offset k owns ceil(P_k / per) consecutive slots.  per is sized so that all
+// offsets together need at most slices x k_vol slots (the surplus ones stay idle).
+int64_t dw_pairs_per_slot(int64_t n_pairs, int64_t slices, int k_vol);
+// which offset a slot belongs to, and which of the offset's slots it is (false: an idle slot)
+__device__ __forceinline__ bool dw_slot_offset(const int32_t* __restrict__ offset_ptr, int k_vol, int64_t m_ident, int64_t per,
+                                               int slot, int& k, int& local, int64_t& p_lo, int64_t& p_hi) {
+    int cum = 0;
+    for (int kk = 0; kk < k_vol; ++kk) {
+        const int64_t lo = offset_ptr ? offset_ptr[kk] : 0, hi = offset_ptr ? offset_ptr[kk + 1] : m_ident;
+        const int sk = (int)((hi - lo + per - 1) / per);
+        if (slot < cum + sk) { k = kk; local = slot - cum; p_lo = lo; p_hi = hi; return true; }
+        cum += sk;
+    }
+    return false;
+}
+__global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n_k, int k_vol, const int32_t* __restrict__ offset_ptr,
+                                 int64_t m_ident, int64_t per, float* __restrict__ dw);
 
 // spconv_rows.hip: identity maps (kernel_size 1 / the centre pass) as a streaming row GEMM.
 bool rows_kernel_applies(const ConvParams& p);

@@ -977,7 +977,7 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
                                                            const float* __restrict__ g, const int32_t* __restrict__ pairs_in,
                                                            const int32_t* __restrict__ pairs_out,
                                                            const int32_t* __restrict__ offset_ptr, int64_t m_out,
-                                                           int c_out, int slices, float* __restrict__ dw,
+                                                           int c_out, int64_t per, float* __restrict__ dw,
                                                            float* __restrict__ part, int k_vol) {
     constexpr int CIT = 16 * NBI, COT = 128 * CB;        // tile extents
     constexpr int PA = CIT + 16, PG = COT + 16;          // LDS row pitches (words): = 16 mod 32
@@ -989,16 +989,15 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
     const int c_in = c_in_a + c_in_b;
     // offsets vary fastest over the grid: workgroups in flight together work on the same stretch of rows under
     // different offsets, i.e. on the same rows of g and neighbouring rows of in (L2 reuse)
-    const int k = blockIdx.x;
     const int co_tiles = (c_out + COT - 1) / COT;
     const int ci0 = (blockIdx.y / co_tiles) * CIT, co0 = (blockIdx.y % co_tiles) * COT;
-    // this offset's pairs, and this workgroup's slice of them (whole chunks)
-    const int64_t p_lo = IDENT ? 0 : offset_ptr[k], p_hi = IDENT ? m_out : offset_ptr[k + 1];
-    const int64_t per = (((p_hi - p_lo + slices - 1) / slices + kDwPairs - 1) / kDwPairs) * kDwPairs;
-    const int64_t s_lo = p_lo + (int64_t)blockIdx.z * per, s_hi = min(p_hi, s_lo + per);
-    // (a slice without pairs: nothing to add to dw -- but its tile of the slice workspace is written all the same, with zeros,
-    //  so that the workspace needs no clearing pass: up to 38 slices x 27 x 256 x 256 floats = 269 MB per 256-channel layer)
-    if (s_lo >= s_hi && part == nullptr) return;
+    // this workgroup's slot: `per` pairs (whole chunks) of the offset the slot belongs to -- slots go to the offsets in proportion
+    // to their pair counts (spconv.h), offsets varying fastest over consecutive slots
+    const int slot = (int)(blockIdx.z * gridDim.x + blockIdx.x);
+    int k, local;
+    int64_t p_lo, p_hi;
+    if (!dw_slot_offset(IDENT ? nullptr : offset_ptr, k_vol, m_out, per, slot, k, local, p_lo, p_hi)) return;       // idle slot
+    const int64_t s_lo = p_lo + (int64_t)local * per, s_hi = min(p_hi, s_lo + per);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
@@ -1084,7 +1083,7 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
     }
     // D layout: col = lane & 15 (co), row = 4 (lane >> 4) + reg (ci).  With a workspace every pair slice stores its partial
     // tile (summed in slice order by dw_reduce_kernel: deterministic); without one the slices meet in dw by fp32 atomics.
-    float* dwk = part ? part + ((int64_t)blockIdx.z * k_vol + k) * c_in * c_out : dw + (int64_t)k * c_in * c_out;
+    float* dwk = part ? part + (int64_t)slot * c_in * c_out : dw + (int64_t)k * c_in * c_out;
 #pragma unroll
     for (int b = 0; b < NBI; ++b)
 #pragma unroll
@@ -1099,21 +1098,38 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_kernel(const float* __restri
             }
 }
 
-// dw[e] = sum over the pair slices, in slice order (slices that held no pairs of an offset were pre-zeroed)
-__global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n, int slices, float* __restrict__ dw) {
+// dw[k][e] = sum over the offset's slots, in slot order (an offset without pairs: zeros)
+__global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n_k, int k_vol, const int32_t* __restrict__ offset_ptr,
+                                 int64_t m_ident, int64_t per, float* __restrict__ dw) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    const int k = blockIdx.y;
+    if (e >= n_k) return;
+    int first = 0, count = 0;
+    for (int kk = 0; kk <= k; ++kk) {
+        const int64_t lo = offset_ptr ? offset_ptr[kk] : 0, hi = offset_ptr ? offset_ptr[kk + 1] : m_ident;
+        first += count;
+        count = (int)((hi - lo + per - 1) / per);
+    }
     float v = 0.f;
-    for (int s = 0; s < slices; ++s) v += part[(int64_t)s * n + e];
-    dw[e] = v;
+    for (int s = first; s < first + count; ++s) v += part[(int64_t)s * n_k + e];
+    dw[(int64_t)k * n_k + e] = v;
+}
+
+int64_t dw_pairs_per_slot(int64_t n_pairs, int64_t slices, int k_vol) {
+    if (slices <= 1) return (int64_t)1 << 40;             // one slot per offset
+    // sum_k ceil(P_k / per) <= n_pairs / per + k_vol <= slices * k_vol
+    const int64_t slots = slices * k_vol - k_vol;
+    return ceil_div(ceil_div(n_pairs > 0 ? n_pairs : 1, slots), (int64_t)kDwPairs) * kDwPairs;
 }
 
 int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot) {
     const int tiles = (int)(ceil_div(c_in, cit) * ceil_div(c_out, cot));
-    // pair slices: several workgroups per CU slot -- the offsets' pair counts differ widely (the centre offset holds every row), so
-    // many short slices balance better than few long ones: 2 048 workgroups measured best on the bf16 step (1 024: 104.7 ms,
-    // 2 048: 102.0-103.1, 4 096: 103.4, 8 192: 107.1; LIDIFF_DW_TARGET) -- but at least 4 chunks each
-    static const int64_t target = [] { const char* e = getenv("LIDIFF_DW_TARGET"); return e ? (int64_t)atoi(e) : (int64_t)2048; }();
+    // workgroups per launch (LIDIFF_DW_TARGET).  With EQUAL slices per offset, whose pair counts differ widely (the centre offset
+    // holds every row), many short slices balanced best: 2 048 (bf16 step 1 024: 104.7 ms, 2 048: 102.0, 4 096: 103.4, 8 192: 107.1).
+    // With slots handed out in proportion to the pair counts (dw_pairs_per_slot) every workgroup has the same work, and fewer, longer
+    // slots win -- less partial-tile traffic through the workspace: 2 048: 84.1 ms, 1 024: 80.7, 768: 80.2, 512: 79.8, 384: 80.4
+    // (fp32: 164 / 160 / - / 162) -- but at least 4 chunks each
+    static const int64_t target = [] { const char* e = getenv("LIDIFF_DW_TARGET"); return e ? (int64_t)atoi(e) : (int64_t)768; }();
     int64_t slices = ceil_div(target, (int64_t)tiles * k_vol);
     const int64_t max_slices = max((int64_t)1, n_pairs / k_vol / (4 * kDwPairs));
     return max((int64_t)1, min(slices, max_slices));
@@ -1135,11 +1151,12 @@ static int launch_bwd_w(const float* in_a, int c_in_a, const float* in_b, int c_
     const int c_in = c_in_a + c_in_b;
     const int tiles = (int)(ceil_div(c_in, CIT) * ceil_div(c_out, COT));
     const int64_t slices = dw_slices(c_in, c_out, k_vol, n_pairs, CIT, COT);
-    const int64_t n = (int64_t)k_vol * c_in * c_out;
+    const int64_t per = dw_pairs_per_slot(n_pairs, slices, k_vol);
+    const int64_t n_k = (int64_t)c_in * c_out;
     float* part = (workspace != nullptr && slices > 1) ? workspace : nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)k_vol, (unsigned)tiles, (unsigned)slices), dim3(512), lds, st, in_a, c_in_a,
-                       in_b, c_in_b, g, pin, pout, off, m_out, c_out, (int)slices, dw, part, k_vol);
-    if (part) dw_reduce_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(part, n, (int)slices, dw);
+                       in_b, c_in_b, g, pin, pout, off, m_out, c_out, per, dw, part, k_vol);
+    if (part) dw_reduce_kernel<<<dim3((unsigned)ceil_div(n_k, 256), (unsigned)k_vol), 256, 0, st>>>(part, n_k, k_vol, off, m_out, per, dw);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

@@ -936,7 +936,7 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __r
                                                                 const float* __restrict__ g, const int32_t* __restrict__ pairs_in,
                                                                 const int32_t* __restrict__ pairs_out,
                                                                 const int32_t* __restrict__ offset_ptr, int64_t m_out,
-                                                                int c_out, int slices, float* __restrict__ dw,
+                                                                int c_out, int64_t per, float* __restrict__ dw,
                                                                 float* __restrict__ part, int k_vol) {
     constexpr int CIT = 16 * NBI, COT = 128 * CB;
     constexpr int PB = 2 * kDwPairs + 16;                    // LDS row pitch in bytes
@@ -946,15 +946,13 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __r
     char* a_t = smem;                                        // [ci][pair] bf16
     char* g_t = smem + CIT * PB;                             // [co][pair] bf16
     const int c_in = c_in_a + c_in_b;
-    const int k = blockIdx.x;
     const int co_tiles = (c_out + COT - 1) / COT;
     const int ci0 = (blockIdx.y / co_tiles) * CIT, co0 = (blockIdx.y % co_tiles) * COT;
-    const int64_t p_lo = IDENT ? 0 : offset_ptr[k], p_hi = IDENT ? m_out : offset_ptr[k + 1];
-    const int64_t per = (((p_hi - p_lo + slices - 1) / slices + kDwPairs - 1) / kDwPairs) * kDwPairs;
-    const int64_t s_lo = p_lo + (int64_t)blockIdx.z * per, s_hi = min(p_hi, s_lo + per);
-    // (a slice without pairs: nothing to add to dw -- but its tile of the slice workspace is written all the same, with zeros,
-    //  so that the workspace needs no clearing pass: up to 38 slices x 27 x 256 x 256 floats = 269 MB per 256-channel layer)
-    if (s_lo >= s_hi && part == nullptr) return;
+    const int slot = (int)(blockIdx.z * gridDim.x + blockIdx.x);       // slots by pair count: see spconv.h
+    int k, local;
+    int64_t p_lo, p_hi;
+    if (!dw_slot_offset(IDENT ? nullptr : offset_ptr, k_vol, m_out, per, slot, k, local, p_lo, p_hi)) return;       // idle slot
+    const int64_t s_lo = p_lo + (int64_t)local * per, s_hi = min(p_hi, s_lo + per);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
@@ -1075,7 +1073,7 @@ __global__ __launch_bounds__(512) void spconv_bwd_w_bf16_kernel(const float* __r
             }
         }
     }
-    float* dwk = part ? part + ((int64_t)blockIdx.z * k_vol + k) * c_in * c_out : dw + (int64_t)k * c_in * c_out;
+    float* dwk = part ? part + (int64_t)slot * c_in * c_out : dw + (int64_t)k * c_in * c_out;
 #pragma unroll
     for (int b = 0; b < NBI; ++b)
 #pragma unroll
@@ -1106,11 +1104,12 @@ static int launch_bwd_w_bf16(const float* in_a, int c_in_a, const float* in_b, i
     const int c_in = c_in_a + c_in_b;
     const int tiles = (int)(ceil_div(c_in, CIT) * ceil_div(c_out, COT));
     const int64_t slices = dw_slices(c_in, c_out, k_vol, n_pairs, CIT, COT);
-    const int64_t n = (int64_t)k_vol * c_in * c_out;
+    const int64_t per = dw_pairs_per_slot(n_pairs, slices, k_vol);
+    const int64_t n_k = (int64_t)c_in * c_out;
     float* part = (workspace != nullptr && slices > 1) ? workspace : nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)k_vol, (unsigned)tiles, (unsigned)slices), dim3(512), lds, st, in_a, c_in_a,
-                       in_b, c_in_b, g, pin, pout, off, m_out, c_out, (int)slices, dw, part, k_vol);
-    if (part) dw_reduce_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(part, n, (int)slices, dw);
+                       in_b, c_in_b, g, pin, pout, off, m_out, c_out, per, dw, part, k_vol);
+    if (part) dw_reduce_kernel<<<dim3((unsigned)ceil_div(n_k, 256), (unsigned)k_vol), 256, 0, st>>>(part, n_k, k_vol, off, m_out, per, dw);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

@@ -1111,7 +1111,16 @@ __global__ void dw_reduce_kernel(const float* __restrict__ part, int64_t n_k, in
         count = (int)((hi - lo + per - 1) / per);
     }
     float v = 0.f;
-    for (int s = first; s < first + count; ++s) v += part[(int64_t)s * n_k + e];
+    const float* src = part + (int64_t)first * n_k + e;
+    int s = 0;
+    for (; s + 8 <= count; s += 8) {                      // eight loads in flight, added in slot order
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = src[(int64_t)(s + i) * n_k];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += t[i];
+    }
+    for (; s < count; ++s) v += src[(int64_t)s * n_k];
     dw[(int64_t)k * n_k + e] = v;
 }
 

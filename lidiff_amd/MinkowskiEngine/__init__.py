@@ -487,6 +487,24 @@ class _GatherRows(torch.autograd.Function):
         return ops.scatter_add_rows(g, idx, ctx.m), None
 
 
+class _GatherMulRows(torch.autograd.Function):
+    """x * table[idx] (the conditioning multiply with its MLP evaluated on a table, minkunet.py:431) as ONE pass forward and one
+    for the gradient of x -- no [M, C] copy of the gathered weights; the table's gradient is the segment sum of g * x."""
+
+    @staticmethod
+    def forward(ctx, x, table, idx):
+        ctx.save_for_backward(x, table, idx)
+        return ops.gather_mul_rows(x, table, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, table, idx = ctx.saved_tensors
+        g = g.contiguous()
+        gx = ops.gather_mul_rows(g, table, idx) if ctx.needs_input_grad[0] else None
+        gt = ops.scatter_add_rows(g * x, idx, table.shape[0]) if ctx.needs_input_grad[1] else None
+        return gx, gt, None
+
+
 class _SparseConv(torch.autograd.Function):
     """out = sum_k in[nbr[k]] @ W[k].  backward: dX is the same operator over the swapped map
     with W^T (for a centred odd kernel on one map the swap is k -> K-1-k); dW = gather^T @ g."""

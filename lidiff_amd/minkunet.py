@@ -585,6 +585,8 @@ class MinkUNetDiff(_Base):
                 comb = aux.get(key)
                 if comb is None:                      # (kept for the step: the backward's sort by destination is cached on it)
                     comb = aux[key] = idx * nb + self._batch_index(x)
+                if x.F.is_cuda and x.F.dtype == torch.float32 and table.dtype == torch.float32:
+                    return x._like(ME._GatherMulRows.apply(x.F, table, comb))           # x * table[comb], one pass each way
                 return x * ME._GatherRows.apply(table, comb)
             hidden = TF.leaky_relu(ME._GatherRows.apply(h_p.float(), idx) + self._per_batch_rows(h_t.float(), x), 0.1)
             return x * _run_mlp(lin2, hidden)

@@ -21,6 +21,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # A session takes 2-3 minutes.  Should it ever sit somewhere for a quarter of an hour (a stalled disk under a fixture load was
+    # seen once in the build container), the stacks of all threads go to stderr -- every 15 minutes, without failing anything.
+    import faulthandler
+    faulthandler.dump_traceback_later(900, repeat=True)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+
+
 def has_gpu() -> bool:
     return torch.cuda.is_available()
 

@@ -1312,3 +1312,29 @@ def test_spconv_bf16_from_shadow_rows_is_bit_identical(device, cin, split, cout,
         ref_w = ops.spconv_bwd_w(x1, gr, nbr, k, bf16=True)
         got_w = ops.spconv_bwd_w(ops.cast_bf16(x1), ops.cast_bf16(gr), nbr, k, bf16=True)
         assert torch.equal(got_w, ref_w), (got_w - ref_w).abs().max().item()
+
+
+@pytest.mark.parametrize("n_points", [1, 17, 300, 2000])
+def test_spconv_bf16_row_kernels_on_tiny_and_ragged_maps(device, n_points):
+    """The three kernels for bf16 rows on maps far smaller than a tile, with ragged last tiles, with kernel offsets that have no
+    pair at all (a cloud spread thin: most of the 27 offsets are empty) and with one replica: the pair-list kernels bit-identical to
+    the fp32-row form, the wide register-tile kernel within 1e-4, and all of them against the float64 oracle on the bf16-rounded
+    operands at the fp32 kernel's bar."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(100 + n_points)
+    uniq, _, _ = me.voxelize(random_cloud(n_points, 9, 200 + n_points))
+    nbr_np = me.kernel_map(uniq, uniq, 3, 1)
+    m = uniq.shape[0]
+    nbr = dev_i32(nbr_np, device)
+    for cin, cout in ((64, 128), (96, 96), (32, 32), (256, 256)):
+        x = torch.randn(m, cin, generator=g)
+        w = torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 3)
+        xd, wd = x.to(device), w.to(device)
+        ref = ops.spconv_fwd_bf16(xd, wd, nbr, m)
+        x16 = ops.cast_bf16(xd)
+        for kern in ("two_stage", "ring"):
+            assert torch.equal(ops.spconv_fwd_bf16(x16, wd, nbr, m, kernel=kern), ref), (kern, cin, cout, m)
+        wide = ops.spconv_fwd_bf16(x16, wd, nbr, m, kernel="wide")
+        assert torch.allclose(wide, ref, rtol=1e-4, atol=1e-4), (cin, cout, m, (wide - ref).abs().max().item())
+        want = me.conv_forward(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), nbr_np)
+        assert torch.allclose(wide.cpu().double(), want, rtol=RTOL, atol=ATOL), (cin, cout, m)

@@ -316,7 +316,7 @@ def train_leg(scan_np, device, steps=3, warmup=1):
         gen = torch.Generator(device=device).manual_seed(1)
         tot = {"forward_loss_ms": 0.0, "backward_ms": 0.0, "optimizer_ms": 0.0}
         torch.cuda.reset_peak_memory_stats()
-        conv_ms = dw_ms = 0.0
+        conv_ms = dw_ms = conv_flops = 0.0
         for step in range(warmup + steps):
             timed = step >= warmup
             prof = ops.ConvProfiler(None) if timed else None
@@ -338,11 +338,16 @@ def train_leg(scan_np, device, steps=3, warmup=1):
                 tot["optimizer_ms"] += e[2].elapsed_time(e[3])
                 conv_ms += sum(a.elapsed_time(b) for _, a, b, *_ in prof.launches if a is not None)
                 dw_ms += prof.dw_ms()
+                conv_flops += sum(d["flops_timed"] for d in prof.summary().values())        # 2 P C_in C_out per forward / dX launch
         ms = {k: v / steps for k, v in tot.items()}
         total = sum(ms.values())
         out[("f32" if precision == "32" else "bf16") + ("_syncbn" if sync else "")] = {
             "ms_per_step": total, "steps_per_s": 1e3 / total, "scans_per_s": 2e3 / total, **ms,
             "conv_fwd_dx_kernels_ms": conv_ms / steps, "conv_dw_kernels_ms": dw_ms / steps,
+            # the step's convolution classes against the matrix peak of their operand type (algorithmic flops 2 P C_in
+            # C_out per launch, HIP-event time of the launches; the weight gradient does the forward launches' flops once more)
+            "roofline_conv_fwd_dx": _mfma_roofline(conv_flops / steps, conv_ms / steps, precision),
+            "roofline_conv_dw": _mfma_roofline(0.5 * conv_flops / steps, dw_ms / steps, precision),
             "other_ms": total - (conv_ms + dw_ms) / steps,
             "peak_memory_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "final_loss": float(loss.detach())}
         if sync:
@@ -372,6 +377,13 @@ def train_leg(scan_np, device, steps=3, warmup=1):
                                 "parameter-gradient cosine of 0.86 (worst 0.71) at random initialisation "
                                 "(tests/test_gpu_network.py::test_bf16_training_step_tracks_the_fp32_step)")
     return out
+
+
+def _mfma_roofline(flops_per_step, ms_per_step, precision):
+    peak = 157.3 if precision == "32" else 2500.0            # dense fp32 / bf16 MFMA peak (MI355X_MICROARCH.md), TFLOP/s
+    tf = flops_per_step / (ms_per_step * 1e-3) / 1e12 if ms_per_step > 0 else 0.0
+    return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+            "gflop_per_step": flops_per_step / 1e9, "ms_per_step": ms_per_step}
 
 
 def train_refine_leg(scan_np, device, items=2, steps=2, warmup=1):

@@ -450,6 +450,8 @@ class CoordinateManager:
     def check(self):
         """Raise if a kernel flagged a coordinate outside the hash-key range (host sync)."""
         s = int(self.status.item())
+        if s:
+            self.status.zero_()          # (raised once: the word may be shared with the fields of a later loop)
         if s & ops.STATUS_KEY_RANGE:
             raise RuntimeError("coordinate outside [-32768, 32767]: not representable in the 64-bit key")
         if s & ops.STATUS_HASH_FULL:

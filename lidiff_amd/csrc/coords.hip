@@ -199,8 +199,10 @@ __global__ void mean_absmax_kernel(const float* __restrict__ feats, int64_t tota
     // the critical path between two denoising steps for 2 MB of input)
     __shared__ uint32_t wmax[kBlock / kWave];
     uint32_t m = 0;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
-        m = max(m, __float_as_uint(feats[e]) & 0x7fffffffu);          // |x| as bits: monotonic for finite values
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = __float_as_uint(feats[e]) & 0x7fffffffu;   // |x| as bits: monotonic for finite values
+        if (b < 0x7f800000u) m = max(m, b);                           // (Inf / NaN take no part in the scale: see mean_accum_kernel)
+    }
     for (int off = kWave / 2; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off));
     if (lane_id() == 0) wmax[threadIdx.x / kWave] = m;
     __syncthreads();
@@ -217,6 +219,8 @@ __device__ __forceinline__ int mean_shift(uint32_t amax_bits, int n_bits) {
     return 62 - e - n_bits;
 }
 
+constexpr int32_t kMeanPoison = 1 << 30;      // bit 30 of a voxel's point count: one of its features is Inf / NaN
+
 __global__ void mean_accum_kernel(const float* __restrict__ feats, const int64_t* __restrict__ inverse,
                                   int64_t n, int c, int n_bits, const uint32_t* __restrict__ amax,
                                   unsigned long long* __restrict__ acc, int32_t* __restrict__ cnt) {
@@ -224,6 +228,17 @@ __global__ void mean_accum_kernel(const float* __restrict__ feats, const int64_t
     const bool valid = i < n;
     const int row = valid ? (int)inverse[i] : -1;
     const double scale = ldexp(1.0, mean_shift(*amax, n_bits));
+    // An Inf / NaN feature has no fixed-point image: it adds nothing to the sums and marks ITS voxel (bit 30 of the count, N <
+    // 2^30), whose channels mean_div_kernel then sums in fp32 in point order -- the non-finite value reaches the voxel it belongs
+    // to and no other, as the reference's fp32 sum does (round 5 made the whole batch NaN).
+    auto fixed = [&](float x) {
+        return (__float_as_uint(x) & 0x7fffffffu) < 0x7f800000u ? __double2ll_rn((double)x * scale) : 0ll;
+    };
+    if (valid) {
+        bool bad = false;
+        for (int j = 0; j < c; ++j) bad |= (__float_as_uint(feats[i * c + j]) & 0x7fffffffu) >= 0x7f800000u;
+        if (bad) atomicOr(&cnt[row], kMeanPoison);
+    }
     // all valid lanes of the wave fall in one voxel (x_uncond, heavy duplicates): reduce in the
     // wave and issue ONE atomic per channel instead of 64 serialised same-address atomics.
     const unsigned long long vm = __ballot(valid);
@@ -231,7 +246,7 @@ __global__ void mean_accum_kernel(const float* __restrict__ feats, const int64_t
     const int r0 = __shfl(row, __ffsll((long long)vm) - 1);
     if (__all(!valid || row == r0)) {
         for (int j = 0; j < c; ++j) {
-            long long v = valid ? __double2ll_rn((double)feats[i * c + j] * scale) : 0ll;
+            long long v = valid ? fixed(feats[i * c + j]) : 0ll;
             for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane_id() == 0) atomicAdd(&acc[(int64_t)r0 * c + j], (unsigned long long)v);
         }
@@ -240,21 +255,35 @@ __global__ void mean_accum_kernel(const float* __restrict__ feats, const int64_t
     }
     if (!valid) return;
     for (int j = 0; j < c; ++j)
-        atomicAdd(&acc[(int64_t)row * c + j], (unsigned long long)__double2ll_rn((double)feats[i * c + j] * scale));
+        atomicAdd(&acc[(int64_t)row * c + j], (unsigned long long)fixed(feats[i * c + j]));
     atomicAdd(&cnt[row], 1);
 }
 
 __global__ void mean_div_kernel(const unsigned long long* __restrict__ acc, const int32_t* __restrict__ cnt,
                                 int64_t total, int c, int n_bits, const uint32_t* __restrict__ amax,
+                                const float* __restrict__ feats, const int64_t* __restrict__ inverse, int64_t n_rows,
                                 float* __restrict__ out, float* __restrict__ counts) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const double inv_scale = ldexp(1.0, -mean_shift(*amax, n_bits));
-    const float n = (float)cnt[e / c];
+    const int32_t cw = cnt[e / c];
+    const float n = (float)(cw & (kMeanPoison - 1));
     float sum = (float)((double)(long long)acc[e] * inv_scale);        // the exact sum, rounded to fp32 once
-    // an Inf / NaN feature anywhere makes the common scale meaningless for every voxel: the whole batch reads NaN (a diverged
-    // training run must not be masked by finite garbage; the fp32-atomic form propagated NaN to the affected voxel only)
-    if (*amax >= 0x7f800000u) sum = __uint_as_float(0x7fc00000u);
+    if (cw & kMeanPoison) {
+        // a voxel holding an Inf / NaN feature: its channels as the plain fp32 sum of its points in point order (a scan of the
+        // whole inverse map per element -- the pathological case only), so that the value propagates the way fp32 addition
+        // propagates it (NaN; +-Inf; Inf - Inf = NaN), to this voxel and to no other
+        // (a channel of that voxel without such a value keeps its exact sum)
+        float seq = 0.f;
+        bool bad = false;
+        for (int64_t i = 0; i < n_rows; ++i)
+            if (inverse[i] == e / c) {
+                const float x = feats[i * c + e % c];
+                bad |= (__float_as_uint(x) & 0x7fffffffu) >= 0x7f800000u;
+                seq += x;
+            }
+        if (bad) sum = seq;
+    }
     out[e] = sum / n;
     if (e % c == 0) counts[e / c] = n;
 }
@@ -1525,7 +1554,7 @@ int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, 
         mean_absmax_kernel<<<(unsigned)(ceil_div(total, 4 * kBlock) < 256 ? ceil_div(total, 4 * kBlock) : 256), kBlock, 0, st>>>(feats, total, amax);
         mean_accum_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(feats, inverse, n_rows, c, n_bits, amax, acc, cnt);
     }
-    mean_div_kernel<<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(acc, cnt, m * c, c, n_bits, amax, out, counts);
+    mean_div_kernel<<<(unsigned)ceil_div(m * c, kBlock), kBlock, 0, st>>>(acc, cnt, m * c, c, n_bits, amax, feats, inverse, n_rows, out, counts);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

@@ -245,20 +245,23 @@ def train_loop(module, batches, steps: int, sync_bn: bool = True, transport_dtyp
                     log(len(losses) - 1, v)
             pending.clear()
 
-    for step in range(steps):
-        loss = module.training_step(batches[(step * world + rank) % len(batches)], step)
-        reducer.zero_grad()
-        loss.backward()
-        reducer.all_reduce()
-        opt.step()
-        if sched is not None:
-            if interval == "step":
-                if (step + 1) % frequency == 0:
+    try:
+        for step in range(steps):
+            loss = module.training_step(batches[(step * world + rank) % len(batches)], step)
+            reducer.zero_grad()
+            loss.backward()
+            reducer.all_reduce()
+            opt.step()
+            if sched is not None:
+                if interval == "step":
+                    if (step + 1) % frequency == 0:
+                        sched.step()
+                elif (step + 1) % steps_per_epoch == 0 and ((step + 1) // steps_per_epoch) % frequency == 0:
                     sched.step()
-            elif (step + 1) % steps_per_epoch == 0 and ((step + 1) // steps_per_epoch) % frequency == 0:
-                sched.step()
-        pending.append(loss.detach())
-        if len(pending) >= log_every:
-            drain()
-    drain()
+            pending.append(loss.detach())
+            if len(pending) >= log_every:
+                drain()
+        drain()
+    finally:
+        reducer.close()           # hooks and flat buffers go with the loop (a second train_loop on the module starts clean)
     return losses

@@ -114,9 +114,33 @@ class GradAllReducer:
         self.attached = False
         if attach:
             self.attach()
+        self._hooks = []
         if overlap:
             for p in self.params:
-                p.register_post_accumulate_grad_hook(self._on_grad)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def close(self):
+        """Remove the post-accumulate hooks and let go of the flat buffers: a second reducer on the same module must not find
+        this one's hooks still copying gradients and launching all-reduces nobody waits for.  Gradients that are
+        views into the buffers are detached copies afterwards."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self.attached:
+            with torch.no_grad():
+                for b in self.buckets:
+                    for p, v in zip(b.params, b.views):
+                        if p.grad is v:
+                            p.grad = v.clone()
+            self.attached = False
+        self.buckets, self._bucket_of = [], {}
+
+    def __del__(self):
+        try:
+            for h in self._hooks:
+                h.remove()
+        except Exception:
+            pass
 
     @staticmethod
     def _active() -> bool:

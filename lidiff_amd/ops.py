@@ -136,12 +136,24 @@ class SizeFeed:
         self.bad = None              # first failed validation (message), sticky until reset()
 
     def reset(self):
-        """Forget every record (a new scan: its first pyramid is built with a host read again)."""
-        self.drain()
+        """Forget every record (a new scan: its first pyramid is built with a host read again).  Records the device still owes
+        are read if the feed is healthy; after a failure (a record that never arrived, a voided loop) they are DISCARDED -- a
+        publish launch that never ran must not make every later loop wait for it."""
+        if self.bad is None:
+            self.drain(timeout_s=5.0)
+        self._discard_pending()
         self.done.clear()
         self.checks.clear()
         self.seq_base = self.seq
         self.bad = None
+        if self.dev_seq is not None:
+            self.dev_seq.fill_(self.seq)         # the device-side numbering follows the host's again
+
+    def _discard_pending(self):
+        for seq in list(self.n_words):
+            del self.n_words[seq]
+            self.checks.pop(seq, None)
+        self.slot_owner = {s: q for s, q in self.slot_owner.items() if q in self.n_words}
 
     def has_records(self) -> bool:
         return self.seq > self.seq_base
@@ -150,10 +162,11 @@ class SizeFeed:
         """What the host assumed about record `seq`: words that must equal / must not exceed a value."""
         self.checks[seq] = (dict(exact_rows), dict(maxima or {}))
 
-    def drain(self):
+    def drain(self, timeout_s: float = 30.0):
         """Read every record the device still owes (end of a loop: all checks done).  Returns self.bad."""
         for seq in sorted(self.n_words):
-            self.get(seq)
+            if seq in self.n_words:
+                self.get(seq, timeout_s)
         return self.bad
 
     def _check(self, seq, status, sizes):
@@ -233,7 +246,15 @@ class SizeFeed:
         t0 = time.perf_counter()
         while int(row[0]) != seq:                      # the device has not got there yet (plain memory reads, no HIP call)
             if time.perf_counter() - t0 > timeout_s:
-                raise RuntimeError("SizeFeed: the device never published record %d" % seq)
+                # a publish launch that never ran (launch error, an exception inside a capture) or a device lagging far behind
+                # (a profiler, a shared GPU): the feed is marked bad -- the loop is redone with exact sizes -- and every record
+                # still owed is dropped, so that nothing waits for this one again
+                self.bad = self.bad or "record %d was never published by the device (waited %.0f s)" % (seq, timeout_s)
+                self._discard_pending()
+                older = [k for k in self.done if k < seq]
+                if not older:
+                    raise RuntimeError("SizeFeed: " + self.bad)
+                return (STATUS_BOUND, list(self.done[max(older)][1]))     # stale sizes as hints: the loop is void anyway
             time.sleep(0)
         n = self.n_words.pop(seq)
         hit = self.done[seq] = (int(row[1]), [int(v) for v in row[2:2 + n]])

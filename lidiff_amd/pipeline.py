@@ -111,7 +111,15 @@ class DiffCompletion(nn.Module):
         for f in self.__dict__.get("_feeds", {}).values():
             f.reset()
         if self.__dict__.get("_status") is not None:
+            # the word is shared by every field of the loop, the ones voxelised BEFORE it included: what they flagged (a
+            # coordinate outside the key range, a full table) is raised here, not erased; one read per scan
+            from . import ops
+            s = int(self._status.item())
             self._status.zero_()
+            if s & ops.STATUS_KEY_RANGE:
+                raise RuntimeError("coordinate outside [-32768, 32767]: not representable in the 64-bit key")
+            if s & ops.STATUS_HASH_FULL:
+                raise RuntimeError("coordinate hash table overflow")
 
     def read_free_check(self):
         """None, or why the host-read-free steps since the last reset are void (waits for the sizes the device still owes and

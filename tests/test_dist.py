@@ -59,6 +59,18 @@ def _worker(rank, world, port, result_q):
     out["overlap_views"] = all(p.grad.data_ptr() == v.data_ptr() for b in red.buckets for p, v in zip(b.params, b.views))
     out["overlap_launched_in_backward"] = launched_in_backward
     out["overlap_buckets"] = len(red.buckets)
+    # close(): the hooks go (a second reducer on the module must not find the first one's still launching collectives --
+    # ADVICE r5), the gradients survive as plain tensors, and a fresh overlapped reducer gives the same averages again
+    red.close()
+    out["hooks_after_close"] = sum(len(getattr(p, "_post_accumulate_grad_hooks", None) or {}) for p in model.parameters())
+    out["grads_after_close"] = all(torch.equal(p.grad, g) for p, g in zip(model.parameters(), out["avg_overlap"]))
+    red2 = ldist.GradAllReducer(model.parameters(), bucket_bytes=64, attach=True, overlap=True)
+    red2.zero_grad()
+    model(x).pow(2).sum().backward()
+    red2.all_reduce()
+    out["avg_overlap_second"] = [p.grad.clone() for p in model.parameters()]
+    out["hooks_second"] = sum(len(getattr(p, "_post_accumulate_grad_hooks", None) or {}) for p in model.parameters())
+    red2.close()
     # train_loop: rank r takes batch (step * world + r) mod len -- disjoint data per rank (DistributedSampler), the
     # LR follows Lightning's {'interval': 'epoch', 'frequency': 5} (models.py:340-344), losses are read back lazily
     from lidiff_amd.diffusion import train_loop
@@ -129,6 +141,8 @@ def test_two_rank_gloo():
     for r in (0, 1):
         assert results[r]["avg_overlap"] == results[r]["avg"] and results[r]["overlap_views"]
         assert results[r]["overlap_buckets"] > 1 and results[r]["overlap_launched_in_backward"] == results[r]["overlap_buckets"]
+        assert results[r]["hooks_after_close"] == 0 and results[r]["grads_after_close"]
+        assert results[r]["avg_overlap_second"] == results[r]["avg"] and results[r]["hooks_second"] == 4
 
 
 def test_single_process_is_a_noop():

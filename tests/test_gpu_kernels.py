@@ -159,6 +159,37 @@ def test_voxel_mean_is_deterministic_and_correctly_rounded(device, fps_scan):
     assert torch.equal(zeros.cpu(), torch.zeros(1, 3))
 
 
+def test_voxel_mean_confines_a_non_finite_feature_to_its_voxel(device, fps_scan):
+    """An Inf / NaN feature poisons the voxel (and channel) it belongs to, as the reference's fp32 sum does, and nothing else
+    (the common fixed-point scale made the whole batch NaN): every other voxel keeps the bits of the clean run; the
+    poisoned channels read what the sequential fp32 sum gives (NaN, +-Inf, Inf - Inf = NaN)."""
+    from lidiff_amd import ops
+    pts = noisy_scan_points(fps_scan, 0.05, 0, n_rep=2)
+    feats = torch.from_numpy(pts).clone()
+    ci = torch.cat([torch.zeros(pts.shape[0], 1), torch.round(feats / 0.2)], 1).to(torch.int32).to(device)   # several points per voxel
+    uniq, inv, _, _ = ops.vox_unique(ci, status(device))
+    m = uniq.shape[0]
+    clean, _ = ops.vox_mean(feats.to(device), inv, m)
+    inv_np = inv.cpu().numpy()
+    order = np.argsort(np.bincount(inv_np, minlength=m))[::-1]
+    va, vb, vc = (int(v) for v in order[:3])                                   # three crowded voxels
+    pa, pb, pc = (np.flatnonzero(inv_np == v) for v in (va, vb, vc))
+    assert min(len(pa), len(pb), len(pc)) >= 2
+    feats[pa[0], 0] = float("nan")
+    feats[pb[0], 1] = float("inf")
+    feats[pc[0], 2] = float("inf")
+    feats[pc[1], 2] = float("-inf")
+    out, counts = ops.vox_mean(feats.to(device), inv, m)
+    out, clean = out.cpu(), clean.cpu()
+    untouched = torch.ones(m, dtype=torch.bool)
+    untouched[[va, vb, vc]] = False
+    assert torch.equal(out[untouched], clean[untouched])
+    assert torch.isnan(out[va, 0]) and torch.equal(out[va, 1:], clean[va, 1:])
+    assert out[vb, 1] == float("inf") and torch.equal(out[vb, [0, 2]], clean[vb, [0, 2]])
+    assert torch.isnan(out[vc, 2]) and torch.equal(out[vc, :2], clean[vc, :2])
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(inv_np, minlength=m))
+
+
 def conv_case(device, coords_np, cin, cout, kind, seed, epilogue=False, split=0):
     """kind: 'k3' | 'down' | 'up' | 'k1'."""
     from lidiff_amd import ops
@@ -868,8 +899,7 @@ def test_scatter_add_as_segment_sum_is_deterministic(device):
     ms = t0.elapsed_time(t1)
     record_parity("segment_sum_long_segments", ms_360k_rows_onto_2=ms)
     assert torch.allclose(out.cpu().double(), torch.stack([src[:n // 2].double().sum(0), src[n // 2:].double().sum(0)]).cpu(), rtol=1e-4, atol=2e-2)
-    if os.environ.get("LIDIFF_TIMING_ASSERTS") == "1":      # a wall-clock bound is no correctness test: opt-in, recorded always
-        assert ms < 20.0, ms
+    # (the time is recorded, not asserted: a wall-clock bound is no correctness test -- bench.py --layer-table times kernels)
 
 
 ROW_KERNEL_SHAPES = [(32, 0, 32), (32, 0, 64), (64, 0, 64), (64, 0, 128), (96, 0, 96), (96, 64, 96), (128, 96, 96),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 26
+#define LIDIFF_ABI_VERSION 27
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
@@ -37,6 +37,7 @@ extern "C" {
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
 #define LIDIFF_CONV_TILE_128 16     /* 64-column layers on 128-row tiles as well (default: 256-row tiles for large maps; A/B measurements) */
 #define LIDIFF_CONV_PERSIST 32      /* tile kernels as resident workgroups that pull tile slots from per-XCD counters (A/B measurements) */
+#define LIDIFF_CONV_PINGPONG 64     /* dense 128-column tiles: the two waves of a SIMD alternate between MFMAs and everything else (round 6; bit-identical) */
 #define LIDIFF_CONV_TILE_ONLY 8     /* identity maps (nbr == NULL) through the tile kernel as well, not the row kernel (A/B measurements, tests) */
 
 int lidiff_abi_version(void);
@@ -285,6 +286,24 @@ int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b,
                            int32_t planes, const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out,
                            float* out, const float* ep_scale, const float* ep_shift, const float* residual, int32_t relu,
                            int32_t replicas, int32_t in_bf16, void* stream);
+
+/* lidiff_spconv_fwd for the dense levels with the contraction on the bf16 matrix pipe from THREE-WAY SPLIT operands (round 6;
+ * MinkowskiConvolution, minkunet.py:53-66,184-259, eval-mode fused plan): fp32 in, fp32 out, fp32 accuracy.  Every fp32 value is
+ * the exact sum of three bf16 pieces x0 + x1 + x2 (round to nearest even at each cut); the six products x_i w_j with i + j <= 2 --
+ * each exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16 -- leave out only terms below 2^-24 |x w|: the error against
+ * float64 equals the fp32 MFMA's own (tests/test_gpu_kernels.py::test_spconv_split3_*; profiles/r06_split3.txt).
+ *   lidiff_split3_rows: fp32 [m][c] -> bf16 [m][3][c] (the operand layout; c % 8 == 0);
+ *   weights: lidiff_spconv_pack_weights_bf16 with planes = 3;
+ *   lidiff_spconv_fwd_split3: in_a3 / in_b3 = split matrices of `replicas` stacked feature matrices (fused ME.cat as in
+ *   lidiff_spconv_fwd), nbr / k_vol / m_in / m_out / epilogue / replicas / d_m_out as there; out_planes (nullable): the
+ *   output ALSO as bf16 [replicas * m_out][3][c_out] -- the next dense convolution's operand, cut in the epilogue.
+ *   Shapes: c_in_a, c_in_b multiples of 32, c_out a multiple of 128 (lidiff_spconv_fwd_split3_supported). */
+int lidiff_split3_rows(const float* src, int64_t m, int32_t c, void* dst, void* stream);
+int32_t lidiff_spconv_fwd_split3_supported(int32_t c_in_a, int32_t c_in_b, int32_t c_out);
+int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const void* in_b3, int32_t c_in_b, const void* w_packed3,
+                             const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* out,
+                             void* out_planes, const float* ep_scale, const float* ep_shift, const float* residual,
+                             int32_t relu, int32_t replicas, const int32_t* d_m_out, void* stream);
 
 /* Weight gradient of lidiff_spconv_fwd (training path, models.py:180-217; ME: ConvolutionBackwardGPU):
  * dw[k] += gather(in)[pairs_in of offset k]^T @ grad_out[pairs_out of offset k], in = [in_a | in_b], over the

@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["coords.hip", "spconv.hip", "spconv_rows.hip", "spconv_bf16.hip", "norm.hip", "step.hip", "head.hip"]
+SOURCES = ["coords.hip", "spconv.hip", "spconv_rows.hip", "spconv_bf16.hip", "spconv_split3.hip", "norm.hip", "step.hip", "head.hip"]
 # step.hip restates a sequence of separately rounded torch launches: no fused multiply-adds there
 EXTRA_FLAGS = {"step.hip": ["-ffp-contract=off"]}
 HEADERS = ["common.h", "spconv.h", os.path.join("..", "..", "include", "lidiff_amd.h")]

@@ -1,5 +1,5 @@
 // Shared declarations of the sparse-convolution kernels (spconv.hip: tile kernels for every shape; spconv_rows.hip: one pair per
-// output row; spconv_bf16.hip: bf16 operands).
+// output row; spconv_bf16.hip: bf16 operands; spconv_split3.hip: fp32 results from three-way split bf16 operands).
 #pragma once
 #include <type_traits>
 
@@ -19,6 +19,7 @@ struct ConvParams {
     const int32_t* nbr;
     const int32_t* row_order;   // nullable: tile rows -> output rows
     float* out;
+    void* out_planes;           // nullable (spconv_split3.hip): the output cut into three bf16 pieces, [m_out][3][c_out]
     const float* scale;
     const float* shift;
     const float* residual;

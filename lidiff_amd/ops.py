@@ -886,7 +886,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert t_rows.shape == (replicas * n_tail, c_out) and t_rows.is_contiguous() and t_rows.dtype == torch.float32
         assert t_ptr.dtype == torch.int32 and t_ptr.shape == (m_out + 1,) and t_idx.dtype == torch.int32
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
-    flags = int(bool(sparse_map)) | {"tile": 0, "tile_only": 8, "tile128": 16, "persist": 32}[kernel or "tile"] | CONV_FLAGS
+    flags = int(bool(sparse_map)) | {"tile": 0, "tile_only": 8, "tile128": 16, "persist": 32, "pingpong": 64}[kernel or "tile"] | CONV_FLAGS
     if PERSIST_MIN_CIN and c_in >= PERSIST_MIN_CIN and c_out % 128 == 0 and not sparse_map and k > 1:
         flags |= 32
     if rows_hint is not None and rows_hint * replicas < 256 * 512:
@@ -1287,6 +1287,93 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
         end.record()
     if prof is not None:
         prof.launches.append((variant, start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
+    return out
+
+
+# Dense kernel_size-3 convolutions of the eval-mode fused plan (tensor stride >= SPLIT3_MIN_STRIDE, maps that are not low-density,
+# widths lidiff_spconv_fwd_split3 takes) through the three-way split bf16 kernel: fp32 in, fp32 out, fp32 accuracy (include/lidiff_amd.h).
+# LIDIFF_SPLIT3=0: every layer on the native fp32-MFMA kernel.
+SPLIT3 = os.environ.get("LIDIFF_SPLIT3", "1") != "0"
+SPLIT3_MIN_STRIDE = int(os.environ.get("LIDIFF_SPLIT3_MIN_STRIDE", "8"))
+SPLIT3_MIN_ROWS = 8192          # smaller maps (the condition encoders) do not fill the chip with 256-row tiles
+
+
+class split3:
+    """Context manager: `with ops.split3(False):` runs the native fp32 kernel everywhere (A/B measurements, parity tests)."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global SPLIT3
+        self.prev, SPLIT3 = SPLIT3, self.on
+
+    def __exit__(self, *exc):
+        global SPLIT3
+        SPLIT3 = self.prev
+
+
+def split3_rows(x: torch.Tensor) -> torch.Tensor:
+    """fp32 rows [M, C] -> bf16 [M, 3, C]: every value as the exact sum of three bf16 pieces (lidiff_split3_rows) -- the operand
+    layout of spconv_fwd_split3.  Kept on the tensor object (`_lidiff_split3`): consumers of one tensor share the cut."""
+    hit = getattr(x, "_lidiff_split3", None)
+    if hit is not None and hit[0] == (x.data_ptr(), x._version, tuple(x.shape)):
+        return hit[1]
+    require_device(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 8 == 0
+    x = x.contiguous()
+    out = torch.empty((x.shape[0], 3, x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    call("lidiff_split3_rows", ptr(x), x.shape[0], x.shape[1], ptr(out), stream_ptr())
+    try:
+        x._lidiff_split3 = ((x.data_ptr(), x._version, tuple(x.shape)), out)
+    except AttributeError:
+        pass
+    return out
+
+
+def split3_conv_applies(c_in_a: int, c_in_b: int, c_out: int) -> bool:
+    return bool(_lib.load().lidiff_spconv_fwd_split3_supported(int(c_in_a), int(c_in_b), int(c_out)))
+
+
+def spconv_fwd_split3(in_a, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int, in_b=None, scale=None, shift=None,
+                      residual=None, relu: bool = False, replicas: int = 1, d_rows: torch.Tensor | None = None,
+                      want_planes: bool = False) -> torch.Tensor:
+    """spconv_fwd (fp32 in, fp32 out, fp32 accuracy) with the contraction on the bf16 matrix pipe from three-way split operands
+    (lidiff_spconv_fwd_split3; include/lidiff_amd.h).  in_a / in_b: fp32 [R * M_in, C] (cut here, the cut cached on the
+    tensor) or the bf16 [R * M_in, 3, C] pieces themselves.  want_planes: the result carries its own pieces
+    (`_lidiff_split3`, written by the kernel's epilogue) for the next dense convolution."""
+    require_device(w, nbr, scale, shift, residual)
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    k, c_in, c_out = w3.shape
+    wp = packed_weights_bf16(w, planes=3)
+    a3 = in_a if in_a.dtype == torch.bfloat16 else split3_rows(in_a)
+    b3 = None if in_b is None else (in_b if in_b.dtype == torch.bfloat16 else split3_rows(in_b))
+    assert a3.dim() == 3 and a3.shape[1] == 3 and a3.is_contiguous() and a3.shape[0] % replicas == 0
+    c_a, c_b = a3.shape[2], 0 if b3 is None else b3.shape[2]
+    assert c_a + c_b == c_in, f"channel mismatch {c_a}+{c_b} != {c_in}"
+    m_in = a3.shape[0] // replicas
+    if nbr is not None:
+        assert nbr.shape == (k, m_out) and nbr.dtype == torch.int32 and nbr.is_contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == (replicas * m_out, c_out)
+    out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=a3.device)
+    out3 = torch.empty((replicas * m_out, 3, c_out), dtype=torch.bfloat16, device=a3.device) if want_planes else None
+    prof = PROFILER
+    timed = prof is not None and prof.wants("split3")
+    start = end = None
+    if timed:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.join_pending()
+        start.record()
+    call("lidiff_spconv_fwd_split3", ptr(a3), c_a, ptr(b3), c_b, ptr(wp), ptr(nbr), k, m_in, m_out, c_out, ptr(out), ptr(out3),
+         ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), ptr(d_rows), stream_ptr())
+    if timed:
+        end.record()
+    if prof is not None:
+        prof.launches.append(("split3", start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
+    if out3 is not None:
+        out._lidiff_split3 = ((out.data_ptr(), out._version, tuple(out.shape)), out3)
     return out
 
 

@@ -790,6 +790,107 @@ def test_spconv_resident_workgroups_equal_the_plain_launch(device, cin, split, c
     assert torch.equal(s1, ref) and torch.equal(s2, ref)
 
 
+@pytest.mark.parametrize("cin,split,cout", [(128, 0, 128), (256, 0, 256), (64, 0, 128), (256, 128, 256), (128, 0, 256), (192, 128, 128)])
+def test_spconv_pingpong_schedule_is_bit_identical(device, cin, split, cout):
+    """LIDIFF_CONV_PINGPONG (round 6): the dense 128-column tiles with the two waves of every SIMD alternating between a stage's
+    MFMAs and everything else (gather requests two stages ahead from the second half of the waves, flush, W loads; two barriers
+    per stage) -- the same MFMA sequence per output and the same flush order as the plain schedule: bit-identical, on dense
+    and on nearly empty maps (few work items, tiles without a pair), the CFG pair stacked, a ragged last tile, fused ME.cat, a
+    device-side row count, every epilogue; and against the float64 oracle."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(3 + cin + cout)
+    for n_pts, extent in ((60000, 14), (3000, 40), (130, 3)):
+        cloud = random_cloud(n_pts, extent, 17 + n_pts)
+        uniq, _, _ = me.voxelize(cloud)
+        nbr_np = me.kernel_map(uniq, uniq, 3, 1)
+        nbr = dev_i32(nbr_np, device)
+        m = uniq.shape[0]
+        for reps in (1, 2):
+            x = torch.randn(reps * m, cin, generator=g)
+            w = torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)
+            sc, sh, res = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g), torch.randn(reps * m, cout, generator=g)
+            xd = x.to(device)
+            a = xd[:, :split].contiguous() if split else xd
+            kw = dict(in_b=xd[:, split:].contiguous() if split else None, scale=sc.to(device), shift=sh.to(device),
+                      residual=res.to(device), relu=True, replicas=reps)
+            ref = ops.spconv_fwd(a, w.to(device), nbr, m, **kw)
+            for _ in range(2):
+                assert torch.equal(ops.spconv_fwd(a, w.to(device), nbr, m, kernel="pingpong", **kw), ref), (cin, cout, m, reps)
+            plain = ops.spconv_fwd(a, w.to(device), nbr, m, in_b=kw["in_b"], replicas=reps)
+            assert torch.equal(ops.spconv_fwd(a, w.to(device), nbr, m, in_b=kw["in_b"], replicas=reps, kernel="pingpong"), plain)
+            if m > 200:
+                rows = torch.tensor([m - 77], dtype=torch.int32, device=device)
+                ref_d = ops.spconv_fwd(a, w.to(device), nbr, m, d_rows=rows, **kw)
+                got_d = ops.spconv_fwd(a, w.to(device), nbr, m, d_rows=rows, kernel="pingpong", **kw)
+                for r in range(reps):
+                    assert torch.equal(got_d[r * m:r * m + m - 77], ref_d[r * m:r * m + m - 77])
+        pick = np.random.default_rng(5).choice(m, min(m, 2000), replace=False)
+        want = me.conv_forward(x[:m].double(), w.double(), nbr_np[:, pick])
+        want = torch.relu(want * sc.double() + sh.double() + res[:m][pick].double())
+        got = ops.spconv_fwd(a, w.to(device), nbr, m, kernel="pingpong", **kw)
+        assert torch.allclose(got[:m][pick].cpu().double(), want, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("cin,split,cout", [(128, 0, 128), (256, 0, 256), (384, 256, 256), (128, 0, 256), (192, 128, 128), (64, 0, 128)])
+def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout):
+    """lidiff_spconv_fwd_split3 (round 6): fp32 in / fp32 out with the contraction on the bf16 matrix pipe from three-way split
+    operands -- against the float64 oracle at the NATIVE fp32 kernel's own bars (RTOL / ATOL of this file), and its worst error
+    next to the native kernel's on the same inputs (recorded; asserted within 1.5x + one ulp of the output scale): dense and
+    nearly empty maps, tiles without a pair, the CFG pair stacked, a ragged last tile, fused ME.cat, every epilogue, a
+    device-side row count, the identity map (kernel_size 1), and the pieces of the OUTPUT written by the epilogue (their sum is
+    the fp32 output, bit for bit)."""
+    from lidiff_amd import ops
+    g = torch.Generator().manual_seed(5 + cin + cout)
+    worst = {}
+    for n_pts, extent in ((60000, 14), (3000, 40), (130, 3)):
+        cloud = random_cloud(n_pts, extent, 23 + n_pts)
+        uniq, _, _ = me.voxelize(cloud)
+        nbr_np = me.kernel_map(uniq, uniq, 3, 1)
+        nbr = dev_i32(nbr_np, device)
+        m = uniq.shape[0]
+        for reps in (1, 2):
+            x = torch.randn(reps * m, cin, generator=g) * (torch.rand(cin, generator=g) * 4 + 0.05)      # mixed channel scales
+            w = torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)
+            sc, sh, res = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g), torch.randn(reps * m, cout, generator=g)
+            xd = x.to(device)
+            a = xd[:, :split].contiguous() if split else xd
+            b = xd[:, split:].contiguous() if split else None
+            kw = dict(scale=sc.to(device), shift=sh.to(device), residual=res.to(device), relu=True, replicas=reps)
+            got = ops.spconv_fwd_split3(a, w.to(device), nbr, m, in_b=b, want_planes=True, **kw)
+            assert torch.equal(got, ops.spconv_fwd_split3(a, w.to(device), nbr, m, in_b=b, **kw))          # run to run
+            native = ops.spconv_fwd(a, w.to(device), nbr, m, in_b=b, **kw)
+            pick = np.random.default_rng(5).choice(m, min(m, 3000), replace=False)
+            for r in range(reps):
+                want = me.conv_forward(x[r * m:(r + 1) * m].double(), w.double(), nbr_np[:, pick])
+                want = torch.relu(want * sc.double() + sh.double() + res[r * m:(r + 1) * m][pick].double())
+                e3 = (got[r * m:(r + 1) * m][pick].cpu().double() - want).abs().max().item()
+                en = (native[r * m:(r + 1) * m][pick].cpu().double() - want).abs().max().item()
+                assert torch.allclose(got[r * m:(r + 1) * m][pick].cpu().double(), want, rtol=RTOL, atol=ATOL)
+                scale_out = want.abs().max().item()
+                assert e3 <= 1.5 * en + 1.2e-7 * scale_out, (cin, cout, m, e3, en)
+                worst[n_pts] = max(worst.get(n_pts, (0, 0)), (e3, en))
+            planes = got._lidiff_split3[1].float()
+            assert torch.equal(planes[:, 0] + planes[:, 1] + planes[:, 2], got)
+            assert torch.equal(planes, ops.split3_rows(got.clone()).float())
+            # no epilogue
+            plain = ops.spconv_fwd_split3(a, w.to(device), nbr, m, in_b=b, replicas=reps)
+            ref = ops.spconv_fwd(a, w.to(device), nbr, m, in_b=b, replicas=reps)
+            assert torch.allclose(plain, ref, rtol=1e-5, atol=1e-5)
+            if m > 300:
+                rows = torch.tensor([m - 77], dtype=torch.int32, device=device)
+                nbr_d = nbr.clone()
+                nbr_d[:, m - 77:] = -1
+                got_d = ops.spconv_fwd_split3(a, w.to(device), nbr_d, m, in_b=b, d_rows=rows, **kw)
+                for r in range(reps):
+                    assert torch.equal(got_d[r * m:r * m + m - 77], got[r * m:r * m + m - 77])
+    # kernel_size 1 (identity map)
+    w1 = torch.randn(1, cin, cout, generator=g) / np.sqrt(cin)
+    got1 = ops.spconv_fwd_split3(a, w1.to(device), None, m, in_b=b, replicas=reps)
+    want1 = x.double() @ w1[0].double()
+    assert torch.allclose(got1.cpu().double(), want1, rtol=RTOL, atol=ATOL)
+    record_parity(f"split3_{cin}_{cout}", **{f"err_split3_vs_native_{k}": v for k, v in worst.items()})
+
+
 @pytest.mark.parametrize("m,c", [(2, 32), (37, 96), (5000, 256), (120001, 64), (70000, 128), (9, 4)])
 def test_batch_norm_train_kernels_vs_torch_float64(device, m, c):
     """lidiff_bn_stats / lidiff_bn_apply / lidiff_bn_bwd (ops._BatchNormTrain: the training-mode MinkowskiBatchNorm) against

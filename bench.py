@@ -37,6 +37,13 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0
+# what the path computes in when ops.SPLIT3 is on (the default): said in full, because it is NOT the plain fp32 MFMA everywhere
+DTYPE_SPLIT3 = ("f32 in / f32 out / f32 accumulate everywhere; kernel_size-3 convolutions of the dense levels (tensor stride >= 8, "
+                "C_out % 128 == 0): each fp32 operand cut into 3 bf16 pieces (exact sum), the 6 piece products with i + j <= 2 on "
+                "v_mfma_f32_16x16x32_bf16, dropped terms < 2^-24 |x w| -- error vs float64 equal to the native fp32 MFMA kernel's "
+                "(tests/test_gpu_kernels.py::test_spconv_split3_is_an_fp32_convolution; the whole GPU parity suite runs in this mode at "
+                "the native kernel's bars); every other kernel: native fp32 (v_mfma_f32_16x16x4_f32 / VALU). LIDIFF_SPLIT3=0: native "
+                "fp32 MFMA everywhere -- that number is `native_fp32` in this line")
 N_POINTS = 180000
 T_STEPS = 50
 
@@ -495,7 +502,7 @@ def pipeline_main(args, rank, world, device):
         "metric": "completed scans/sec (FPS + T=50 CFG denoising + refinement) on 180k-pt scans", "value": total / elapsed,
         "unit": "scans/s", "n_gpus": world, "rccl_ranks_seen": ranks_seen, "visible_devices": torch.cuda.device_count(),
         "scans": total, "scans_per_gpu": args.scans, "s_per_scan": elapsed / args.scans, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_SPLIT3 if ops.SPLIT3 else "f32", "data": "synthetic",
         "denoising_steps_per_s": total * T_STEPS / elapsed,
         "config": {"workload": "configs[2]: independent 180000-point scans (bundled scan, own noise seed each) sharded one per GPU, "
                                "DiffCompletion.complete_scan = range filter + FPS 18000 + T=50 sde-dpmsolver++ CFG loop (closed) + "
@@ -565,7 +572,7 @@ def main():
     ap.add_argument("--no-train", action="store_true",
                     help="skip the 'train' leg (configs[4]'s per-GPU training step, fp32 and bf16: 4 steps each)")
     ap.add_argument("--no-alt", action="store_true",
-                    help="skip the 'alt' leg (the same steps with the dense layers from two bf16 pieces per operand)")
+                    help="skip the 'native_fp32' leg (the same steps with every layer on the native fp32-MFMA kernel)")
     ap.add_argument("--pipeline", action="store_true",
                     help="time whole scans instead of denoising steps: DiffCompletion.complete_scan (FPS + T = 50 + refinement) on "
                          "--scans scans per rank, sharded over the ranks (BASELINE configs[2] / [3]); prints scans/s and s/scan")
@@ -622,7 +629,7 @@ def main():
         torch.cuda.synchronize()
         # (every 3rd launch of the dominant variant carries events: 40 launches per step, so over the steps every layer is
         # sampled; all of them cost ~0.4 ms per step of event records in the timed region)
-        prof = None if args.no_kernel_events else ops.ConvProfiler(None if args.all_variants else {"bn128"},
+        prof = None if args.no_kernel_events else ops.ConvProfiler(None if args.all_variants else {"bn128", "split3"},
                                                                    sample=1 if args.all_variants else 3)
         ops.PROFILER = prof
         ldist.barrier()
@@ -665,21 +672,21 @@ def main():
             saved = {k: getattr(pipe, k) for k in ("overlap_maps", "lazy_x_t", "encode_ahead")}
             pipe.overlap_maps = pipe.lazy_x_t = pipe.encode_ahead = False
             run_steps(pipe, x_init, wx, wt, 0, 1)
-            sprof = ops.ConvProfiler({"bn128"})
+            psum = prof.summary()
+            dom_variant = max(psum, key=lambda v: psum[v]["ms"])
+            sprof = ops.ConvProfiler({dom_variant})
             ops.PROFILER = sprof
             run_steps(pipe, x_init, xs, tvals, 0, args.steps)
             torch.cuda.synchronize()
             ops.PROFILER = None
             for k, v in saved.items():
                 setattr(pipe, k, v)
-        # beside the metric, never `value`: the same K steps with the dense 128-column layers computed from two bf16 pieces
-        # per operand (3 bf16 MFMAs per block, fp32 accumulation; ops.split_planes, lidiff_spconv_fwd_bf16 planes = 2)
+        # beside the metric: the same K steps with EVERY layer on the native fp32-MFMA kernel (ops.split3(False) / LIDIFF_SPLIT3=0)
         alt = None
-        if world == 1 and not args.no_alt:
-            rf, pipe.read_free = pipe.read_free, False          # (the bf16-split kernel takes exact row counts only)
-            with ops.split_planes(2):
-                run_steps(pipe, x_init, wx, wt, 0, 1)                   # packs the bf16 weight planes
-                aprof = None if args.no_kernel_events else ops.ConvProfiler({"bf16x2"})
+        if world == 1 and not args.no_alt and ops.SPLIT3:
+            with ops.split3(False):
+                run_steps(pipe, x_init, wx, wt, 0, 1)
+                aprof = None if args.no_kernel_events else ops.ConvProfiler({"bn128"}, sample=3)
                 ops.PROFILER = aprof
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -687,7 +694,6 @@ def main():
                 torch.cuda.synchronize()
                 alt = (time.perf_counter() - t0, aprof)
                 ops.PROFILER = None
-            pipe.read_free = rf
     elapsed = ldist.max_over_ranks(elapsed, device=device)
     if args.cached_condition:
         elapsed_cached = ldist.max_over_ranks(elapsed_cached, device=device)
@@ -699,7 +705,7 @@ def main():
         "n_gpus": world, "rccl_ranks_seen": ranks_seen, "visible_devices": torch.cuda.device_count(),
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE_SPLIT3 if ops.SPLIT3 else "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: one 180000-point scan (bundled scan FPS 18000 x10), voxel 0.05 m, "
                                "T=50 sde-dpmsolver++ trajectory, CFG w=6 (2 forwards/step), fp32, "
                                "random-init weights, offsets sigma_t*N(0,I) per step",
@@ -725,15 +731,28 @@ def main():
         tflops = d["flops_timed"] / (d["ms"] * 1e-3) / 1e12
         traffic, traffic_src = traffic_from_profile([dom])
         step_flops = sum(v["flops"] for v in summ.values()) / args.steps
+        s3 = dom == "split3"
+        # split3: the algorithm's matrix work is SIX bf16 x bf16 products per fp32 product -- `achieved` counts those against the
+        # dense bf16 MFMA peak; the fp32-equivalent rate (2 P C_in C_out / time) and what the pipe executes (rows without a
+        # neighbour are multiplied as zeros) stand beside it
+        ach, peak = (6.0 * tflops, PEAK_BF16_MFMA_TFLOPS) if s3 else (tflops, PEAK_F32_MFMA_TFLOPS)
         out["roofline"] = {
-            "kernel": f"spconv_fwd_kernel, BN={dom[2:]} output-channel tile ({dom})", "bound": "mfma",
-            "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
+            "kernel": ("spconv_fwd_split3_kernel<128> (256 x 128 register tiles, v_mfma_f32_16x16x32_bf16, 6 products per block)" if s3
+                       else f"spconv_fwd_kernel, BN={dom[2:]} output-channel tile ({dom})"), "bound": "mfma",
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "achieved_note": ("algorithmic: 6 bf16 MFMA products per fp32 product x 2 P C_in C_out per launch / HIP-event time, against the "
+                              "dense bf16 MFMA peak" if s3 else "algorithmic 2 P C_in C_out per launch / HIP-event time, against the fp32 MFMA peak"),
+            "fp32_equivalent_tflops": tflops, "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "fp32_equivalent_over_fp32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS,
+            "executed_mfma_tflops": d["mfma_flops_timed"] / (d["ms"] * 1e-3) / 1e12,
+            "executed_note": "what the matrix pipe runs, rows without a neighbour included (the wide tiles multiply them as zeros)" if s3 else None,
             "traffic": traffic, "launches": d["timed"], "avg_us": 1e3 * d["ms"] / max(1, d["timed"]),
             "traffic_unit": "GB per launch (HBM-side, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": None if traffic is None else f"static: {traffic_src} (tools/pmc_bench.sh over this bench "
                                                             "command; counters cannot be read inside the timed process)",
             "mfma_busy": mfma_busy_profile(),
             "step_frac": step_flops / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "step_frac_note": "all convolution flops of a step (fp32-equivalent, 2 P C_in C_out) / wall time / the fp32 MFMA peak -- with "
+                              "the dense levels on the bf16 pipe this is a rate, not a fraction of a roofline",
             "step_conv_gflop": step_flops / 1e9,
             "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_gbytes_per_launch": d["bytes"] / d["launches"] / 1e9,
@@ -744,7 +763,7 @@ def main():
                 "avg_us": 1e3 * q["ms"] / max(1, q["timed"]), "launches": q["timed"],
                 "note": "the same launches in a pass of the same steps with every stream overlap off (one queue: nothing runs beside "
                         "the kernel); `achieved` above is from the timed pass, where the side streams' kernels share the chip"})(
-                sprof.summary()["bn128"]),
+                sprof.summary()[dom_variant]),
             "timed_variants": sorted(k for k, v in summ.items() if v["timed"]),
             "conv_ms_per_step_timed_variants": sum(v["ms"] * v["launches"] / max(1, v["timed"]) for v in summ.values() if v["timed"]) / args.steps,
             "variants": {k: {"launches": v["launches"], "timed": v["timed"], "ms": round(v["ms"], 3),
@@ -756,7 +775,7 @@ def main():
         # intensity of the launch (algorithmic flops / algorithmic bytes) against the ridge point 157.3 TFLOP/s / 8 TB/s = 19.7
         # FLOP/B -- the 64 / 96-column kernel_size-3 layers and the wide row-kernel launches are MFMA-bound, the 32-channel
         # layers, the stems and the narrow row-kernel launches are HBM-bound; each class against ITS peak
-        narrow_variants = ("bn96", "bn64", "bn32", "bn16", "rows", "thin")
+        narrow_variants = ("bn96", "bn64", "bn32", "bn16", "rows", "thin") + (("bn128",) if ops.SPLIT3 else ())
         split = ops.launches_by_bound(vprof or prof, PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9), narrow_variants)
         tiny = split.pop("tiny")
         if tiny["launches"]:
@@ -797,22 +816,18 @@ def main():
                 "layers": layers}
     if alt is not None:
         a_elapsed, aprof = alt
-        out["alt"] = {
-            "dtype": "f32 from 2 bf16 pieces per operand (x1 w1 + x1 w2 + x2 w1: 3 bf16 MFMAs, fp32 accumulate) on the dense "
-                     "128-column layers; every other kernel native fp32",
+        out["native_fp32"] = {
+            "dtype": "f32: every convolution on the native fp32 matrix instruction (v_mfma_f32_16x16x4_f32), ops.split3(False) / LIDIFF_SPLIT3=0",
             "value": args.steps / a_elapsed, "unit": "steps/s", "ms_per_step": 1e3 * a_elapsed / args.steps,
-            "note": "opt-in (ops.split_planes(2) / LIDIFF_SPLIT_PLANES=2), never the metric: products keep 16-17 bits "
-                    "(per-layer error 10-15x the native fp32 kernel's, inside the 1e-4 parity bar; DESIGN.md 4.3)"}
+            "note": "the same K steps, same process, right after the timed pass; `value` above is the default configuration"}
         if aprof is not None:
-            d = aprof.summary().get("bf16x2")
+            d = aprof.summary().get("bn128")
             if d and d["ms"] > 0:
-                tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                out["alt"]["roofline"] = {
-                    "kernel": "spconv_fwd_bf16_kernel, planes = 2", "bound": "mfma", "achieved": tf,
-                    "peak": PEAK_BF16_MFMA_TFLOPS / 3.0, "unit": "TFLOP/s (fp32-equivalent: 2 P C_in C_out per launch)",
-                    "frac": tf / (PEAK_BF16_MFMA_TFLOPS / 3.0), "launches": d["timed"],
-                    "avg_us": 1e3 * d["ms"] / max(1, d["timed"]),
-                    "peak_note": "dense bf16 MFMA peak / 3 MFMAs per block"}
+                tf = d["flops_timed"] / (d["ms"] * 1e-3) / 1e12
+                out["native_fp32"]["roofline"] = {
+                    "kernel": "spconv_fwd_kernel, BN=128 output-channel tile (bn128)", "bound": "mfma", "achieved": tf,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "launches": d["timed"],
+                    "avg_us": 1e3 * d["ms"] / max(1, d["timed"])}
     if world == 1 and not args.no_coords_roofline:
         with torch.no_grad():
             out["roofline_hbm"] = coords_roofline(scan_np, device)
@@ -830,29 +845,6 @@ def main():
                         "seeded random-init weights -- the offsets do not contract as with trained weights (they grow to ~1 / alpha_T), "
                         "so the maps are sparser than on the metric's sigma_t trajectory; parity of this loop against the oracle: "
                         "tests/test_gpu_baseline.py::test_closed_loop_c2_chamfer_vs_oracle"}
-        # the same scan with the per-step kernel sequence captured as a HIP graph (DiffCompletion.graph_steps: conditions encoded
-        # once per scan, the step body replayed while its kernel choices hold), and -- for a like-for-like eager number -- with the
-        # conditions cached but every step queued by the host.  Beside the metric, never `value`.
-        variants = {}
-        with torch.no_grad():
-            for name, flags in (("eager_cached_conditions", {"cache_condition": True}), ("graph_steps", {"graph_steps": True})):
-                keep = {k: getattr(pipe, k) for k in flags}
-                for k, v in flags.items():
-                    setattr(pipe, k, v)
-                try:
-                    pipeline_leg(pipe, device, [5000], warm=False)            # (first use: captures / allocator growth, untimed)
-                    per, ph, _ = pipeline_leg(pipe, device, [5000], warm=False)
-                    variants[name] = {"s_per_scan": per[0], "ms_per_denoising_step": 1e3 * ph["denoise_s"] / T_STEPS}
-                    if name == "graph_steps":
-                        variants[name]["steps"] = dict(pipe.graph_stats or {})
-                finally:
-                    for k, v in keep.items():
-                        setattr(pipe, k, v)
-        out["closed_loop"]["variants"] = variants
-        out["closed_loop"]["variants_note"] = (
-            "graph_steps: SURVEY 8(f) row 1 (step-invariant caching + the per-step kernel sequence as a HIP graph) -- bit-identical to "
-            "the eager loop with cached conditions (tests/test_gpu_readfree.py); `steps` = how many of the T steps ran eagerly / were "
-            "captures / replays (a graph holds while the kernel choices, which follow the previous step's map sizes, stand still)")
     if world == 1 and not args.no_train:
         del pipe
         torch.cuda.empty_cache()

@@ -36,8 +36,6 @@ extern "C" {
                                        steps, lidiff_tail_map_fill_bounded): nothing was overrun, the results of the step are void */
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
 #define LIDIFF_CONV_TILE_128 16     /* 64-column layers on 128-row tiles as well (default: 256-row tiles for large maps; A/B measurements) */
-#define LIDIFF_CONV_PERSIST 32      /* tile kernels as resident workgroups that pull tile slots from per-XCD counters (A/B measurements) */
-#define LIDIFF_CONV_PINGPONG 64     /* dense 128-column tiles: the two waves of a SIMD alternate between MFMAs and everything else (round 6; bit-identical) */
 #define LIDIFF_CONV_TILE_ONLY 8     /* identity maps (nbr == NULL) through the tile kernel as well, not the row kernel (A/B measurements, tests) */
 
 int lidiff_abi_version(void);
@@ -183,12 +181,6 @@ int lidiff_tail_map_fill_bounded(const int32_t* nbr, int32_t k_vol, int64_t m_bo
 int lidiff_host_device_pointer(void* host_ptr, void** dev_ptr);
 int lidiff_publish_words(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* host_mapped, int32_t seq,
                          void* stream);
-/* ... with the sequence number on the device (*d_seq is incremented by the launch) and the record's slot -- ring_mapped +
- * (seq % slots) * slot_words -- derived from it: no per-record argument, so a captured HIP graph that holds the launch can be
- * replayed for every step of a trajectory. */
-int lidiff_publish_words_seq(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* ring_mapped, int32_t slots,
-                             int32_t slot_words, int32_t* d_seq, void* stream);
-
 /* Weight layout of the sparse convolution.  MinkowskiConvolution.kernel is [K, c_in, c_out] row-major
  * (minkunet.py:17,36,53,61; [c_in, c_out] for kernel_size 1, :72).  The HIP kernel consumes it in MFMA
  * fragment order: [K][slab = ceil(c_in/32)][c_out/16][j 0..1][lane 0..63][e 0..3] with
@@ -261,19 +253,16 @@ int lidiff_spconv_fwd_pairs(const float* in_a, int32_t c_in_a, const float* in_b
                             const float* ep_scale, const float* ep_shift, const float* residual, int32_t relu,
                             int32_t replicas, void* stream);
 
-/* lidiff_spconv_fwd with bf16 matrix operands and fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Features, BatchNorm and
- * the epilogue stay fp32 in HBM; each gathered input value is cut into `planes` bf16 pieces (round to nearest even:
- * x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)) as it enters the matrix unit, the weights likewise when they are
- * packed (lidiff_spconv_pack_weights_bf16, once per weight version), and all products x_i w_j with i + j <= planes + 1 are
- * summed in fp32 (1, 3 or 6 MFMAs per 16 x 16 x 32 block).
- *   planes = 1: the mixed-precision TRAINING convolution (train.py under bf16; models.py:180-217): forward and, over the
- *               swapped map with W^T, the input gradient.  Equal to lidiff_spconv_fwd on bf16-rounded inputs and weights up
- *               to fp32 summation order.
- *   planes = 2, 3: fp32-accurate results from bf16 pieces (opt-in inference mode; error of a K = 6912 dot product relative to
- *               sum |x w|: 2.5e-7 / 1.3e-7 against 1.1e-7 of the native fp32 MFMA).
+/* lidiff_spconv_fwd with bf16 matrix operands and fp32 accumulation (v_mfma_f32_16x16x32_bf16): the mixed-precision TRAINING
+ * convolution (train.py under bf16; models.py:180-217) -- forward and, over the swapped map with W^T, the input gradient.
+ * Features, BatchNorm and the epilogue stay fp32 in HBM; each gathered input value is rounded to bf16 (nearest even) as it enters
+ * the matrix unit, the weights when they are packed (lidiff_spconv_pack_weights_bf16 with planes = 1, once per weight version).
+ * Equal to lidiff_spconv_fwd on bf16-rounded inputs and weights up to fp32 summation order.  `planes` must be 1 (rounds 1-5
+ * also built fp32-accurate results from 2 / 3 pieces per operand on this kernel; that is lidiff_spconv_fwd_split3 now).  The
+ * weight packer cuts 1..3 pieces: piece 0 = bf16(w), piece 1 = bf16(w - piece 0), piece 2 = bf16(w - piece 0 - piece 1).
  * Input widths and c_out multiples of 32; same map / epilogue / replica arguments as lidiff_spconv_fwd (no row order, no
  * tail).
- * in_bf16 != 0 (planes = 1 only; 1 = the library picks the kernel, 2 / 3 force the ring / the two-stage kernel -- bit-identical,
+ * in_bf16 != 0 (1 = the library picks the kernel, 2 / 3 force the ring / the two-stage kernel -- bit-identical,
  * for A/B measurements and tests): in_a / in_b point at bf16 rows -- the shadow copy of the fp32 feature matrix that its producer or
  * lidiff_cast_bf16 left (bf16 activations in HBM, the bf16 training configuration): half the gather traffic and requests, no
  * conversion in the kernel; the same operands, products and order of sums, i.e. bit-identical to in_bf16 = 0 on the fp32 rows.
@@ -457,16 +446,6 @@ int lidiff_cfg_dpm_step(const float* eps_cond, const float* eps_uncond, float w,
                         const double* m_prev, const double* noise, float sigma_t, double inv_alpha_t, double c_sample, double c_m0,
                         double c_d1, double inv_r0, double c_noise, float inv_resolution, int64_t n_points, int64_t n_per_batch,
                         int32_t scale_batch_column, double* x0_out, float* feats_out, int32_t* coords_out, void* stream);
-/* lidiff_cfg_dpm_step with everything that changes from step to step read from DEVICE memory: row *d_step of coef_table [T][8]
- * doubles (sigma_t, 1 / alpha_t, c_sample, c_m0, c_d1, 1 / r0, c_noise, second-order flag: the scalars of lidiff_cfg_dpm_step) and
- * of noise_table [T][3 n_points] (nullable: no noise term); m_prev must point at a buffer (read only when the row's flag is set).
- * The same arithmetic, operation by operation; no per-step argument, so ONE captured HIP graph serves every step of a trajectory
- * (DiffCompletion.graph_steps; SURVEY 8(f) row 1: "HIP-graph the per-step kernel sequence"). */
-int lidiff_cfg_dpm_step_table(const float* eps_cond, const float* eps_uncond, float w, const float* x_t, const double* x_init,
-                              const double* m_prev, const double* noise_table, const double* coef_table, const int32_t* d_step,
-                              float inv_resolution, int64_t n_points, int64_t n_per_batch, int32_t scale_batch_column, double* x0_out,
-                              float* feats_out, int32_t* coords_out, void* stream);
-
 /* points_to_tensor alone (pipeline:68-84; models.py:162-178 with scale_batch_column = 0): [B, n, 3] points, fp64 (is_f64 != 0)
  * or fp32 -> fp32 features [B n, 3] and int32 voxel coordinates [B n, 4], one launch. */
 int lidiff_points_to_field(const void* points, int32_t is_f64, float inv_resolution, int64_t n_points, int64_t n_per_batch,

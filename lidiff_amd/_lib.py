@@ -63,8 +63,6 @@ SIGNATURES = {
     "lidiff_cfg_dpm_step": (_i32, [_p, _p, C.c_float, _p, _p, _p, _p, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_double, C.c_float, _i64, _i64, _i32, _p, _p, _p, _p]),
     "lidiff_points_to_field": (_i32, [_p, _i32, C.c_float, _i64, _i64, _i32, _p, _p, _p]),
-    "lidiff_cfg_dpm_step_table": (_i32, [_p, _p, C.c_float, _p, _p, _p, _p, _p, _p, C.c_float, _i64, _i64, _i32, _p, _p, _p, _p]),
-    "lidiff_publish_words_seq": (_i32, [_p, _i32, _p, _p, _i32, _i32, _p, _p]),
     "lidiff_bn_sums": (_i32, [_p, _i64, _i32, _p, _p, _p]),
     "lidiff_bn_stats_from_sums": (_i32, [_p, _i32, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p]),
     "lidiff_bn_bwd_sums": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),

@@ -706,27 +706,6 @@ __global__ void publish_kernel(const int32_t* __restrict__ words, int n, const i
     }
 }
 
-// ... with the sequence number kept on the DEVICE (*d_seq, incremented here) and the ring slot derived from it: the launch has no
-// per-record argument, so a captured HIP graph that contains it can be replayed step after step (DiffCompletion.graph_steps)
-__global__ void publish_seq_kernel(const int32_t* __restrict__ words, int n, const int32_t* __restrict__ d_status,
-                                   volatile int32_t* __restrict__ ring, int slots, int slot_words, int32_t* __restrict__ d_seq) {
-    __shared__ int32_t seq_s;
-    if (threadIdx.x == 0) seq_s = *d_seq + 1;
-    __syncthreads();
-    const int32_t seq = seq_s;
-    volatile int32_t* host = ring + (int64_t)(seq % slots) * slot_words;
-    const int i = threadIdx.x;
-    if (i < n) host[2 + i] = words[i];
-    if (i == 0) host[1] = d_status ? *d_status : 0;
-    __threadfence_system();
-    __syncthreads();
-    if (i == 0) {
-        host[0] = seq;
-        *d_seq = seq;
-        __threadfence_system();
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // row gather / scatter-add
 template <bool VEC4>
@@ -1762,15 +1741,6 @@ int lidiff_publish_words(const int32_t* words, int32_t n_words, const int32_t* d
                          void* stream) {
     LIDIFF_CHECK_ARG(words != nullptr && host_mapped != nullptr && n_words >= 0 && n_words <= 62, "up to 62 words");
     publish_kernel<<<1, 64, 0, (hipStream_t)stream>>>(words, n_words, d_status, host_mapped, seq);
-    LIDIFF_CHECK_LAUNCH();
-    return 0;
-}
-
-int lidiff_publish_words_seq(const int32_t* words, int32_t n_words, const int32_t* d_status, int32_t* ring_mapped, int32_t slots,
-                             int32_t slot_words, int32_t* d_seq, void* stream) {
-    LIDIFF_CHECK_ARG(words && ring_mapped && d_seq && n_words >= 0 && n_words <= 62 && slots >= 1 && slot_words >= n_words + 2,
-                     "up to 62 words per slot");
-    publish_seq_kernel<<<1, 64, 0, (hipStream_t)stream>>>(words, n_words, d_status, ring_mapped, slots, slot_words, d_seq);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

@@ -32,8 +32,6 @@ struct ConvParams {
                                 //   pitch of nbr / of the stacked replicas and bounds the grid): tiles behind it leave at once
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
     int tiles_m, tiles_n, flags, replicas;
-    int32_t* queue;           // LIDIFF_CONV_PERSIST: 8 tile counters (one per XCD) + a count of finished workgroups, all zero at
-    int bids;                 //   launch and zeroed again by the last workgroup to leave; `bids` = tile slots of the plain grid
     int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
                               // 2 = no barrier, 4 = no flush
     long long* timeline;      // LIDIFF_CONV_PROBE builds only: 8 cycle counters per workgroup (tools/conv_probe.py)

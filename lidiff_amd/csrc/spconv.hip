@@ -31,8 +31,6 @@
 //
 // Replaces ME's ConvolutionForwardGPU (gather -> GEMM -> atomic scatter per offset) behind
 // MinkowskiConvolution / MinkowskiConvolutionTranspose; call sites in include/lidiff_amd.h.
-#include <atomic>
-#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -70,21 +68,8 @@ struct ConvCfg {
     }
 };
 
-// LIDIFF_CONV_PERSIST: the next tile slot of a resident workgroup.  Slots keep their XCD (slot & 7 -- the column tiles of a row
-// tile and their gathers stay in one L2): a workgroup serves its own XCD's queue first and the others' when that is empty.
-__device__ __forceinline__ int next_tile_slot(const ConvParams& p) {
-    const int groups = p.bids >> 3, home = blockIdx.x & 7;
-    for (int j = 0; j < 8; ++j) {
-        const int q = (home + j) & 7;
-        if (j > 0 && __atomic_load_n(&p.queue[q], __ATOMIC_RELAXED) >= groups) continue;
-        const int g = atomicAdd(&p.queue[q], 1);
-        if (g < groups) return 8 * g + q;
-    }
-    return -1;
-}
-
 // One tile slot `bid` of the launch: everything from the pair lists to the epilogue.
-template <int BM, int WN, int WM, int KS, bool VEC, bool PP = false>
+template <int BM, int WN, int WM, int KS, bool VEC>
 __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int bid) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
     ConvParams p = p_launch;                     // per-replica view (pointers moved below)
@@ -93,12 +78,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
     constexpr int NCHK = KS / 4;                 // 16-byte chunks per image row
     constexpr int RPI = 64 / NCHK;               // image rows per LDS-DMA wave-instruction (1 KB)
     constexpr int NINST = kChunk / RPI;          // DMA instructions per full stage
-    // PP ("ping-pong", round 6): the two waves of a SIMD alternate between the stage's MFMAs and everything else (flush, W
-    // loads, gather requests) -- see run_item.  The gather requests of an image then all come from the second half of the
-    // waves (the half whose "everything else" phase lies beside the first half's MFMAs of the stage before).
-    static_assert(!PP || (VEC && NW % 2 == 0 && NINST % (NW / 2) == 0), "ping-pong: vector gather, an even wave count");
-    constexpr int NWD = NW;                      // waves that issue gather requests
-    constexpr int T = (NINST + NWD - 1) / NWD;   // ... per (issuing) wave
+    constexpr int T = (NINST + NW - 1) / NW;     // ... per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* a_buf = reinterpret_cast<float*>(smem);
     float* acc_lds = a_buf + 2 * AF;
@@ -158,8 +138,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int wn = wave % WN, wm = wave / WN;
-    const bool is_b = PP && wave >= NW / 2;                      // second half: one wave of each SIMD (waves w and w + 4 share one)
-    const int dwave = wave;                                      // index among the waves that issue gather requests
     STAMP(t_start);
 #ifdef LIDIFF_CONV_PROBE
     const long long rt_start = __builtin_amdgcn_s_memrealtime();      // 100 MHz wall clock
@@ -228,7 +206,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
     // (stride-1/2 levels: ~1-2 neighbours per voxel) a stage per offset is almost empty and the tile is
     // bound by per-stage latency, so such tiles split the stage into SEG segments of 128/SEG rows, each
     // with its own offset (own W fragment registers).  Decided per tile from its own pair counts.
-    constexpr int SEG = (VEC && KS == 32 && !PP) ? (WM == 1 ? 4 : 8) : 1;   // segments per stage in packed mode
+    constexpr int SEG = (VEC && KS == 32) ? (WM == 1 ? 4 : 8) : 1;   // segments per stage in packed mode
     constexpr int SEGR = kChunk / SEG, BPS = SEGR / 16;               // rows / row blocks per segment
     bool packed = false;
     if constexpr (SEG > 1) {
@@ -281,7 +259,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
     int chb[T];                                           // byte offset of the source chunk inside a slab row
 #pragma unroll
     for (int j = 0; j < T; ++j) {
-        const int r = RPI * (dwave + NWD * j) + lane / NCHK;
+        const int r = RPI * (wave + NW * j) + lane / NCHK;
         chb[j] = 16 * ((lane % NCHK) ^ swz(r));
     }
     int list_base = 0;                                    // in_list offset of the item being gathered
@@ -296,8 +274,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
         if constexpr (VEC) {
 #pragma unroll
             for (int j = 0; j < T; ++j) {
-                const int r = RPI * (dwave + NWD * j) + lane / NCHK;
-                rowv[j] = (r < it.n && (T * NWD == NINST || dwave + NWD * j < NINST)) ? in_list[list_base + r] : -1;
+                const int r = RPI * (wave + NW * j) + lane / NCHK;
+                rowv[j] = (r < it.n && (T * NW == NINST || wave + NW * j < NINST)) ? in_list[list_base + r] : -1;
             }
             set_rowoff(p.c_in_a * 4);
         }
@@ -307,7 +285,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
 
     // Loads of one stage: A by LDS-DMA into the image at byte offset `img`, this wave's W fragment of
     // (offset k, slab) into w[].  `n` = pair rows of the stage's item, whose rows are in rowv[].
-    auto issue_w = [&](int k, int slab, f32x4* w) {
+    auto issue = [&](int img, int k, int slab, int n, f32x4* w) {
         if (!PROBE(2)) {
             __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(p.wp), 0, (int)((size_t)p.k_vol * nslab32 * 32 * p.c_out * 4), 0x00020000);
@@ -318,8 +296,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
                 w[2 * h + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_lane_off + 1024, ws + h * w_slab_bytes, 0));
             }
         }
-    };
-    auto issue_a = [&](int img, int slab, int n) {
         const int k0 = slab * KS;
         if constexpr (VEC) {
             const bool from_a = k0 < p.c_in_a;                 // uniform: slabs never straddle a|b
@@ -332,11 +308,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
             char* dst = reinterpret_cast<char*>(a_buf) + img;
 #pragma unroll
             for (int j = 0; j < T; ++j) {                      // RPI rows x KS*4 B per wave-instruction; no branches,
-                const int t = dwave + NWD * j;                 // no per-stage VALU: the slab offset rides in soffset
+                const int t = wave + NW * j;                   // no per-stage VALU: the slab offset rides in soffset
                 // (an instruction whose RPI rows all lie behind the item's last pair is not issued: those image rows feed only
                 // accumulator rows that are flushed into the dummy row, and every vector-memory instruction costs the SIMD
                 // ~100 cycles of issue while fp32 MFMAs are queued -- wave-uniform test, scalar branch)
-                if ((T * NWD == NINST || t < NINST) && RPI * t < n && !PROBE(1)) {
+                if ((T * NW == NINST || t < NINST) && RPI * t < n && !PROBE(1)) {
                     const int voff = rowoff[j];
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + t * 1024), 16, voff, cb4, 0, 0);
                 }
@@ -354,10 +330,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
             }
         }
     };
-    auto issue = [&](int img, int k, int slab, int n, f32x4* w) {
-        issue_w(k, slab, w);
-        issue_a(img, slab, n);
-    };
 
     // float offset of this lane's chunk (channels 16 j + 4 lq .. +3 of row li) for the 16-channel group j
     int foff[NJ];
@@ -367,23 +339,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
     constexpr int IMG = AF * 4;                           // bytes per A image
     int img = 0;                                          // byte offset of the image being multiplied
     f32x4 wc[NJ], wnx[NJ];                                // W fragments: current stage / next stage
-
-    // PP: the gather requests run TWO stages ahead of the issuing wave's own MFMAs (see run_item): a cursor over the stages in
-    // work-list order -- (item, slab), the image it fills, the item's gather rows in rowv[] / rowoff[]
-    int d_wi = 0, d_slab = 0, d_img = 0, d_n = 0;
-    auto dma_next = [&]() {
-        if constexpr (PP) {
-            if (d_wi >= nwork) return;                    // (wave-uniform)
-            if (d_slab == 0) {
-                const Item it = load_item(d_wi);
-                load_rows(it);
-                d_n = it.n;
-            }
-            issue_a(d_img, d_slab, d_n);
-            d_img ^= IMG;
-            if (++d_slab == nslab) { d_slab = 0; ++d_wi; }
-        }
-    };
 
     // One work item (offset, chunk) with NB active row blocks for this wave: all its slabs, straight-line
     // per stage (the only branches are the slab loop and the barrier).  MFMA step (j, e) takes
@@ -449,87 +404,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
 #else
 #define PHASE(acc, from)
 #endif
-        auto flush = [&]() {
-            if constexpr (NB > 0) {
-                if (!PROBE(16)) {
-                    // per element: its list word (one b128 read per block), one address add, read, add, write.
-                    // Round 3 tried two other forms, both measured and dropped (profiles/r03_dense_ablation.txt):
-                    //  * the add inside the MFMA -- accumulators initialised from the tile rows, written back after the last slab, no
-                    //    VALU arithmetic: +2 % on 256 -> 256, +4.6 % on 128 -> 128 at stride 8, but one 27 x C_in-term fp32 chain per
-                    //    output instead of 27 short ones: 10x the rounding error against the float64 oracle (5.1e-5 vs 4.7e-6);
-                    //  * list words, addresses and tile reads issued in FRONT of the last slab's MFMAs (they do not depend on the
-                    //    results): 252 VGPRs, 4-7 % SLOWER (98 -> 94 TFLOP/s on 256 -> 256, 84 -> 78 on 128 -> 128).
-                    // The MFMAs run with the operands SWAPPED (W fragment as A, the gathered rows as B): the transposed product
-                    // leaves in each lane four CONSECUTIVE channels (16 wn + 4 lq .. + 3) of ONE pair row (16 b + li) -- one 16-byte
-                    // read-modify-write of the tile per block instead of four 4-byte ones to four different rows, one list word per
-                    // block instead of four (round 4; the sums and their order are the same: bit-identical results).
-                    const OutT* ol = out_list + item.k * BM + item.start + li;
-                    char* accb = reinterpret_cast<char*>(acc_lds);
-                    int addr[NB > 0 ? NB : 1];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) addr[b] = tile_addr((int)ol[16 * (wm + WM * b)], 4 * wn + lq);
-                    f32x4 old[NB > 0 ? NB : 1];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) old[b] = *reinterpret_cast<const f32x4*>(accb + addr[b]);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) *reinterpret_cast<f32x4*>(accb + addr[b]) = old[b] + acc[b];
-                }
-            }
-        };
-        if constexpr (PP) {
-            // Ping-pong schedule (round 6).  The plain schedule below runs all eight waves through "requests, MFMAs, flush,
-            // barrier" in lockstep: the two waves of a SIMD want the matrix pipe at the same time, and at the end of every stage
-            // the pipe idles while the later of the two finishes its requests and flush (profiles/r04_conv_timeline_session3.txt:
-            // 2 x 1 877 cycles of MFMAs in a 5 745-cycle stage).  Here a stage is two intervals with a barrier after each:
-            //     first half  (waves 0 .. 3):   MFMAs(g) | flush(g), W(g+1)            | MFMAs(g+1) | ...
-            //     second half (waves 4 .. 7):   ...      | MFMAs(g)                    | gather(g+2), flush(g), W(g+1) | ...
-            // -- one wave of every SIMD multiplies while its partner does everything else.  The second half issues ALL gather
-            // requests of an image, two stages ahead of its own MFMAs: into the image both halves have just finished with, a whole
-            // interval before the first half reads it.  Same MFMA sequence per output and same flush order as the plain
-            // schedule: bit-identical results.
-            auto bar = [&]() {
-#ifdef LIDIFF_CONV_PROBE
-                STAMP(tb0);
-                if (!PROBE(4)) __syncthreads();
-                t_barrier += __builtin_readcyclecounter() - tb0;
-#else
-                __syncthreads();
-#endif
-            };
-            for (int s = 0; s < nslab; ++s) {
-                const bool last = s + 1 == nslab;
-                if (p.flags & 256) __builtin_amdgcn_s_setprio(1);
-                mma();
-                if (p.flags & 256) __builtin_amdgcn_s_setprio(0);
-                PHASE(t_mma, tp);
-                bar();                                    // the partner half's turn at the matrix pipe
-#ifdef LIDIFF_CONV_PROBE
-                tp = __builtin_readcyclecounter();
-#endif
-                if (p.flags & 128) __builtin_amdgcn_s_setprio(2);
-                dma_next();                               // first: the requests' latency runs beside the flush and the W loads
-                PHASE(t_issue, tp);
-                if (last) {
-                    STAMP(tf0);
-                    flush();
-#ifdef LIDIFF_CONV_PROBE
-                    t_flush += __builtin_readcyclecounter() - tf0;
-                    tp = __builtin_readcyclecounter();
-#endif
-                }
-                if (!last) issue_w(item.k, s + 1, wnx);
-                else if (has_next) issue_w(next.k, 0, wnx);
-                PHASE(t_issue, tp);
-                if (p.flags & 128) __builtin_amdgcn_s_setprio(0);
-                if (!(is_b && last && !has_next)) bar();  // (the second half started one barrier late: it skips the last one)
-#ifdef LIDIFF_CONV_PROBE
-                tp = __builtin_readcyclecounter();
-#endif
-#pragma unroll
-                for (int h = 0; h < NJ; ++h) wc[h] = wnx[h];
-                img ^= IMG;
-            }
-        } else {
         for (int s = 0; s + 1 < nslab; ++s) {             // not the last slab: the next stage is the same item
             issue(img ^ IMG, item.k, s + 1, item.n, wnx);
             PHASE(t_issue, tp);
@@ -548,12 +422,35 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
         mma();
         PHASE(t_mma, tp);
         STAMP(tf0);
-        flush();
+        if constexpr (NB > 0) {
+            if (!PROBE(16)) {
+                // per element: its list word (one b128 read per block), one address add, read, add, write.
+                // Round 3 tried two other forms, both measured and dropped (profiles/r03_dense_ablation.txt):
+                //  * the add inside the MFMA -- accumulators initialised from the tile rows, written back after the last slab, no
+                //    VALU arithmetic: +2 % on 256 -> 256, +4.6 % on 128 -> 128 at stride 8, but one 27 x C_in-term fp32 chain per
+                //    output instead of 27 short ones: 10x the rounding error against the float64 oracle (5.1e-5 vs 4.7e-6);
+                //  * list words, addresses and tile reads issued in FRONT of the last slab's MFMAs (they do not depend on the
+                //    results): 252 VGPRs, 4-7 % SLOWER (98 -> 94 TFLOP/s on 256 -> 256, 84 -> 78 on 128 -> 128).
+                // The MFMAs run with the operands SWAPPED (W fragment as A, the gathered rows as B): the transposed product
+                // leaves in each lane four CONSECUTIVE channels (16 wn + 4 lq .. + 3) of ONE pair row (16 b + li) -- one 16-byte
+                // read-modify-write of the tile per block instead of four 4-byte ones to four different rows, one list word per
+                // block instead of four (round 4; the sums and their order are the same: bit-identical results).
+                const OutT* ol = out_list + item.k * BM + item.start + li;
+                char* accb = reinterpret_cast<char*>(acc_lds);
+                int addr[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) addr[b] = tile_addr((int)ol[16 * (wm + WM * b)], 4 * wn + lq);
+                f32x4 old[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) old[b] = *reinterpret_cast<const f32x4*>(accb + addr[b]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) *reinterpret_cast<f32x4*>(accb + addr[b]) = old[b] + acc[b];
+            }
+        }
 #ifdef LIDIFF_CONV_PROBE
         t_flush += __builtin_readcyclecounter() - tf0;
 #endif
         stage_end();
-        }
     };
 
     // ---- packed mode: a stage = SEG segments x SEGR rows, every segment its own offset ---------------
@@ -720,17 +617,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
         run_packed();
     } else {
     Item item = load_item(0);
-    if constexpr (PP) {
-        if (nwork > 0) issue_w(item.k, 0, wc);
-        dma_next();                                       // image 0
-        if (is_b) dma_next();                             // the second half's part of image 1
-        __syncthreads();
-        if (is_b && nwork > 0) __syncthreads();           // the second half runs one interval behind the first
-    } else {
     load_rows(item);
     if (nwork > 0) issue(0, item.k, 0, item.n, wc);
     __syncthreads();
-    }
     for (int wi = 0; wi < nwork; ++wi) {
         const Item next = load_item(wi + 1);
         const bool has_next = wi + 1 < nwork;
@@ -749,7 +638,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
         }
         item = next;
     }
-    if constexpr (PP) __syncthreads();                   // the second half's last flush (it skipped the loop's last barrier)
     }
 
     STAMP(t_epi);
@@ -818,42 +706,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p_launch, const int 
 #endif
 }
 
-template <int BM, int WN, int WM, int KS, bool VEC, bool PP = false>
-__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p_launch) {
-    conv_tile<BM, WN, WM, KS, VEC, PP>(p_launch, blockIdx.x);
-}
-
-// LIDIFF_CONV_PERSIST: as many workgroups as the chip holds at once, each pulling tile slots until none is left.  Every tile
-// re-reads the parameter block from the kernel-argument segment (scalar loads through a pointer the compiler cannot see through):
-// kept alive across the tile beside the tile's own moved copy it cost 120 more spilled SGPRs and 56 VGPRs; as a CALL with the block
-// behind a reference its fields arrived in vector registers and every buffer descriptor became a waterfall loop (10-30 % slower).
 template <int BM, int WN, int WM, int KS, bool VEC>
-__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_persist_kernel(const ConvParams p_launch) {
-    typedef __attribute__((address_space(4))) const uint32_t* KernArg;
-    constexpr int NWORD = sizeof(ConvParams) / 4;
-    static_assert(sizeof(ConvParams) % 4 == 0, "ConvParams");
-    __shared__ int s_slot;
-    for (;;) {
-        uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();     // the block is the first (only) argument
-        asm volatile("" : "+s"(ka));
-        union { ConvParams p; uint32_t w[NWORD]; } blk;
-#pragma unroll
-        for (int i = 0; i < NWORD; ++i) blk.w[i] = ((KernArg)ka)[i];
-        const ConvParams& pl = blk.p;
-        if (threadIdx.x == 0) s_slot = next_tile_slot(pl);
-        __syncthreads();
-        const int bid = s_slot;
-        if (bid < 0) break;
-        conv_tile<BM, WN, WM, KS, VEC>(pl, bid);
-        __syncthreads();                         // the tile's LDS and s_slot are free again
-    }
-    if (threadIdx.x == 0) {                      // the last workgroup to leave zeroes the counters for the next launch
-        __threadfence();
-        if (atomicAdd(&p_launch.queue[8], 1) == (int)gridDim.x - 1) {
-            for (int q = 0; q < 9; ++q) __atomic_store_n(&p_launch.queue[q], 0, __ATOMIC_RELAXED);
-            __threadfence();
-        }
-    }
+__global__ __launch_bounds__(64 * WN * WM) void spconv_fwd_kernel(const ConvParams p_launch) {
+    conv_tile<BM, WN, WM, KS, VEC>(p_launch, blockIdx.x);
 }
 
 // W [K, c_in, c_out] row-major  ->  [K][slab32][c_out/16][j 0..1][lane 0..63][e 0..3]  with
@@ -874,40 +729,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int k_vol, int 
     wp[idx] = kin < c_in ? w[((int64_t)k * c_in + kin) * c_out + col] : 0.f;
 }
 
-// Tile counters of the LIDIFF_CONV_PERSIST launches: a ring of zeroed 16-word sets per device; a launch takes the next set and its
-// last workgroup zeroes it again (launches on different streams run side by side: every one needs counters of its own; a set comes
-// round again after 4096 launches).
-static int32_t* tile_queue() {
-    constexpr int kSets = 4096, kDevs = 16;
-    static int32_t* ring[kDevs] = {};
-    static std::mutex mu;
-    static std::atomic<unsigned> next{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) return nullptr;
-    if (ring[dev] == nullptr) {
-        std::lock_guard<std::mutex> lock(mu);
-        if (ring[dev] == nullptr) {
-            int32_t* q = nullptr;
-            if (hipMalloc(&q, (size_t)kSets * 16 * sizeof(int32_t)) != hipSuccess) return nullptr;
-            if (hipMemset(q, 0, (size_t)kSets * 16 * sizeof(int32_t)) != hipSuccess) return nullptr;
-            ring[dev] = q;
-        }
-    }
-    return ring[dev] + (size_t)(next.fetch_add(1) % kSets) * 16;
-}
-
-template <int BM, int WN, int WM, int KS, bool VEC, bool PP = false>
+template <int BM, int WN, int WM, int KS, bool VEC>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
     using Cfg = ConvCfg<BM, WN, WM, KS>;
     const size_t lds = Cfg::lds_bytes(p.k_vol);
     LIDIFF_CHECK_ARG(lds <= 160 * 1024, "LDS budget exceeded");
-    auto kern = spconv_fwd_kernel<BM, WN, WM, KS, VEC, PP>;
-    auto kern_p = spconv_fwd_persist_kernel<BM, WN, WM, KS, VEC>;
+    auto kern = spconv_fwd_kernel<BM, WN, WM, KS, VEC>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_p),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
@@ -915,27 +745,6 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     q.tiles_m = (int)ceil_div(p.m_out, BM);
     q.tiles_n = p.c_out / Cfg::BN;
     const unsigned grid = (unsigned)(ceil_div((int64_t)q.tiles_m * q.replicas, 8) * 8 * q.tiles_n);
-    if (p.flags & LIDIFF_CONV_PERSIST) {
-        // resident workgroups -- as many as the chip holds at once -- pull tile slots from per-XCD counters
-        static thread_local size_t occ_lds = ~(size_t)0;
-        static thread_local int occ = 0, cus = 0;
-        if (occ_lds != lds) {
-            int dev = 0;
-            LIDIFF_CHECK_HIP(hipGetDevice(&dev));
-            LIDIFF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            LIDIFF_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern_p), Cfg::NT, lds));
-            occ_lds = lds;
-        }
-        const unsigned resident = (unsigned)(cus * (occ > 0 ? occ : 1)) & ~7u;
-        if (resident >= 8 && grid > resident) {
-            q.queue = tile_queue();
-            LIDIFF_CHECK_ARG(q.queue != nullptr, "no tile queue");
-            q.bids = (int)grid;
-            hipLaunchKernelGGL(kern_p, dim3(resident), dim3(Cfg::NT), lds, st, q);
-            LIDIFF_CHECK_LAUNCH();
-            return 0;
-        }
-    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), lds, st, q);
     LIDIFF_CHECK_LAUNCH();
     return 0;
@@ -946,11 +755,8 @@ static int dispatch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
     if (!vec) return launch_fwd<BM, WN, WM, 32, false>(p, st);
     // 64-channel stages halve the per-stage costs of dense maps; low-density maps (hint from the caller)
     // take the 32-channel kernel, whose tiles can pack several offsets into one stage
-    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0 && !(p.flags & LIDIFF_CONV_SPARSE_MAP)) {
-        if constexpr (WN * WM == 8 && WM == 1)
-            if (p.flags & LIDIFF_CONV_PINGPONG) return launch_fwd<BM, WN, WM, 64, true, true>(p, st);
+    if (p.c_in_a % 64 == 0 && p.c_in_b % 64 == 0 && !(p.flags & LIDIFF_CONV_SPARSE_MAP))
         return launch_fwd<BM, WN, WM, 64, true>(p, st);
-    }
     return launch_fwd<BM, WN, WM, 32, true>(p, st);
 }
 

@@ -2,10 +2,8 @@
 //   planes = 1: the mixed-precision TRAINING convolution -- BASELINE.json configs[4] "train.py diffusion training ... bf16"
 //               (models.py:180-217 under autocast: GEMM operands in bf16, fp32 accumulate, fp32 master weights) -- forward
 //               and, over the swapped map with W^T, the input gradient;
-//   planes = 2 / 3: an fp32-accurate forward from bf16 pieces (opt-in for inference; never the benchmark's `value`):
-//               x = x1 + x2 (+ x3) and w = w1 + w2 (+ w3) in bf16, all products x_i w_j with i + j <= planes + 1 (3 or 6
-//               MFMAs) -- measured error of a K = 6912 dot product relative to sum |x w|: 2.5e-7 (two planes), 1.3e-7
-//               (three planes), native fp32 MFMA 1.1e-7 (profiles/r01_bf16_split_micro.txt).
+//   (planes = 2 / 3 of rounds 1-5 -- fp32-accurate results from split operands on THIS tile kernel -- are gone: round 6 does
+//   that on wide register tiles with pre-cut operands, spconv_split3.hip; the weight packer still cuts 1..3 pieces.)
 // Features are fp32 in HBM (BatchNorm, the loss, the optimizer and every consumer are fp32): the gathered rows are split /
 // rounded (nearest even, v_cvt_pk_bf16_f32) on their way from the LDS image into the MFMA operand, the weights once per
 // weight version when they are packed.  Round 5 (planes = 1, the training step): the rows may arrive as bf16 ALREADY -- the
@@ -1206,9 +1204,10 @@ extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const f
                                       int32_t c_out, float* out, const float* ep_scale, const float* ep_shift,
                                       const float* residual, int32_t relu, int32_t replicas, int32_t in_bf16, void* stream) {
     LIDIFF_CHECK_ARG(in_a != nullptr && c_in_a > 0 && w_packed != nullptr && out != nullptr, "null pointer");
-    LIDIFF_CHECK_ARG(in_bf16 >= 0 && in_bf16 <= 4 && (!in_bf16 || planes == 1), "bf16 feature rows: in_bf16 in 0..4, planes must be 1");
+    LIDIFF_CHECK_ARG(in_bf16 >= 0 && in_bf16 <= 4, "bf16 feature rows: in_bf16 in 0..4");
     LIDIFF_CHECK_ARG((in_b == nullptr) == (c_in_b == 0), "in_b and c_in_b must agree");
-    LIDIFF_CHECK_ARG(planes >= 1 && planes <= 3, "planes must be 1, 2 or 3");
+    LIDIFF_CHECK_ARG(planes == 1, "planes must be 1 (operands rounded to bf16: the training convolution); fp32-accurate results from "
+                                  "split operands: lidiff_spconv_fwd_split3");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
     LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
     LIDIFF_CHECK_ARG(c_in_a % 32 == 0 && c_in_b % 32 == 0, "the bf16 kernel needs input widths that are multiples of 32");
@@ -1242,7 +1241,5 @@ extern "C" int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const f
     hipStream_t st = (hipStream_t)stream;
     const bool ks64 = c_in_a % 64 == 0 && c_in_b % 64 == 0;
     if (in_bf16) return dispatch_bf16_rows(p, ks64, in_bf16, st);
-    if (planes == 1) return dispatch_bf16<1>(p, ks64, st);
-    if (planes == 2) return dispatch_bf16<2>(p, ks64, st);
-    return dispatch_bf16<3>(p, ks64, st);
+    return dispatch_bf16<1>(p, ks64, st);
 }

@@ -81,27 +81,6 @@ __global__ __launch_bounds__(kStepBlock) void cfg_dpm_step_kernel(const float* _
     step_point(i, SECOND, e_c, e_u, x_t, x_init, m1, z, k, n_per_batch, scale_batch, x0_out, feats, coords);
 }
 
-// The same step with everything that changes from step to step read from DEVICE memory: row *d_step of a coefficient table
-// [T][8] doubles (sigma_t, 1 / alpha_t, c_sample, c_m0, c_d1, 1 / r0, c_noise, second-order flag) and of a noise table
-// [T][3 n] -- so that one captured HIP graph serves every step of a trajectory (DiffCompletion.graph_steps): the launch has no
-// per-step argument.  Same arithmetic, operation by operation.
-__global__ __launch_bounds__(kStepBlock) void cfg_dpm_step_table_kernel(const float* __restrict__ e_c, const float* __restrict__ e_u,
-                                                                        const float* __restrict__ x_t, const double* __restrict__ x_init,
-                                                                        const double* __restrict__ m1, const double* __restrict__ z_table,
-                                                                        const double* __restrict__ coef_table,
-                                                                        const int32_t* __restrict__ d_step, float w, float inv_res,
-                                                                        int64_t n, int64_t n_per_batch, int32_t scale_batch,
-                                                                        double* __restrict__ x0_out, float* __restrict__ feats,
-                                                                        int32_t* __restrict__ coords) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t s = *d_step;
-    const double* r = coef_table + 8 * s;
-    const StepCoeffs k{w, (float)r[0], inv_res, r[1], r[2], r[3], r[4], r[5], r[6]};
-    step_point(i, r[7] != 0.0, e_c, e_u, x_t, x_init, m1, z_table ? z_table + s * 3 * n : nullptr, k, n_per_batch, scale_batch, x0_out,
-               feats, coords);
-}
-
 // DiffCompletion.points_to_tensor (pipeline:68-84) alone: [B, n, 3] points -> float32 features + int32 voxel coordinates
 template <typename T>
 __global__ __launch_bounds__(kStepBlock) void points_to_field_kernel(const T* __restrict__ pts, float inv_res, int64_t n,
@@ -143,22 +122,6 @@ extern "C" int lidiff_cfg_dpm_step(const float* eps_cond, const float* eps_uncon
     else
         cfg_dpm_step_kernel<false><<<grid, kStepBlock, 0, st>>>(eps_cond, eps_uncond, x_t, x_init, nullptr, noise, k, n_points,
                                                                 n_per_batch, scale_batch_column, x0_out, feats_out, coords_out);
-    LIDIFF_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int lidiff_cfg_dpm_step_table(const float* eps_cond, const float* eps_uncond, float w, const float* x_t, const double* x_init,
-                                         const double* m_prev, const double* noise_table, const double* coef_table,
-                                         const int32_t* d_step, float inv_resolution, int64_t n_points, int64_t n_per_batch,
-                                         int32_t scale_batch_column, double* x0_out, float* feats_out, int32_t* coords_out, void* stream) {
-    LIDIFF_CHECK_ARG(n_points >= 1 && n_per_batch >= 1, "need n_points >= 1 and n_per_batch >= 1");
-    LIDIFF_CHECK_ARG(eps_cond && eps_uncond && x_t && x_init && m_prev && coef_table && d_step && x0_out && feats_out && coords_out,
-                     "null pointer");
-    LIDIFF_CHECK_ARG(((uintptr_t)coords_out & 15) == 0, "coords_out must be 16-byte aligned");
-    const unsigned grid = (unsigned)ceil_div(n_points, kStepBlock);
-    cfg_dpm_step_table_kernel<<<grid, kStepBlock, 0, (hipStream_t)stream>>>(eps_cond, eps_uncond, x_t, x_init, m_prev, noise_table,
-                                                                            coef_table, d_step, w, inv_resolution, n_points, n_per_batch,
-                                                                            scale_batch_column, x0_out, feats_out, coords_out);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }

@@ -146,8 +146,6 @@ class SizeFeed:
         self.checks.clear()
         self.seq_base = self.seq
         self.bad = None
-        if self.dev_seq is not None:
-            self.dev_seq.fill_(self.seq)         # the device-side numbering follows the host's again
 
     def _discard_pending(self):
         for seq in list(self.n_words):
@@ -182,33 +180,9 @@ class SizeFeed:
             if sizes[i] > top:
                 self.bad = f"record {seq}: word {i} = {sizes[i]} exceeds the bound {top} the host sized a buffer by"
 
-    # device-side sequence numbers (enable_device_seq): the publishing launch takes no per-record argument -- it increments a
-    # device counter and derives the ring slot from it -- so it can sit inside a captured HIP graph that is replayed step
-    # after step (DiffCompletion.graph_steps); the host mirrors the numbering (announce() per replay)
-    dev_seq = None
-
-    def enable_device_seq(self):
-        if self.dev_base is None:
-            raise RuntimeError("SizeFeed: device-side sequence numbers need the pinned ring mapped into the device's address space")
-        if self.dev_seq is None:
-            self.dev_seq = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.dev_seq.fill_(self.seq)
-
-    def announce(self, n_words: int):
-        """Host bookkeeping of a record that a REPLAYED graph will publish (the launch itself is inside the graph)."""
-        self.seq += 1
-        prev = self.slot_owner.get(self.seq % self.SLOTS)
-        if prev is not None and prev in self.n_words:
-            self.get(prev)
-        self.slot_owner[self.seq % self.SLOTS] = self.seq
-        self.n_words[self.seq] = int(n_words)
-        return self.seq
-
     def push_host(self, sizes, status: int = 0):
         self.seq += 1
         self.done[self.seq] = (int(status), [int(v) for v in sizes])
-        if self.dev_seq is not None:
-            self.dev_seq.fill_(self.seq)
         self._trim()
         return self.seq
 
@@ -221,10 +195,7 @@ class SizeFeed:
             self.get(prev)                             # the slot's previous record has not been consumed yet: do it now
         self.slot_owner[self.seq % self.SLOTS] = self.seq
         self.n_words[self.seq] = counts.numel()
-        if self.dev_seq is not None:
-            call("lidiff_publish_words_seq", ptr(counts), counts.numel(), ptr(status), self.dev_base, self.SLOTS, self.WORDS,
-                 ptr(self.dev_seq), stream_ptr())
-        elif self.dev_base is not None:
+        if self.dev_base is not None:
             call("lidiff_publish_words", ptr(counts), counts.numel(), ptr(status), self.dev_base + 4 * self.WORDS * (self.seq % self.SLOTS),
                  self.seq, stream_ptr())
         else:
@@ -686,14 +657,23 @@ class ConvProfiler:
                 p = counts[key]
             p, m_in, m_out = reps * p, reps * m_in, reps * m_out
             d = out.setdefault(variant, {"launches": 0, "timed": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0,
-                                         "flops_timed": 0.0, "bytes_timed": 0.0})
+                                         "flops_timed": 0.0, "bytes_timed": 0.0, "mfma_flops_timed": 0.0})
             fl, by = 2.0 * p * c_in * c_out, 4.0 * (m_in * c_in + m_out * c_out) + 4.0 * k * c_in * c_out + 8.0 * p
+            ex = fl
+            if variant == "split3" and nbr is not None:
+                # what the matrix pipe EXECUTES: six bf16 products per fp32 product, for every row of every 256-row tile under
+                # every offset (the wide tiles multiply rows without a neighbour as zeros); rows = the centre offset's entries
+                ck = ("rows", key)
+                if ck not in counts:
+                    counts[ck] = int((nbr[k // 2] >= 0).sum().item())
+                ex = 6 * 2.0 * reps * (-(-counts[ck] // 256) * 256) * k * c_in * c_out
             d["launches"] += 1
             if start is not None:
                 d["timed"] += 1
                 d["ms"] += start.elapsed_time(end)
                 d["flops_timed"] += fl
                 d["bytes_timed"] += by
+                d["mfma_flops_timed"] += ex
             d["flops"] += fl
             d["bytes"] += by
         return out
@@ -769,8 +749,6 @@ PROFILER: ConvProfiler | None = None
 DETERMINISTIC_DW = True
 # extra lidiff_spconv_fwd flag bits (include/lidiff_amd.h LIDIFF_CONV_*), e.g. 8 = LIDIFF_CONV_TILE_ONLY
 CONV_FLAGS = int(os.environ.get("LIDIFF_CONV_FLAGS", "0"))
-# resident workgroups (LIDIFF_CONV_PERSIST) for the dense layers of >= this many input channels (0: never)
-PERSIST_MIN_CIN = int(os.environ.get("LIDIFF_PERSIST_MIN_CIN", "0"))
 
 
 def conv_variant(c_out: int, kernel_id: int = 0) -> str:
@@ -839,8 +817,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     row_order: int32 permutation of the output rows (tile_order()); `nbr` must then hold its columns in that
     order (nbr[:, row_order]).  Results do not depend on it.
     kernel: "tile_only" keeps identity maps off the row kernel (spconv_rows.hip); "tile128" keeps 64-column layers on 128-row
-    tiles (large maps take 256-row tiles by default); "persist" runs the tile kernels as resident workgroups that pull their tiles
-    from per-XCD counters (LIDIFF_CONV_PERSIST; bit-identical results).
+    tiles (large maps take 256-row tiles by default).
     d_rows: int32 [1] on the device -- the number of VALID output rows when m_out is only their bound (a step without host reads):
     m_out still shapes the result, the table's pitch and the replica pitch; tiles behind the count leave at once.  rows_hint: the
     row count the host BELIEVES (an earlier step's): it alone picks the tile size where the bound would pick another one.
@@ -848,11 +825,6 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
     kernel_size-3 map.  tail = (rows [R * P, C_out], ptr int32 [m_out + 1], idx int32 [P]): rows added to the sum before
     the epilogue, out[o] += sum(rows[idx[ptr[o]:ptr[o + 1]]]) -- the other offsets' contributions (TailMap)."""
     require_device(in_a, w, nbr, in_b, scale, shift, residual)
-    if (SPLIT_PLANES and not sparse_map and row_order is None and tail is None and offset is None and d_rows is None
-            and bf16_conv_applies(in_a.shape[1], 0 if in_b is None else in_b.shape[1], w.shape[-1])
-            and w.shape[-1] % SPLIT_MIN_COUT == 0):
-        return spconv_fwd_bf16(in_a, w, nbr, m_out, in_b=in_b, scale=scale, shift=shift, residual=residual, relu=relu,
-                               replicas=replicas, planes=SPLIT_PLANES)
     wp = packed_weights(w, offset)
     if w.dim() == 2:
         k, (c_in, c_out) = 1, w.shape
@@ -886,9 +858,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
         assert t_rows.shape == (replicas * n_tail, c_out) and t_rows.is_contiguous() and t_rows.dtype == torch.float32
         assert t_ptr.dtype == torch.int32 and t_ptr.shape == (m_out + 1,) and t_idx.dtype == torch.int32
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=in_a.device)
-    flags = int(bool(sparse_map)) | {"tile": 0, "tile_only": 8, "tile128": 16, "persist": 32, "pingpong": 64}[kernel or "tile"] | CONV_FLAGS
-    if PERSIST_MIN_CIN and c_in >= PERSIST_MIN_CIN and c_out % 128 == 0 and not sparse_map and k > 1:
-        flags |= 32
+    flags = int(bool(sparse_map)) | {"tile": 0, "tile_only": 8, "tile128": 16}[kernel or "tile"] | CONV_FLAGS
     if rows_hint is not None and rows_hint * replicas < 256 * 512:
         flags |= 16                 # the exact-size path would keep 128-row tiles for this map: the same choice under a bound
     prof = PROFILER
@@ -1128,29 +1098,6 @@ def spconv_fwd_pairs(in_a: torch.Tensor, w: torch.Tensor, pair_in: torch.Tensor,
         prof.launches.append(("rows", start, end, m_in if in_rows_hint is None else int(in_rows_hint),
                               m_out if rows_hint is None else int(rows_hint), c_in, c_out, k, None, replicas))
     return out
-
-
-# Opt-in for the INFERENCE forward (never the benchmark's `value`; bench.py reports it as "alt"): 0 = native fp32 MFMA
-# (default); 2 / 3 = the dense-map layers (no sparse hint, C_out a multiple of SPLIT_MIN_COUT) through lidiff_spconv_fwd_bf16
-# with every operand cut into 2 / 3 bf16 pieces -- 3 / 6 bf16 MFMAs per block, fp32 accumulation, fp32-accurate results.
-SPLIT_PLANES = int(os.environ.get("LIDIFF_SPLIT_PLANES", "0"))
-SPLIT_MIN_COUT = 128
-
-
-class split_planes:
-    """with ops.split_planes(2): ... -- the inference forward's dense layers from bf16 pieces."""
-
-    def __init__(self, planes: int):
-        assert planes in (0, 2, 3)
-        self.planes = planes
-
-    def __enter__(self):
-        global SPLIT_PLANES
-        self.prev, SPLIT_PLANES = SPLIT_PLANES, self.planes
-
-    def __exit__(self, *exc):
-        global SPLIT_PLANES
-        SPLIT_PLANES = self.prev
 
 
 # GEMM operand precision of the TRAINING convolutions (_SparseConv forward and input gradient): "f32" or "bf16"
@@ -1640,41 +1587,6 @@ def cfg_dpm_step(e_cond, e_uncond, w: float, x_t, x_init, plan: dict, noise, res
     call("lidiff_cfg_dpm_step", ptr(e_cond), ptr(e_uncond), float(w), ptr(x_t), ptr(x_init), ptr(m_prev), ptr(noise),
          float(np.float32(plan["sigma_t"])), 1.0 / plan["alpha_t"], plan["c_sample"], plan["c_m0"], plan["c_d1"], plan["inv_r0"],
          plan["c_noise"], _inv_resolution(resolution), n, max(1, n_per), int(bool(scale_batch_column)), ptr(x0), ptr(feats),
-         ptr(coords), stream_ptr())
-    return x0, feats, coords
-
-
-def step_coefficient_table(plans, device) -> torch.Tensor:
-    """[T, 8] float64 on the device from DPMSolverMultistepScheduler.plan_table(): the rows lidiff_cfg_dpm_step_table reads
-    (sigma_t as the float32 it is multiplied in, 1 / alpha_t, c_sample, c_m0, c_d1, 1 / r0, c_noise, second-order flag)."""
-    import numpy as np
-    rows = [[float(np.float32(p["sigma_t"])), 1.0 / p["alpha_t"], p["c_sample"], p["c_m0"], p["c_d1"], p["inv_r0"], p["c_noise"],
-             1.0 if p["second"] else 0.0] for p in plans]
-    return torch.tensor(rows, dtype=torch.float64).to(device)
-
-
-def cfg_dpm_step_table(e_cond, e_uncond, w: float, x_t, x_init, m_prev, noise_table, coef_table, d_step, resolution: float,
-                       scale_batch_column: bool = True):
-    """cfg_dpm_step with the step's scalars and noise read from device tables at row d_step[0] (lidiff_cfg_dpm_step_table): no
-    per-step argument -- the launch can be replayed from a captured graph.  m_prev [B, n, 3] float64 (read when the row's
-    second-order flag is set), noise_table [T, B n 3] float64 or None, coef_table step_coefficient_table(), d_step int32 [1]."""
-    require_device(e_cond, e_uncond, x_t, x_init, m_prev, noise_table, coef_table, d_step)
-    b, n_per = x_init.shape[0], x_init.shape[1]
-    n = b * n_per
-    e_cond, e_uncond, x_t, x_init = (v.contiguous() for v in (e_cond, e_uncond, x_t, x_init))
-    if not (e_cond.dtype == e_uncond.dtype == x_t.dtype == torch.float32 and x_init.dtype == m_prev.dtype == torch.float64
-            and e_cond.numel() == e_uncond.numel() == x_t.numel() == x_init.numel() == m_prev.numel() == 3 * n):
-        raise ValueError("cfg_dpm_step_table: float32 eps / points [B, n, 3], float64 x_init / m_prev [B, n, 3] expected")
-    assert coef_table.dtype == torch.float64 and coef_table.dim() == 2 and coef_table.shape[1] == 8 and coef_table.is_contiguous()
-    assert d_step.dtype == torch.int32 and m_prev.is_contiguous()
-    if noise_table is not None:
-        assert noise_table.dtype == torch.float64 and noise_table.is_contiguous() and noise_table.shape[0] == coef_table.shape[0] \
-            and noise_table.numel() == coef_table.shape[0] * 3 * n
-    x0 = torch.empty((b, n_per, 3), dtype=torch.float64, device=x_init.device)
-    feats = torch.empty((n, 3), dtype=torch.float32, device=x_init.device)
-    coords = torch.empty((n, 4), dtype=torch.int32, device=x_init.device)
-    call("lidiff_cfg_dpm_step_table", ptr(e_cond), ptr(e_uncond), float(w), ptr(x_t), ptr(x_init), ptr(m_prev), ptr(noise_table),
-         ptr(coef_table), ptr(d_step), _inv_resolution(resolution), n, max(1, n_per), int(bool(scale_batch_column)), ptr(x0), ptr(feats),
          ptr(coords), stream_ptr())
     return x0, feats, coords
 

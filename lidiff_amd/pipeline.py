@@ -576,24 +576,6 @@ class DiffCompletion(nn.Module):
         loop is redone from the same inputs, scheduler state and random draws with exact sizes -- same results as if it had run
         that way from the start."""
         self.read_free_reset()          # the first pyramid of every role in this loop is built with its host read
-        if (self.graph_steps and x_t.F.device.type == "cuda" and self.fused_step and self.pair_cfg and x_init.dtype == torch.float64
-                and self.dpm_scheduler.algorithm_type == "sde-dpmsolver++" and minknet._FUSION and not self.training):
-            rng = torch.cuda.get_rng_state(self.device) if noises is None else None
-            try:
-                return self._completion_loop_graph(x_init, x_t, x_cond, x_uncond, noises)
-            except RuntimeError as e:
-                if "voided" not in str(e):
-                    raise
-                import warnings
-                warnings.warn(f"graph-captured denoising loop voided ({e}); redone eagerly with exact sizes")
-                if rng is not None:
-                    torch.cuda.set_rng_state(rng, self.device)
-                self.read_free_reset()
-                prev, self.read_free = self.read_free, False
-                try:
-                    return self._completion_loop(x_init, x_t, x_cond, x_uncond, noises)
-                finally:
-                    self.read_free = prev
         if not (self.read_free and x_t.F.device.type == "cuda"):
             return self._completion_loop(x_init, x_t, x_cond, x_uncond, noises)
         sch = self.dpm_scheduler
@@ -621,124 +603,6 @@ class DiffCompletion(nn.Module):
             return self._completion_loop(x_init, x_t, x_cond, x_uncond, noises)
         finally:
             self.read_free = prev
-
-    # -- the per-step kernel sequence as a captured HIP graph ("cache partial_enc(x_cond), partial_enc(x_uncond)
-    # ...; HIP-graph the per-step kernel sequence"; opt-in: graph_steps / LIDIFF_GRAPH_STEPS=1) ---------------------------------
-    # With the conditions encoded once per scan and no map size reaching the host, a step is a fixed launch sequence for as long
-    # as the kernel CHOICES stand still (they follow the previous step's sizes: _decision_key).  The step body below takes nothing
-    # from the host: x_t lives in static buffers that the body reads and rewrites, the timestep, the solver's scalars and the
-    # scheduler's noise come from device tables at a device-side step counter (lidiff_cfg_dpm_step_table), the size record's
-    # sequence number is counted on the device (lidiff_publish_words_seq).  The body runs eagerly until a key has been seen
-    # twice, is then captured (torch.cuda.graph -> hipGraph) and replayed while the key holds; a new key runs eagerly and is
-    # captured in turn.  Same bits as the eager loop with cached conditions (tests/test_gpu_readfree.py).  One stream inside the
-    # body.  It does NOT make a step faster -- the host is not on the critical path -- and so it is not
-    # the default; it is what the row asks for, and it makes the step immune to a slow host (a profiler, a loaded machine).
-    graph_steps = os.environ.get("LIDIFF_GRAPH_STEPS", "0") == "1"
-    graph_stats = None            # {"eager": steps run eagerly, "captured": graphs captured, "replayed": steps replayed} of the last loop
-
-    @staticmethod
-    def _decision_key(hints):
-        """Everything the host decides from the previous pyramid's sizes (CoordinateManager.is_sparse_map, the centre + tail and
-        pair-list thresholds of conv_bn_act / up_order, the tile height of ops.spconv_fwd): two steps with the same key queue the
-        same kernels with the same arguments."""
-        rows = list(hints[:5]) + [0]
-        key = []
-        for lv in range(5):
-            m, nxt = rows[lv], rows[lv + 1]
-            key += [nxt > 0 and nxt >= 0.85 * m, nxt > 0 and nxt >= 0.5 * m, nxt >= 0.67 * max(1, m), m >= 1024, m >= 4096,
-                    m >= 256 * 512, 2 * m >= 256 * 512]
-        return tuple(key)
-
-    def _completion_loop_graph(self, x_init, x_t, x_cond, x_uncond, noises=None):
-        from . import ops
-        dev, sch = self.device, self.dpm_scheduler
-        ts = sch.host_timesteps
-        n_steps, b, n_per = len(ts), x_init.shape[0], x_init.shape[1]
-        keep = (self.overlap_maps, self.read_free)
-        import time
-        stats = {"eager": 0, "captured": 0, "replayed": 0, "capture_s": 0.0}
-        try:
-            self.read_free = True
-            parts = self.encode_conditions(x_cond, x_uncond)                 # once per scan (the row's step-invariant caching)
-            self.overlap_maps = False                                        # one stream inside the step body
-            from . import _lib
-            _lib.join_pending()                                              # (nothing built on a side stream may be left to join
-            torch.cuda.synchronize(dev)                                      #  inside a capture)
-            coef = ops.step_coefficient_table(sch.plan_table(), dev)
-            t_table = torch.tensor(ts, dtype=torch.int64, device=dev)
-            if noises is None:          # the draws dpm_scheduler.step would make, in its order (same generator state, same values)
-                noise_table = torch.stack([torch.randn(x_init.shape, device=dev, dtype=torch.float64) for _ in range(n_steps)])
-            else:
-                noise_table = torch.stack([z.to(dev).double() for z in noises])
-            noise_table = noise_table.reshape(n_steps, -1).contiguous()
-            xf = x_t.F.detach().float().contiguous().clone()
-            xc = (x_t.C if x_t.C.dtype == torch.int32 else ops.coords_floor(x_t.C)).contiguous().clone()
-            m_prev = torch.zeros((b, n_per, 3), dtype=torch.float64, device=dev)
-            d_step = torch.zeros(1, dtype=torch.int32, device=dev)
-            feed = self._feed("x_t")
-            feed.enable_device_seq()
-            w, res = self.w_uncond, self.hparams["data"]["resolution"]
-
-            def body():
-                field = self._make_field(xf, xc, "x_t")
-                t = t_table.index_select(0, d_step.long())
-                e_c, e_u = self.classfree_pair(field, None, None, t, parts)
-                x0, feats, coords = ops.cfg_dpm_step_table(e_c, e_u, w, xf, x_init, m_prev, noise_table, coef, d_step, res,
-                                                           scale_batch_column=True)
-                m_prev.copy_(x0)
-                xf.copy_(feats)
-                xc.copy_(coords)
-                d_step.add_(1)
-
-            graphs, warm = {}, None
-            pool = None
-            with torch.no_grad():
-                for i in range(n_steps):
-                    key = self._decision_key(feed.get()[1]) if feed.has_records() else None
-                    g = graphs.get(key) if key is not None else None
-                    if g is not None:
-                        feed.announce(7)
-                        g.replay()
-                        stats["replayed"] += 1
-                    elif key is not None and key == warm and len(graphs) < 6:
-                        t0 = time.perf_counter()
-                        g = torch.cuda.CUDAGraph()
-                        # (capture_begin / capture_end by hand: torch.cuda.graph() first synchronises the device, collects
-                        #  garbage and empties the allocator's cache -- with the host a step ahead that wait alone is ~35 ms per
-                        #  capture; a capture executes nothing, so none of it is needed: the body is recorded on a stream of its
-                        #  own while the device is still busy with the steps already queued)
-                        if getattr(self, "_capture_stream", None) is None:
-                            self._capture_stream = torch.cuda.Stream(device=dev)
-                        with torch.cuda.stream(self._capture_stream):
-                            g.capture_begin(pool=pool) if pool is not None else g.capture_begin()
-                            try:
-                                body()
-                            finally:
-                                g.capture_end()
-                        pool = pool or g.pool()
-                        stats["capture_s"] += time.perf_counter() - t0        # (host time: synchronise + capture + instantiate)
-                        graphs[key] = g
-                        g.replay()
-                        stats["captured"] += 1
-                        stats["replayed"] += 1
-                    else:
-                        body()
-                        warm = key
-                        stats["eager"] += 1
-            why = self.read_free_check()
-            if why is not None:
-                raise RuntimeError("host-read-free steps voided: " + why + " (bound exceeded: rerun without graph_steps)")
-            self.graph_stats = stats
-            out = xf.cpu().numpy()
-            st = int(self._loop_status().item())
-            if st:
-                raise RuntimeError(f"coordinate status {st} after the graph loop")
-            return out
-        finally:
-            self.overlap_maps, self.read_free = keep
-            f = self.__dict__.get("_feeds", {}).get("x_t")
-            if f is not None:
-                f.dev_seq = None
 
     def _completion_loop(self, x_init, x_t, x_cond, x_uncond, noises=None, check=True):
         parts = self.encode_conditions(x_cond, x_uncond) if self.cache_condition and self.pair_cfg else None

@@ -157,27 +157,6 @@ class DPMSolverMultistepScheduler:
             plan.update(m_prev=m_prev, c_d1=0.5 * g, inv_r0=1.0 / r0)
         return plan
 
-    def plan_table(self):
-        """step_plan() of EVERY step of the trajectory walked in order from a fresh state (first step first order, then second
-        order, the last one first order again when lower_order_final applies) -- the scalars only; for a caller that keeps the
-        multistep history itself (DiffCompletion.graph_steps: one captured graph for all steps)."""
-        if self.algorithm_type != "sde-dpmsolver++":
-            raise NotImplementedError("plan_table covers sde-dpmsolver++ (the sampler LiDiff constructs)")
-        keep = (list(self.model_outputs), self.lower_order_nums)
-        self.model_outputs, self.lower_order_nums = [None] * self.solver_order, 0
-        rows = []
-        try:
-            for t in self._host_timesteps:
-                if self.lower_order_nums >= 1:
-                    self.model_outputs[-1] = 0.0                 # (a placeholder: only "is there a previous prediction" matters)
-                plan = self.step_plan(t)
-                rows.append({k: v for k, v in plan.items() if k != "m_prev"} | {"second": plan["m_prev"] is not None})
-                if self.lower_order_nums < self.solver_order:
-                    self.lower_order_nums += 1
-        finally:
-            self.model_outputs, self.lower_order_nums = keep
-        return rows
-
     def commit(self, x0):
         """The bookkeeping of the step that step_plan() described, with its data prediction: what step() does around the update."""
         for i in range(self.solver_order - 1):

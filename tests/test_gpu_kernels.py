@@ -751,86 +751,6 @@ def test_spconv_256_row_tiles_vs_128_row_tiles_and_oracle(device, cin, split, co
         assert torch.allclose(got[:m][rows].cpu().double(), want, rtol=RTOL, atol=ATOL)
 
 
-@pytest.mark.parametrize("cin,split,cout,hint", [(128, 0, 128, False), (256, 0, 256, False), (64, 0, 64, False), (32, 0, 32, True),
-                                                 (96, 64, 96, True), (128, 0, 256, False)])
-def test_spconv_resident_workgroups_equal_the_plain_launch(device, cin, split, cout, hint):
-    """LIDIFF_CONV_PERSIST: the tile kernels launched as resident workgroups (as many as the chip holds) that pull tile slots from
-    per-XCD counters -- the same tiles, each computed exactly as in the plain launch: bit-identical, on a map with many more tiles
-    than the chip holds workgroups, with the CFG pair stacked, a ragged last tile, a device-side row count, and launch after
-    launch on the same counters (the last workgroup out zeroes them)."""
-    from lidiff_amd import ops
-    g = torch.Generator().manual_seed(11 + cin)
-    cloud = random_cloud(150000, 36, 71)
-    uniq, _, _ = me.voxelize(cloud)
-    nbr = dev_i32(me.kernel_map(uniq, uniq, 3, 1), device)
-    m = uniq.shape[0]
-    reps = 2
-    x = torch.randn(reps * m, cin, generator=g).to(device)
-    w = (torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)).to(device)
-    a = x[:, :split].contiguous() if split else x
-    kw = dict(in_b=x[:, split:].contiguous() if split else None, scale=(torch.rand(cout, generator=g) + 0.5).to(device),
-              shift=torch.randn(cout, generator=g).to(device), residual=torch.randn(reps * m, cout, generator=g).to(device),
-              relu=True, replicas=reps, sparse_map=hint)
-    ref = ops.spconv_fwd(a, w, nbr, m, **kw)
-    for _ in range(3):
-        assert torch.equal(ops.spconv_fwd(a, w, nbr, m, kernel="persist", **kw), ref)
-    # a device-side row count below the bound: tiles behind it leave at once, in both forms
-    rows = torch.tensor([m - 1000], dtype=torch.int32, device=device)
-    ref_d = ops.spconv_fwd(a, w, nbr, m, d_rows=rows, **kw)
-    got_d = ops.spconv_fwd(a, w, nbr, m, d_rows=rows, kernel="persist", **kw)
-    for r in range(reps):
-        assert torch.equal(got_d[r * m:r * m + m - 1000], ref_d[r * m:r * m + m - 1000])
-    # two streams side by side: every launch has counters of its own
-    side = torch.cuda.Stream(device=device)
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        s1 = ops.spconv_fwd(a, w, nbr, m, kernel="persist", **kw)
-    s2 = ops.spconv_fwd(a, w, nbr, m, kernel="persist", **kw)
-    torch.cuda.current_stream().wait_stream(side)
-    assert torch.equal(s1, ref) and torch.equal(s2, ref)
-
-
-@pytest.mark.parametrize("cin,split,cout", [(128, 0, 128), (256, 0, 256), (64, 0, 128), (256, 128, 256), (128, 0, 256), (192, 128, 128)])
-def test_spconv_pingpong_schedule_is_bit_identical(device, cin, split, cout):
-    """LIDIFF_CONV_PINGPONG (round 6): the dense 128-column tiles with the two waves of every SIMD alternating between a stage's
-    MFMAs and everything else (gather requests two stages ahead from the second half of the waves, flush, W loads; two barriers
-    per stage) -- the same MFMA sequence per output and the same flush order as the plain schedule: bit-identical, on dense
-    and on nearly empty maps (few work items, tiles without a pair), the CFG pair stacked, a ragged last tile, fused ME.cat, a
-    device-side row count, every epilogue; and against the float64 oracle."""
-    from lidiff_amd import ops
-    g = torch.Generator().manual_seed(3 + cin + cout)
-    for n_pts, extent in ((60000, 14), (3000, 40), (130, 3)):
-        cloud = random_cloud(n_pts, extent, 17 + n_pts)
-        uniq, _, _ = me.voxelize(cloud)
-        nbr_np = me.kernel_map(uniq, uniq, 3, 1)
-        nbr = dev_i32(nbr_np, device)
-        m = uniq.shape[0]
-        for reps in (1, 2):
-            x = torch.randn(reps * m, cin, generator=g)
-            w = torch.randn(27, cin, cout, generator=g) / np.sqrt(cin * 9)
-            sc, sh, res = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g), torch.randn(reps * m, cout, generator=g)
-            xd = x.to(device)
-            a = xd[:, :split].contiguous() if split else xd
-            kw = dict(in_b=xd[:, split:].contiguous() if split else None, scale=sc.to(device), shift=sh.to(device),
-                      residual=res.to(device), relu=True, replicas=reps)
-            ref = ops.spconv_fwd(a, w.to(device), nbr, m, **kw)
-            for _ in range(2):
-                assert torch.equal(ops.spconv_fwd(a, w.to(device), nbr, m, kernel="pingpong", **kw), ref), (cin, cout, m, reps)
-            plain = ops.spconv_fwd(a, w.to(device), nbr, m, in_b=kw["in_b"], replicas=reps)
-            assert torch.equal(ops.spconv_fwd(a, w.to(device), nbr, m, in_b=kw["in_b"], replicas=reps, kernel="pingpong"), plain)
-            if m > 200:
-                rows = torch.tensor([m - 77], dtype=torch.int32, device=device)
-                ref_d = ops.spconv_fwd(a, w.to(device), nbr, m, d_rows=rows, **kw)
-                got_d = ops.spconv_fwd(a, w.to(device), nbr, m, d_rows=rows, kernel="pingpong", **kw)
-                for r in range(reps):
-                    assert torch.equal(got_d[r * m:r * m + m - 77], ref_d[r * m:r * m + m - 77])
-        pick = np.random.default_rng(5).choice(m, min(m, 2000), replace=False)
-        want = me.conv_forward(x[:m].double(), w.double(), nbr_np[:, pick])
-        want = torch.relu(want * sc.double() + sh.double() + res[:m][pick].double())
-        got = ops.spconv_fwd(a, w.to(device), nbr, m, kernel="pingpong", **kw)
-        assert torch.allclose(got[:m][pick].cpu().double(), want, rtol=RTOL, atol=ATOL)
-
-
 @pytest.mark.parametrize("cin,split,cout", [(128, 0, 128), (256, 0, 256), (384, 256, 256), (128, 0, 256), (192, 128, 128), (64, 0, 128)])
 def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout):
     """lidiff_spconv_fwd_split3 (round 6): fp32 in / fp32 out with the contraction on the bf16 matrix pipe from three-way split
@@ -1250,56 +1170,6 @@ def test_spconv_bf16_operands_vs_oracle_on_rounded_inputs(device, kind, cin, cou
         assert torch.equal(got2[:m_out], got)
         # (the matrix unit's internal sum is not sign-symmetric to the last bit, so the negated replica is compared closely, not exactly)
         assert torch.allclose(got2[m_out:], -2.0 * got, rtol=1e-5, atol=1e-5)
-
-
-@pytest.mark.parametrize("planes", [2, 3])
-@pytest.mark.parametrize("kind,cin,cout,split,epilogue", [
-    ("k3", 32, 32, 0, False), ("k3", 64, 128, 0, True), ("k3", 96, 96, 0, False), ("k3", 256, 256, 0, False),
-    ("k3", 384, 256, 256, True), ("k3", 160, 64, 96, False), ("down", 128, 128, 0, False), ("up", 256, 128, 0, True),
-    ("k1", 384, 256, 256, False)])
-def test_spconv_from_bf16_pieces_is_fp32_accurate(device, planes, kind, cin, cout, split, epilogue):
-    """lidiff_spconv_fwd_bf16 with planes = 2 / 3 (the opt-in inference mode, ops.split_planes): every operand cut into
-    bf16 pieces, 3 / 6 bf16 MFMAs per block.  Against the float64 oracle on the UNROUNDED operands the result must pass the
-    fp32 kernel's own bar (rtol / atol 1e-4), and its maximum error is held against the native fp32 kernel's on the same
-    case: three pieces are fp32-equal (within 1.5x + 1e-6); two pieces keep 16-17 bits per product (the dropped x2 w2
-    terms are 2^-18 of the products) -- measured 10-25x the fp32 kernel's error, 2-4e-5 on O(1) outputs; bar: 20x or 5e-5."""
-    from lidiff_amd import ops
-    coords = random_cloud(4000, 6, 41, batch=2)
-    uniq, _, _ = me.voxelize(coords)
-    coarse, _ = me.stride_map(uniq, 2)
-    if kind == "k3":
-        nbr, m_in, m_out, K = me.kernel_map(uniq, uniq, 3, 1), uniq.shape[0], uniq.shape[0], 27
-    elif kind == "down":
-        nbr, m_in, m_out, K = me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0], coarse.shape[0], 8
-    elif kind == "up":
-        nbr = me.transpose_kernel_map(me.kernel_map(uniq, coarse, 2, 1), uniq.shape[0])
-        m_in, m_out, K = coarse.shape[0], uniq.shape[0], 8
-    else:
-        nbr, m_in, m_out, K = None, uniq.shape[0], uniq.shape[0], 1
-    g = torch.Generator().manual_seed(13)
-    x = torch.randn(m_in, cin, generator=g)
-    w = torch.randn(K, cin, cout, generator=g) / np.sqrt(cin * max(1, K // 3))
-    want = me.conv_forward(x.double(), w.double() if K > 1 else w[0].double(), nbr)
-    scale = shift = res = None
-    if epilogue:
-        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
-        res = torch.randn(m_out, cout, generator=g)
-        want = torch.relu(want * scale.double() + shift.double() + res.double())
-    d = lambda t: None if t is None else t.to(device)
-    nbr_d = None if nbr is None else dev_i32(nbr, device)
-    kw = dict(scale=d(scale), shift=d(shift), residual=d(res), relu=epilogue)
-    xa, xb = (d(x), None) if not split else (d(x[:, :split].contiguous()), d(x[:, split:].contiguous()))
-    got = ops.spconv_fwd_bf16(xa, d(w), nbr_d, m_out, in_b=xb, planes=planes, **kw)
-    f32 = ops.spconv_fwd(xa, d(w), nbr_d, m_out, in_b=xb, **kw)
-    torch.cuda.synchronize()
-    err = (got.cpu().double() - want).abs().max().item()
-    err32 = (f32.cpu().double() - want).abs().max().item()
-    assert torch.allclose(got.cpu().double(), want, rtol=RTOL, atol=ATOL), f"{kind} {cin}->{cout}: max err {err}"
-    assert err <= (max(20.0 * err32, 5e-5) if planes == 2 else 1.5 * err32 + 1e-6), (err, err32)
-    # the switch of the inference path takes this kernel for the dense 128-column layers only
-    with ops.split_planes(planes):
-        routed = ops.spconv_fwd(xa, d(w), nbr_d, m_out, in_b=xb, **kw)
-    assert torch.equal(routed, got if cout % 128 == 0 else f32)
 
 
 @pytest.mark.parametrize("kind,ks,stride,cin,cout", [("conv", 3, 1, 32, 64), ("conv", 2, 2, 64, 64), ("tconv", 2, 2, 64, 32),

@@ -34,7 +34,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
             assert (a is want) if want is not None else a in (C.c_int32, C.c_int64), (name, q, a)
             if want is None:
                 assert a is (C.c_int64 if q.startswith("int64_t") else C.c_int32), (name, q, a)
-    assert lib.lidiff_abi_version() == _lib.ABI_VERSION == 26
+    assert lib.lidiff_abi_version() == _lib.ABI_VERSION == 27
     assert lib.lidiff_hash_capacity(180000) == 524288 and lib.lidiff_hash_capacity(1) == 1024
     assert lib.lidiff_unique_workspace_bytes(1000) >= 1000 * 4
     # host-side argument validation reaches the error string without touching a device
@@ -332,30 +332,6 @@ def test_step_plan_is_pure_until_commit():
     broken.model_outputs = [None, None]
     with pytest.raises(RuntimeError, match="previous data prediction"):
         broken.step_plan(ts[4])
-
-
-@pytest.mark.parametrize("steps", [50, 10])
-def test_plan_table_is_the_step_plan_sequence(steps):
-    """plan_table() (the coefficient rows a captured step reads by a device counter, DiffCompletion.graph_steps) holds exactly the
-    scalars step_plan() hands out when the trajectory is walked with commits -- first step first order, second order after, and
-    (under 15 steps) the last one first order again -- and leaves the scheduler's multistep state alone."""
-    from lidiff_amd.schedulers import DPMSolverMultistepScheduler
-    mk = lambda: DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_start=3.5e-5, beta_end=0.007, beta_schedule="linear",
-                                             algorithm_type="sde-dpmsolver++", solver_order=2)
-    s, walk = mk(), mk()
-    s.set_timesteps(steps), walk.set_timesteps(steps)
-    s.commit(torch.ones(1))                                          # some state the table must not disturb
-    before = (list(s.model_outputs), s.lower_order_nums)
-    rows = s.plan_table()
-    assert (list(s.model_outputs), s.lower_order_nums) == before
-    assert len(rows) == steps
-    for i, t in enumerate(walk.host_timesteps):
-        plan = walk.step_plan(t)
-        assert rows[i]["second"] == (plan["m_prev"] is not None)
-        assert {k: v for k, v in plan.items() if k != "m_prev"} == {k: v for k, v in rows[i].items() if k != "second"}
-        walk.commit(torch.full((1,), float(i)))
-    assert not rows[0]["second"] and rows[1]["second"]
-    assert rows[-1]["second"] == (steps >= 15)
 
 
 @pytest.mark.parametrize("source", ["spconv_bf16.hip"])

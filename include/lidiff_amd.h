@@ -61,7 +61,11 @@ int lidiff_coords_floor(const float* coords_f, int64_t n_rows, int32_t* coords_i
 int lidiff_vox_unique(const int32_t* coords, int64_t n_rows,
                       uint64_t* hkeys, int32_t* hvals, int64_t cap,
                       int32_t* uniq, int32_t* first_idx, int64_t* inverse,
-                      int32_t* d_m, int32_t* d_status, void* workspace, void* stream);
+                      int32_t* d_m, int32_t* d_status, void* workspace, int32_t preinit, void* stream);
+/* preinit (this call, lidiff_map_stride_dev, lidiff_kernel_map_self_dev, lidiff_kernel_map_down_dev, lidiff_vox_mean): != 0 = the
+ * caller has ALREADY initialised what the call would otherwise clear itself -- hkeys / hvals / nbr / nbr_down filled with 0xFF bytes,
+ * the voxel-mean workspace with zeros -- so that all tables of a coordinate pyramid can live in one pool cleared by ONE memset
+ * (round 6: the denoising step queued 90 clears, one per table; lidiff_amd/ops.py build_pyramid*). */
 
 /* UNWEIGHTED_AVERAGE quantisation -- pipeline:77, models.py:171 (ME:
  * MinkowskiSPMMAverageFunction): out[v] = mean of feats[i] over inverse[i]==v.
@@ -70,7 +74,7 @@ int lidiff_vox_unique(const int32_t* coords, int64_t n_rows,
  * exact sum is rounded to fp32 once.  workspace: lidiff_vox_mean_workspace_bytes(m, c) bytes, 16-byte aligned. */
 int64_t lidiff_vox_mean_workspace_bytes(int64_t m, int32_t c);
 int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, int32_t c,
-                    int64_t m, float* out, float* counts, void* workspace, void* stream);
+                    int64_t m, float* out, float* counts, void* workspace, int32_t preinit, void* stream);
 /* backward of the above: grad_feats[i] = grad_out[inverse[i]] / counts[inverse[i]] */
 int lidiff_vox_mean_bwd(const float* grad_out, const int64_t* inverse, const float* counts,
                         int64_t n_rows, int32_t c, float* grad_feats, void* stream);
@@ -93,7 +97,7 @@ int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out,
  * written; tables keep the pitch of the bound (callers compact them with a strided copy once the sizes are known). */
 int lidiff_map_stride_dev(const int32_t* coords, int64_t n_rows_bound, const int32_t* d_n_rows, int32_t s_out,
                           uint64_t* hkeys, int32_t* hvals, int64_t cap, int32_t* coarse, int32_t* parent,
-                          int32_t* d_m, int32_t* d_status, void* workspace, void* stream);
+                          int32_t* d_m, int32_t* d_status, void* workspace, int32_t preinit, void* stream);
 
 /* Kernel map (rulebook) as a neighbour table -- MinkowskiConvolution ks=3 (minkunet.py:
  * 53-66,94,97,156,159,512,515) and ks=2/stride 2 (13-29) (ME: CoordinateMapManager::
@@ -112,7 +116,7 @@ int lidiff_kernel_map_self(const int32_t* coords, int64_t m, const uint64_t* hke
                            int32_t step, int32_t* nbr, void* stream);
 /* ... with the row count on the device: nbr [27, m_bound] (pitch m_bound), columns >= *d_m stay -1. */
 int lidiff_kernel_map_self_dev(const int32_t* coords, int64_t m_bound, const int32_t* d_m, const uint64_t* hkeys,
-                               const int32_t* hvals, int64_t cap, int32_t step, int32_t* nbr, void* stream);
+                               const int32_t* hvals, int64_t cap, int32_t step, int32_t* nbr, int32_t preinit, void* stream);
 
 /* The kernel_size-2 / stride-2 map of a strided convolution (fine map -> its coarse map, minkunet.py:13-29) from the
  * parent array lidiff_map_stride returned: nbr_down [8, m_coarse] -- the table lidiff_kernel_map(coarse coords, fine
@@ -122,7 +126,7 @@ int lidiff_kernel_map_down(const int32_t* fine_coords, const int32_t* parent, in
 /* ... with the fine map's row count on the device (*d_m_fine <= m_fine_bound); nbr_down [8, m_coarse_bound] (pitch = the bound of
  * the coarse map), columns without a fine row stay -1. */
 int lidiff_kernel_map_down_dev(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine_bound, const int32_t* d_m_fine,
-                               int32_t ts_fine, int64_t m_coarse_bound, int32_t* nbr_down, void* stream);
+                               int32_t ts_fine, int64_t m_coarse_bound, int32_t* nbr_down, int32_t preinit, void* stream);
 
 /* Kernel map of MinkowskiConvolutionTranspose(ks=2,stride=2) -- minkunet.py:32-46 (ME:
  * swapped fine->coarse map): nbr_up[k*m_fine + j] = parent[j] if k == kernel index of
@@ -284,7 +288,7 @@ int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b,
  *   lidiff_split3_rows: fp32 [m][c] -> bf16 [m][3][c] (the operand layout; c % 8 == 0);
  *   weights: lidiff_spconv_pack_weights_bf16 with planes = 3;
  *   lidiff_spconv_fwd_split3: in_a3 / in_b3 = split matrices of `replicas` stacked feature matrices (fused ME.cat as in
- *   lidiff_spconv_fwd), nbr / k_vol / m_in / m_out / epilogue / replicas / d_m_out as there; out_planes (nullable): the
+ *   lidiff_spconv_fwd), nbr / k_vol / m_in / m_out / epilogue / replicas / d_m_out / row_order as there; out_planes (nullable): the
  *   output ALSO as bf16 [replicas * m_out][3][c_out] -- the next dense convolution's operand, cut in the epilogue.
  *   Shapes: c_in_a, c_in_b multiples of 32, c_out a multiple of 128 (lidiff_spconv_fwd_split3_supported). */
 int lidiff_split3_rows(const float* src, int64_t m, int32_t c, void* dst, void* stream);
@@ -292,7 +296,13 @@ int32_t lidiff_spconv_fwd_split3_supported(int32_t c_in_a, int32_t c_in_b, int32
 int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const void* in_b3, int32_t c_in_b, const void* w_packed3,
                              const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                              void* out_planes, const float* ep_scale, const float* ep_shift, const float* residual,
-                             int32_t relu, int32_t replicas, const int32_t* d_m_out, void* stream);
+                             int32_t relu, int32_t replicas, const int32_t* d_m_out, const int32_t* row_order, void* stream);
+/* Rows sorted by their neighbour sets: lidiff_row_mask_keys writes, per row of a table nbr [k_vol][m], bit k = "has a neighbour
+ * under offset k" (the centre offset also as bit 27: a descending sort puts the valid rows of a table handed over at its bound
+ * first).  The caller sorts (stable, descending), permutes the table's columns (nbr[:, order]) and passes `row_order` = order
+ * (tile row -> output row) to lidiff_spconv_fwd_split3: results are the same values, but whole 16-row blocks of a tile then lack
+ * an offset and are neither gathered nor multiplied (the kernel's block masks) -- 30 % fewer MFMAs at stride 8, 70 % at stride 4. */
+int lidiff_row_mask_keys(const int32_t* nbr, int32_t k_vol, int64_t m, int32_t* keys, void* stream);
 
 /* Weight gradient of lidiff_spconv_fwd (training path, models.py:180-217; ME: ConvolutionBackwardGPU):
  * dw[k] += gather(in)[pairs_in of offset k]^T @ grad_out[pairs_out of offset k], in = [in_a | in_b], over the

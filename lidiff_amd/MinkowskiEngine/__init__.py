@@ -209,8 +209,10 @@ class CoordinateManager:
             sparse = tuple(h[lv] >= 1024 and h[lv + 1] >= 0.85 * h[lv] for lv in (0, 1))
             ups = tuple(lv for lv in range(1, levels + 1) if self.lane_up_orders and h[lv - 1] >= self.UP_ORDER_MIN_ROWS)
             with self.building():
+                sorted_lv = tuple(lv for lv in range(levels + 1)
+                                  if ops.SPLIT3_SORTED and ops.split3_layer(1 << lv, h[lv], 2, 128, 0, 128))
                 pyr = ops.build_pyramid_lanes(coords_i32, self.status, self.feed, second, third, strides=levels, on_level_dev=hook,
-                                              feats=feats, tail_levels=sparse, up_pairs_levels=ups)
+                                              feats=feats, tail_levels=sparse, up_pairs_levels=ups, sorted_levels=sorted_lv)
             # every map of the networks exists now and is handed over through per-level events (_acquire): no blanket join
             _lib.unmark_pending(self._async[0])
             self._feats0 = pyr.feats0
@@ -316,6 +318,11 @@ class CoordinateManager:
             with self.building():
                 self.aux[key].fill()
         return self.aux[key]
+
+    def kernel_map_mask_sorted(self, ts: int):
+        """(the kernel_size-3 table of level ts with its columns sorted by the rows' neighbour sets, the order): ops.mask_sorted_map,
+        cached on the table (a pyramid built in lanes sorts the levels the split-operand kernel will take on its own stream)."""
+        return ops.mask_sorted_map(self.kernel_map(ts, ts, 3))
 
     ORDER_MIN_ROWS = 30000      # smaller maps fit the L2 anyway
 

@@ -22,15 +22,15 @@ SIGNATURES = {
     "lidiff_hash_capacity": (_i64, [_i64]),
     "lidiff_unique_workspace_bytes": (_i64, [_i64]),
     "lidiff_coords_floor": (_i32, [_p, _i64, _p, _p]),
-    "lidiff_vox_unique": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "lidiff_vox_unique": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "lidiff_vox_mean_workspace_bytes": (_i64, [_i64, _i32]),
-    "lidiff_vox_mean": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p]),
+    "lidiff_vox_mean": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _i32, _p]),
     "lidiff_vox_mean_bwd": (_i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     "lidiff_map_stride": (_i32, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "lidiff_kernel_map": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
     "lidiff_kernel_map_self": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p, _p]),
-    "lidiff_kernel_map_self_dev": (_i32, [_p, _i64, _p, _p, _p, _i64, _i32, _p, _p]),
-    "lidiff_map_stride_dev": (_i32, [_p, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "lidiff_kernel_map_self_dev": (_i32, [_p, _i64, _p, _p, _p, _i64, _i32, _p, _i32, _p]),
+    "lidiff_map_stride_dev": (_i32, [_p, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _i32, _p]),
     "lidiff_tail_map_dev": (_i32, [_p, _i32, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p]),
     "lidiff_kernel_map_down": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p]),
     "lidiff_kernel_map_up": (_i32, [_p, _p, _i64, _i32, _p, _p]),
@@ -52,7 +52,8 @@ SIGNATURES = {
     "lidiff_cast_bf16": (_i32, [_p, _i64, _p, _p]),
     "lidiff_split3_rows": (_i32, [_p, _i64, _i32, _p, _p]),
     "lidiff_spconv_fwd_split3_supported": (_i32, [_i32, _i32, _i32]),
-    "lidiff_spconv_fwd_split3": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),
+    "lidiff_spconv_fwd_split3": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p]),
+    "lidiff_row_mask_keys": (_i32, [_p, _i32, _i64, _p, _p]),
     "lidiff_spconv_bwd_w_workspace_floats": (_i64, [_i32, _i32, _i32, _i64]),
     "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p]),
     "lidiff_spconv_bwd_w_bf16": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _i32, _p]),
@@ -82,7 +83,7 @@ SIGNATURES = {
     "lidiff_fps": (_i32, [_p, _i64, _i64, _p, _p, _p]),
     "lidiff_fps_coop_supported": (_i32, [_i64]),
     "lidiff_fps_coop": (_i32, [_p, _i64, _i64, _p, _p, _p, _p]),
-    "lidiff_kernel_map_down_dev": (_i32, [_p, _p, _i64, _p, _i32, _i64, _p, _p]),
+    "lidiff_kernel_map_down_dev": (_i32, [_p, _p, _i64, _p, _i32, _i64, _p, _i32, _p]),
     "lidiff_kernel_map_up_dev": (_i32, [_p, _p, _i64, _p, _i32, _p, _p]),
     "lidiff_tail_map_fill_bounded": (_i32, [_p, _i32, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "lidiff_publish_words": (_i32, [_p, _i32, _p, _p, _i32, _p]),

@@ -70,7 +70,7 @@ __global__ void insert_kernel(const int32_t* __restrict__ coords, int64_t n, con
             slot = (slot + 1) & mask;
         }
         if (!placed) { atomicOr(d_status, LIDIFF_STATUS_HASH_FULL); slot = 0; }
-        atomicMin(&hvals[slot], (int32_t)i);
+        atomicMin(reinterpret_cast<unsigned*>(&hvals[slot]), (unsigned)i);      // (unsigned: an empty slot reads 0xFFFFFFFF, the keys' byte pattern)
     }
     if (uni) slot = __builtin_amdgcn_readfirstlane(slot);
     slot_of[i] = (int32_t)slot;
@@ -162,11 +162,15 @@ __global__ void inverse_kernel(const int32_t* __restrict__ hvals, const int32_t*
 
 static int run_unique(const int32_t* coords, int64_t n, const int32_t* d_n, int s, uint64_t* hkeys, int32_t* hvals,
                       int64_t cap, int32_t* uniq, int32_t* first_idx, void* inverse, bool inverse64,
-                      int32_t* d_m, int32_t* d_status, void* workspace, hipStream_t st) {
+                      int32_t* d_m, int32_t* d_status, void* workspace, hipStream_t st, bool preinit = false) {
     LIDIFF_CHECK_ARG(n >= 0 && n < (1ll << 30), "row count out of range");
     LIDIFF_CHECK_ARG(cap >= 2 * n && (cap & (cap - 1)) == 0, "cap must be a power of two >= 2*n");
-    LIDIFF_CHECK_HIP(hipMemsetAsync(hkeys, 0xFF, (size_t)cap * sizeof(uint64_t), st));
-    LIDIFF_CHECK_HIP(hipMemsetAsync(hvals, 0x7F, (size_t)cap * sizeof(int32_t), st));
+    // keys and values start as 0xFF bytes (the empty key; the largest unsigned row index).  preinit: the caller has filled them --
+    // a pyramid's tables and neighbour tables live in ONE pool cleared by ONE memset (ops.build_pyramid_lanes), not one per table
+    if (!preinit) {
+        LIDIFF_CHECK_HIP(hipMemsetAsync(hkeys, 0xFF, (size_t)cap * sizeof(uint64_t), st));
+        LIDIFF_CHECK_HIP(hipMemsetAsync(hvals, 0xFF, (size_t)cap * sizeof(int32_t), st));
+    }
     if (n == 0) {
         LIDIFF_CHECK_HIP(hipMemsetAsync(d_m, 0, sizeof(int32_t), st));
         return 0;
@@ -1489,9 +1493,9 @@ int lidiff_coords_floor(const float* coords_f, int64_t n_rows, int32_t* coords_i
 
 int lidiff_vox_unique(const int32_t* coords, int64_t n_rows, uint64_t* hkeys, int32_t* hvals,
                       int64_t cap, int32_t* uniq, int32_t* first_idx, int64_t* inverse,
-                      int32_t* d_m, int32_t* d_status, void* workspace, void* stream) {
+                      int32_t* d_m, int32_t* d_status, void* workspace, int32_t preinit, void* stream) {
     return run_unique(coords, n_rows, nullptr, 1, hkeys, hvals, cap, uniq, first_idx, inverse, true, d_m,
-                      d_status, workspace, (hipStream_t)stream);
+                      d_status, workspace, (hipStream_t)stream, preinit != 0);
 }
 
 int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out, uint64_t* hkeys,
@@ -1504,11 +1508,11 @@ int lidiff_map_stride(const int32_t* coords, int64_t n_rows, int32_t s_out, uint
 
 int lidiff_map_stride_dev(const int32_t* coords, int64_t n_rows_bound, const int32_t* d_n_rows, int32_t s_out,
                           uint64_t* hkeys, int32_t* hvals, int64_t cap, int32_t* coarse, int32_t* parent, int32_t* d_m,
-                          int32_t* d_status, void* workspace, void* stream) {
+                          int32_t* d_status, void* workspace, int32_t preinit, void* stream) {
     LIDIFF_CHECK_ARG(s_out >= 1, "stride must be >= 1");
     LIDIFF_CHECK_ARG(d_n_rows != nullptr, "d_n_rows");
     return run_unique(coords, n_rows_bound, d_n_rows, s_out, hkeys, hvals, cap, coarse, nullptr, parent, false, d_m,
-                      d_status, workspace, (hipStream_t)stream);
+                      d_status, workspace, (hipStream_t)stream, preinit != 0);
 }
 
 int64_t lidiff_vox_mean_workspace_bytes(int64_t m, int32_t c) {
@@ -1516,7 +1520,7 @@ int64_t lidiff_vox_mean_workspace_bytes(int64_t m, int32_t c) {
 }
 
 int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, int32_t c, int64_t m,
-                    float* out, float* counts, void* workspace, void* stream) {
+                    float* out, float* counts, void* workspace, int32_t preinit, void* stream) {
     LIDIFF_CHECK_ARG(c > 0 && m >= 0 && n_rows >= 0, "bad shape");
     hipStream_t st = (hipStream_t)stream;
     if (m == 0) return 0;
@@ -1525,7 +1529,7 @@ int lidiff_vox_mean(const float* feats, const int64_t* inverse, int64_t n_rows, 
     uint32_t* amax = (uint32_t*)workspace;
     unsigned long long* acc = (unsigned long long*)((char*)workspace + 16);
     int32_t* cnt = (int32_t*)(acc + m * c);
-    LIDIFF_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)lidiff_vox_mean_workspace_bytes(m, c), st));
+    if (!preinit) LIDIFF_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)lidiff_vox_mean_workspace_bytes(m, c), st));
     int n_bits = 1;
     while ((1ll << n_bits) <= n_rows) ++n_bits;                       // n_rows < 2^n_bits
     if (n_rows > 0) {
@@ -1578,12 +1582,12 @@ int lidiff_kernel_map_self(const int32_t* coords, int64_t m, const uint64_t* hke
 }
 
 int lidiff_kernel_map_self_dev(const int32_t* coords, int64_t m_bound, const int32_t* d_m, const uint64_t* hkeys,
-                               const int32_t* hvals, int64_t cap, int32_t step, int32_t* nbr, void* stream) {
+                               const int32_t* hvals, int64_t cap, int32_t step, int32_t* nbr, int32_t preinit, void* stream) {
     LIDIFF_CHECK_ARG(cap > 0 && (cap & (cap - 1)) == 0, "cap must be a power of two");
     LIDIFF_CHECK_ARG(step >= 1 && d_m != nullptr, "step must be >= 1, d_m set");
     if (m_bound == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    LIDIFF_CHECK_HIP(hipMemsetAsync(nbr, 0xff, (size_t)27 * m_bound * sizeof(int32_t), st));
+    if (!preinit) LIDIFF_CHECK_HIP(hipMemsetAsync(nbr, 0xff, (size_t)27 * m_bound * sizeof(int32_t), st));
     kernel_map_self_kernel<<<(unsigned)ceil_div(m_bound, kBlock), kBlock, 0, st>>>(coords, m_bound, d_m, hkeys, hvals,
                                                                                    (uint32_t)(cap - 1), step, nbr);
     LIDIFF_CHECK_LAUNCH();
@@ -1604,11 +1608,11 @@ int lidiff_kernel_map_down(const int32_t* fine_coords, const int32_t* parent, in
 }
 
 int lidiff_kernel_map_down_dev(const int32_t* fine_coords, const int32_t* parent, int64_t m_fine_bound, const int32_t* d_m_fine,
-                               int32_t ts_fine, int64_t m_coarse_bound, int32_t* nbr_down, void* stream) {
+                               int32_t ts_fine, int64_t m_coarse_bound, int32_t* nbr_down, int32_t preinit, void* stream) {
     LIDIFF_CHECK_ARG(ts_fine >= 1 && d_m_fine != nullptr, "tensor stride must be >= 1, d_m_fine set");
     if (m_coarse_bound == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    LIDIFF_CHECK_HIP(hipMemsetAsync(nbr_down, 0xff, (size_t)8 * m_coarse_bound * sizeof(int32_t), st));
+    if (!preinit) LIDIFF_CHECK_HIP(hipMemsetAsync(nbr_down, 0xff, (size_t)8 * m_coarse_bound * sizeof(int32_t), st));
     if (m_fine_bound == 0) return 0;
     kernel_map_down_kernel<<<(unsigned)ceil_div(m_fine_bound, kBlock), kBlock, 0, st>>>(fine_coords, parent, m_fine_bound, d_m_fine,
                                                                                         ts_fine, m_coarse_bound, nbr_down);

@@ -75,6 +75,20 @@ __global__ void split3_rows_kernel(const float* __restrict__ src, int64_t m, int
     *reinterpret_cast<bf16x8*>(d + 2 * c) = q2;
 }
 
+// Sort keys for the rows of a neighbour table: bit k = the row has a neighbour under offset k; the centre offset (every valid row
+// has it) also as bit 27, so that a DESCENDING sort puts the valid rows of a table handed over at its bound first.  Rows sorted by
+// this key sit next to rows with (nearly) the same set of offsets: whole 16-row blocks then lack an offset and the kernel below
+// skips them (its block masks).
+__global__ void row_mask_keys_kernel(const int32_t* __restrict__ nbr, int k_vol, int64_t m, int32_t* __restrict__ keys) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    int32_t key = 0;
+    for (int k = 0; k < k_vol; ++k)
+        if (nbr[(int64_t)k * m + r] >= 0) key |= 1 << k;
+    if (nbr[(int64_t)(k_vol / 2) * m + r] >= 0) key |= 1 << 27;
+    keys[r] = key;
+}
+
 template <int BN>
 __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams p_launch) {
     constexpr int BM = 256, KS = 32, NW = 8, RG = 2, CG = 4;
@@ -91,7 +105,8 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     ConvParams p = p_launch;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* act = reinterpret_cast<int32_t*>(smem + 2 * STAGE);          // offsets with a neighbour in the tile; act[31] = count
-    int32_t* rowbuf = act + 32;                                           // [2][BM]: the tile's column of the table for an offset
+    int32_t* bmask = act + 32;                                            // per offset: which of the tile's 16-row blocks hold a neighbour
+    int32_t* rowbuf = bmask + 32;                                         // [2][BM]: the tile's column of the table for an offset
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, g = bid >> 3;
@@ -122,21 +137,32 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     };
     if (tid < 32) act[tid] = 0;
     __syncthreads();
+    // ... and, per offset, which of the tile's sixteen 16-row blocks hold a neighbour at all: a block without one is neither
+    // requested nor multiplied.  In table order that hardly ever happens on a dense level (P = (1 - occupancy)^16); with the
+    // caller's rows sorted by their neighbour masks (row_order: lidiff_row_mask_keys + a sort) the rows that have offset k sit
+    // together and 30-70 % of the (block, offset) pairs drop out.
     for (int k = wave; k < p.k_vol; k += NW) {
         int v[BM / 64];
 #pragma unroll
         for (int c = 0; c < BM / 64; ++c) v[c] = nbr_at(k, 64 * c + lane);
-        bool any = false;
+        unsigned bm = 0;
 #pragma unroll
-        for (int c = 0; c < BM / 64; ++c) any |= v[c] >= 0;
-        if (__ballot(any) != 0ull && lane == 0) act[k] = 1;
+        for (int c = 0; c < BM / 64; ++c) {
+            const unsigned long long b = __ballot(v[c] >= 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((b >> (16 * q)) & 0xffffull) bm |= 1u << (4 * c + q);
+        }
+        if (lane == 0) { act[k] = bm != 0; bmask[k] = (int32_t)bm; }
     }
     __syncthreads();
     if (wave == 0) {
         const bool on = lane < p.k_vol && act[lane] != 0;
+        const int mine = lane < p.k_vol ? bmask[lane] : 0;
         const unsigned long long m = __ballot(on);          // (one wave, in lockstep: every flag is read before any is overwritten)
-        if (on) act[popc_below(m)] = lane;
+        if (on) { act[popc_below(m)] = lane; }
         if (lane == 0) act[31] = __popcll(m);
+        (void)mine;
     }
     __syncthreads();
     const int nact = __builtin_amdgcn_readfirstlane(act[31]);
@@ -189,6 +215,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     // fixes what they ask for -- (offset, slab), the gather rows -- and moves the cursor on
     int i_oi = 0, i_slab = 0;
     int n_slot = 0, n_ws = 0, n_cw = 0, n_cb = 0;
+    unsigned n_bm = 0;                                       // the requested stage's block mask
     bool n_from_a = true;
     auto next_stage = [&](int sg) {
         n_slot = sg & 1;
@@ -197,6 +224,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
             request_rows(i_oi + 1);
         }
         const int k = to_sgpr(act[i_oi]);
+        n_bm = (unsigned)to_sgpr(bmask[k]);
         n_ws = (k * nslab + i_slab) * w_slab_bytes;
         const int k0 = i_slab * KS;
         n_from_a = k0 < p.c_in_a;
@@ -217,7 +245,8 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         for (int q = 0; q < 3; ++q) soff[q] = n_cb + q * n_cw;
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            const int t = wave + NW * j;
+            const int t = wave + NW * j;                     // a request = one 16-row block of one piece
+            if (!((n_bm >> t) & 1u)) continue;               // (no neighbour in the block under this offset: not requested, not multiplied)
             const int voff = row_cur[j] >= 0 ? row_cur[j] * (3 * n_cw) + chb[j] : (int)0x80000000;    // no neighbour: zeros, no bytes moved
 #pragma unroll
             for (int q = 0; q < 3; ++q)
@@ -247,56 +276,65 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     for (int sg = 0; sg < nst; ++sg) {
         LIDIFF_S3_BARRIER();                                 // stage sg has landed for every wave; the other slot is free
         const bool more = sg + 1 < nst;
+        const unsigned c_bm = n_bm;                          // the block mask of the stage being multiplied
         // The requests of the next stage: the first row group issues them in front of its MFMAs, the second one -- the SIMD
         // partners -- in the middle of its own: while one wave of a SIMD spends its ~10 request slots the other one multiplies
         // (measured, 256 -> 256 at stride 8: 3.55 ms against 3.69 with all eight waves requesting at the head of the stage; where
         // exactly the second group places them -- after one, two or three quarters of its MFMAs, rows and W apart or together --
         // moves nothing: +-2 %).  What bounds the kernel is the matrix pipe under the chip's power limit: 1.39 PFLOP/s executed,
         // the range MI355X_MICROARCH.md quotes for tuned bf16 attention (1.25-1.48) -- with all gather traffic switched off the
-        // same launch takes 3.33 ms.
+        // same launch takes 3.33 ms.  So the lever is the NUMBER of MFMAs: the block masks.
         if (more) next_stage(sg + 1);
         if (more && rg == 0) { issue_a(); issue_w(); }
         const char* st = smem + (sg & 1) * STAGE;
         const char* wsrc = st + ABYTES + (CBW * cg) * 3 * 1024 + lane * 16;
-        const char* asrc = st + (RBW * rg) * (16 * KS * 2) + foff;
+        // this wave's row blocks: 2 j + rg, j = 0 .. 7 (interleaved between the two row groups: under sorted rows the blocks that
+        // hold an offset are neighbours, and both waves of a SIMD should get their share of them)
+        const char* asrc = st + rg * (16 * KS * 2) + foff;
         bf16x8 w[CBW][3];
 #pragma unroll
         for (int c = 0; c < CBW; ++c)
 #pragma unroll
             for (int q = 0; q < 3; ++q) w[c][q] = *reinterpret_cast<const bf16x8*>(wsrc + (c * 3 + q) * 1024);
-        // fragment reads run one pair of row blocks ahead of the MFMAs; a request group sits between the reads and the MFMAs
-        // they feed (the "memory" clobber of a request keeps LDS reads from moving across it)
-        auto read_pair = [&](int jp, bf16x8 (*a)[3]) {
+        // the six products, smallest first; swapped operands (W fragment first): a lane ends up with 4 channels of one row
+#define LIDIFF_S3_PRODUCT(J, A, QA, QW)                                                                                    \
+    _Pragma("unroll") for (int c = 0; c < CBW; ++c)                                                                        \
+        acc_k[J][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][QW], A[QA], acc_k[J][c], 0, 0, 0)
+        auto read_block = [&](int j, bf16x8* a) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    a[jj][q] = *reinterpret_cast<const bf16x8*>(asrc + q * APLANE + (jp + jj) * (16 * KS * 2));
+            for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(asrc + q * APLANE + (2 * j) * (16 * KS * 2));
         };
-        auto mma_pair = [&](auto jp_tag, bf16x8 (*a)[3]) {
-            constexpr int jp = decltype(jp_tag)::value;
-            // the six products, smallest first; swapped operands (W fragment first): a lane ends up with 4 channels of one row
-#define LIDIFF_S3_PRODUCT(QA, QW)                                                                                          \
-    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) _Pragma("unroll") for (int c = 0; c < CBW; ++c)                       \
-        acc_k[jp + jj][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][QW], a[jj][QA], acc_k[jp + jj][c], 0, 0, 0)
-            LIDIFF_S3_PRODUCT(2, 0);
-            LIDIFF_S3_PRODUCT(0, 2);
-            LIDIFF_S3_PRODUCT(1, 1);
-            LIDIFF_S3_PRODUCT(1, 0);
-            LIDIFF_S3_PRODUCT(0, 1);
-            LIDIFF_S3_PRODUCT(0, 0);
-#undef LIDIFF_S3_PRODUCT
+        auto blocks = [&](auto p_tag) {                      // row blocks j = 2 P, 2 P + 1 of this wave, each only if it holds a neighbour
+            constexpr int J0 = 2 * decltype(p_tag)::value, J1 = J0 + 1;
+            const unsigned sel = ((c_bm >> (2 * J0 + rg)) & 1u) | (((c_bm >> (2 * J1 + rg)) & 1u) << 1);
+            if (sel == 3u) {
+                bf16x8 a0[3], a1[3];
+                read_block(J0, a0);
+                read_block(J1, a1);
+                LIDIFF_S3_PRODUCT(J0, a0, 2, 0); LIDIFF_S3_PRODUCT(J1, a1, 2, 0);
+                LIDIFF_S3_PRODUCT(J0, a0, 0, 2); LIDIFF_S3_PRODUCT(J1, a1, 0, 2);
+                LIDIFF_S3_PRODUCT(J0, a0, 1, 1); LIDIFF_S3_PRODUCT(J1, a1, 1, 1);
+                LIDIFF_S3_PRODUCT(J0, a0, 1, 0); LIDIFF_S3_PRODUCT(J1, a1, 1, 0);
+                LIDIFF_S3_PRODUCT(J0, a0, 0, 1); LIDIFF_S3_PRODUCT(J1, a1, 0, 1);
+                LIDIFF_S3_PRODUCT(J0, a0, 0, 0); LIDIFF_S3_PRODUCT(J1, a1, 0, 0);
+            } else if (sel == 1u) {
+                bf16x8 a0[3];
+                read_block(J0, a0);
+                LIDIFF_S3_PRODUCT(J0, a0, 2, 0); LIDIFF_S3_PRODUCT(J0, a0, 0, 2); LIDIFF_S3_PRODUCT(J0, a0, 1, 1);
+                LIDIFF_S3_PRODUCT(J0, a0, 1, 0); LIDIFF_S3_PRODUCT(J0, a0, 0, 1); LIDIFF_S3_PRODUCT(J0, a0, 0, 0);
+            } else if (sel == 2u) {
+                bf16x8 a1[3];
+                read_block(J1, a1);
+                LIDIFF_S3_PRODUCT(J1, a1, 2, 0); LIDIFF_S3_PRODUCT(J1, a1, 0, 2); LIDIFF_S3_PRODUCT(J1, a1, 1, 1);
+                LIDIFF_S3_PRODUCT(J1, a1, 1, 0); LIDIFF_S3_PRODUCT(J1, a1, 0, 1); LIDIFF_S3_PRODUCT(J1, a1, 0, 0);
+            }
         };
-        bf16x8 a0[2][3], a1[2][3];
-        read_pair(0, a0);
-        read_pair(2, a1);
-        mma_pair(ic<0>{}, a0);
-        read_pair(4, a0);
+        blocks(ic<0>{});
+        blocks(ic<1>{});
         if (more && rg == 1) { issue_a(); issue_w(); }
-        mma_pair(ic<2>{}, a1);
-        read_pair(6, a1);
-        mma_pair(ic<4>{}, a0);
-        mma_pair(ic<6>{}, a1);
+        blocks(ic<2>{});
+        blocks(ic<3>{});
+#undef LIDIFF_S3_PRODUCT
         if (++c_slab == nslab) {                             // the offset is complete: its sums join the others'
             c_slab = 0;
 #pragma unroll
@@ -310,7 +348,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     }
 #undef LIDIFF_S3_BARRIER
 
-    // ---- epilogue straight from the registers: lane (li, lq) holds channels n0 + 16 (CBW cg + c) + 4 lq .. + 3 of row 16 (RBW rg + j) + li
+    // ---- epilogue straight from the registers: lane (li, lq) holds channels n0 + 16 (CBW cg + c) + 4 lq .. + 3 of tile row 16 (2 j + rg) + li
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
         const int col = n0 + 16 * (CBW * cg + c) + 4 * lq;
@@ -319,9 +357,10 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + col);
 #pragma unroll
         for (int j = 0; j < RBW; ++j) {
-            const int r = 16 * (RBW * rg + j) + li;
+            const int r = 16 * (2 * j + rg) + li;
             if (r >= rows_here) continue;
-            const int64_t o = (row0 + r) * p.c_out + col;
+            const int64_t orow = p.row_order ? (int64_t)p.row_order[row0 + r] : row0 + r;     // tile row -> output row
+            const int64_t o = orow * p.c_out + col;
             float4 v = make_float4(acc[j][c][0], acc[j][c][1], acc[j][c][2], acc[j][c][3]);
             if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
             if (p.shift) { v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w; }
@@ -342,7 +381,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
                     split3(vv[e], p0, p1, p2);
                     q0[e] = p0; q1[e] = p1; q2[e] = p2;
                 }
-                __bf16* d = out3 + (row0 + r) * 3 * p.c_out + col;
+                __bf16* d = out3 + orow * 3 * p.c_out + col;
                 *reinterpret_cast<bf16x4*>(d) = q0;
                 *reinterpret_cast<bf16x4*>(d + p.c_out) = q1;
                 *reinterpret_cast<bf16x4*>(d + 2 * p.c_out) = q2;
@@ -353,7 +392,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
 
 template <int BN>
 static int launch_split3(const ConvParams& p, hipStream_t st) {
-    constexpr size_t lds = 2 * (size_t)(3 * 256 * 32 * 2 + 3 * (BN / 16) * 1024) + 32 * 4 + 2 * 256 * 4;
+    constexpr size_t lds = 2 * (size_t)(3 * 256 * 32 * 2 + 3 * (BN / 16) * 1024) + 2 * 32 * 4 + 2 * 256 * 4;
     auto kern = spconv_fwd_split3_kernel<BN>;
     static thread_local bool configured = false;
     if (!configured) {
@@ -383,6 +422,15 @@ extern "C" int lidiff_split3_rows(const float* src, int64_t m, int32_t c, void* 
     return 0;
 }
 
+extern "C" int lidiff_row_mask_keys(const int32_t* nbr, int32_t k_vol, int64_t m, int32_t* keys, void* stream) {
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && m >= 0, "kernel volume 1..27, rows >= 0");
+    if (m == 0) return 0;
+    LIDIFF_CHECK_ARG(nbr != nullptr && keys != nullptr, "null pointer");
+    row_mask_keys_kernel<<<(unsigned)ceil_div(m, 256), 256, 0, (hipStream_t)stream>>>(nbr, k_vol, m, keys);
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int32_t lidiff_spconv_fwd_split3_supported(int32_t c_in_a, int32_t c_in_b, int32_t c_out) {
     return c_in_a > 0 && c_in_a % 32 == 0 && c_in_b >= 0 && c_in_b % 32 == 0 && c_out > 0 && c_out % 128 == 0;
 }
@@ -390,7 +438,7 @@ extern "C" int32_t lidiff_spconv_fwd_split3_supported(int32_t c_in_a, int32_t c_
 extern "C" int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const void* in_b3, int32_t c_in_b, const void* w_packed3,
                                         const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                                         void* out_planes, const float* ep_scale, const float* ep_shift, const float* residual,
-                                        int32_t relu, int32_t replicas, const int32_t* d_m_out, void* stream) {
+                                        int32_t relu, int32_t replicas, const int32_t* d_m_out, const int32_t* row_order, void* stream) {
     LIDIFF_CHECK_ARG(in_a3 != nullptr && w_packed3 != nullptr && out != nullptr, "null pointer");
     LIDIFF_CHECK_ARG((in_b3 == nullptr) == (c_in_b == 0), "in_b3 and c_in_b must agree");
     LIDIFF_CHECK_ARG(lidiff_spconv_fwd_split3_supported(c_in_a, c_in_b, c_out), "widths: inputs multiples of 32, c_out a multiple of 128");
@@ -409,7 +457,7 @@ extern "C" int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const
                      "packed weights exceed the 2 GiB buffer-descriptor range");
     ConvParams p{};
     p.in_a = reinterpret_cast<const float*>(in_a3); p.in_b = reinterpret_cast<const float*>(in_b3);
-    p.wp = reinterpret_cast<const float*>(w_packed3); p.nbr = nbr; p.out = out; p.out_planes = out_planes;
+    p.wp = reinterpret_cast<const float*>(w_packed3); p.nbr = nbr; p.row_order = row_order; p.out = out; p.out_planes = out_planes;
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out; p.d_m_out = d_m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;

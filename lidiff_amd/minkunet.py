@@ -155,13 +155,16 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
             hints["tail_hint"] = mgr.tail_rows(ts_out)
         f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
                                    residual=residual, relu=relu, replicas=x.replicas, **hints)
-    elif (ops.SPLIT3 and not hint and conv.kernel_size == 3 and not conv.transposed and order is None and nbr is not None
-          and x.tensor_stride >= ops.SPLIT3_MIN_STRIDE and rows_out * x.replicas >= ops.SPLIT3_MIN_ROWS
-          and ops.split3_conv_applies(x.F.shape[1], 0 if extra is None else extra.shape[1], conv.out_channels)):
-        # the dense levels: the contraction on the bf16 matrix pipe from three-way split operands (fp32 accuracy, ops.SPLIT3);
-        # the output's own pieces are cut in the epilogue -- the next convolution of the level reads them
+    elif (not hint and conv.kernel_size == 3 and not conv.transposed and order is None and nbr is not None
+          and ops.split3_layer(x.tensor_stride, rows_out, x.replicas, x.F.shape[1], 0 if extra is None else extra.shape[1],
+                               conv.out_channels)):
+        # the dense levels: the contraction on the bf16 matrix pipe from three-way split operands (fp32 accuracy, ops.SPLIT3), the
+        # map's rows sorted by their neighbour sets (whole 16-row blocks then lack an offset and are skipped; same bits).  The
+        # output's own pieces are cut in the epilogue -- the next convolution of the level reads them
+        if ops.SPLIT3_SORTED:
+            nbr, order = mgr.kernel_map_mask_sorted(ts_out)
         f = ops.spconv_fwd_split3(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift, residual=residual,
-                                  relu=relu, replicas=x.replicas, d_rows=d_rows, want_planes=True)
+                                  relu=relu, replicas=x.replicas, d_rows=d_rows, want_planes=True, row_order=order)
     else:
         f = ops.spconv_fwd(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift,
                            residual=residual, relu=relu, sparse_map=hint, replicas=x.replicas, row_order=order, **hints)

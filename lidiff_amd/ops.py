@@ -22,10 +22,47 @@ STATUS_BOUND = 4          # a device-side count exceeded the bound a buffer was 
 class HashTable:
     """Open-addressing table of one coordinate map: packed 64-bit key -> row id."""
 
-    def __init__(self, n_rows: int, device):
+    def __init__(self, n_rows: int, device, pool: "BytePool | None" = None):
         self.cap = _lib.load().lidiff_hash_capacity(int(n_rows))
-        self.keys = torch.empty(self.cap, dtype=torch.int64, device=device)
-        self.vals = torch.empty(self.cap, dtype=torch.int32, device=device)
+        if pool is None:
+            self.keys = torch.empty(self.cap, dtype=torch.int64, device=device)
+            self.vals = torch.empty(self.cap, dtype=torch.int32, device=device)
+        else:                        # (views into the pool once it is committed: BytePool.commit)
+            self.keys, self.vals = pool.reserve((self.cap,), torch.int64), pool.reserve((self.cap,), torch.int32)
+            pool.on_commit(self, "keys", "vals")
+
+
+class BytePool:
+    """Several tensors that all START as the same byte pattern, carved out of ONE allocation cleared by ONE fill launch: the
+    hash tables and neighbour tables of a coordinate pyramid (0xFF: the empty key, row -1) and its zeroed workspaces.  Round 5
+    queued a clear per table -- 90 per denoising step --; the library calls take `preinit = 1` for pooled tables.
+    reserve() hands out a ticket, commit(byte) allocates + fills and turns the tickets into views (256-byte aligned)."""
+
+    def __init__(self, device):
+        self.device, self.items, self.total, self.buf, self.fix = device, [], 0, None, []
+
+    def reserve(self, shape, dtype):
+        nbytes = int(torch.empty((), dtype=dtype).element_size())
+        for d in shape:
+            nbytes *= int(d)
+        self.items.append((self.total, nbytes, tuple(int(d) for d in shape), dtype))
+        self.total += -(-max(nbytes, 1) // 256) * 256
+        return len(self.items) - 1
+
+    def on_commit(self, obj, *attrs):
+        self.fix.append((obj, attrs))
+
+    def commit(self, byte: int):
+        self.buf = torch.empty(max(self.total, 256), dtype=torch.uint8, device=self.device)
+        self.buf.fill_(byte)
+        for obj, attrs in self.fix:
+            for a in attrs:
+                setattr(obj, a, self.view(getattr(obj, a)))
+        return self
+
+    def view(self, ticket: int) -> torch.Tensor:
+        off, nbytes, shape, dtype = self.items[ticket]
+        return self.buf[off:off + nbytes].view(dtype).view(shape)
 
 
 def _workspace(n_rows: int, device):
@@ -56,7 +93,7 @@ def vox_unique(coords: torch.Tensor, status: torch.Tensor):
     d_m = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = _workspace(n, dev)
     call("lidiff_vox_unique", ptr(coords), n, ptr(table.keys), ptr(table.vals), table.cap,
-         ptr(uniq), ptr(first_idx), ptr(inverse), ptr(d_m), ptr(status), ptr(ws), stream_ptr())
+         ptr(uniq), ptr(first_idx), ptr(inverse), ptr(d_m), ptr(status), ptr(ws), 0, stream_ptr())
     m = int(d_m.item())
     return uniq[:m], inverse, first_idx[:m], table
 
@@ -265,13 +302,21 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     counts = torch.zeros(strides + 1 + tail_levels, dtype=torch.int32, device=dev)
     cptr = lambda i: counts.data_ptr() + 4 * i
     st = stream_ptr()
-    tables = [HashTable(n, dev)]
+    # every table that starts as 0xFF bytes -- the hash tables of all levels, the kernel_size-3 tables of the tail levels -- in ONE
+    # pool with ONE fill (preinit = 1 below); round 5: three clears per level and one per table
+    pool = BytePool(dev)
+    tables = [HashTable(n, dev, pool) for _ in range(strides + 1)]
+    nbr_t = [pool.reserve((27, n), torch.int32) for _ in range(min(tail_levels, strides + 1))]
+    pool.commit(0xFF)
+    if second_stream is not None:
+        pool.buf.record_stream(second_stream)
+    nbr_t = [pool.view(t) for t in nbr_t]
     rows = [torch.empty((n, 4), dtype=torch.int32, device=dev)]
     first_idx = torch.empty(n, dtype=torch.int32, device=dev)
     inverse = torch.empty(n, dtype=torch.int64, device=dev)
     keep = [_workspace(n, dev)]
     call("lidiff_vox_unique", ptr(coords), n, ptr(tables[0].keys), ptr(tables[0].vals), tables[0].cap, ptr(rows[0]),
-         ptr(first_idx), ptr(inverse), cptr(0), ptr(status), ptr(keep[0]), st)
+         ptr(first_idx), ptr(inverse), cptr(0), ptr(status), ptr(keep[0]), 1, st)
     _trace("level 0 queued")
     cur = torch.cuda.current_stream(dev)
     level_ev = []
@@ -281,12 +326,11 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
     parents = [None]
     for lv in range(1, strides + 1):
         _trace(f"level {lv}: alloc")
-        tables.append(HashTable(n, dev))
         rows.append(torch.empty((n, 4), dtype=torch.int32, device=dev))
         parents.append(torch.empty(n, dtype=torch.int32, device=dev))
         keep.append(_workspace(n, dev))
         call("lidiff_map_stride_dev", ptr(rows[lv - 1]), n, cptr(lv - 1), 1 << lv, ptr(tables[lv].keys), ptr(tables[lv].vals),
-             tables[lv].cap, ptr(rows[lv]), ptr(parents[lv]), cptr(lv), ptr(status), ptr(keep[lv]), st)
+             tables[lv].cap, ptr(rows[lv]), ptr(parents[lv]), cptr(lv), ptr(status), ptr(keep[lv]), 1, st)
         if second_stream is not None and lv < tail_levels:
             level_ev.append(torch.cuda.Event())
             level_ev[lv].record(cur)
@@ -301,9 +345,9 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
         for lv in range(min(tail_levels, strides + 1)):
             if second_stream is not None:
                 second_stream.wait_event(level_ev[lv])
-            nbr = torch.empty((27, n), dtype=torch.int32, device=dev)
+            nbr = nbr_t[lv]
             call("lidiff_kernel_map_self_dev", ptr(rows[lv]), n, cptr(lv), ptr(tables[lv].keys), ptr(tables[lv].vals),
-                 tables[lv].cap, 1 << lv, ptr(nbr), st2)
+                 tables[lv].cap, 1 << lv, ptr(nbr), 1, st2)
             ws = torch.empty(lib.lidiff_tail_map_workspace_bytes(27, n), dtype=torch.uint8, device=dev)
             off = torch.empty(28, dtype=torch.int32, device=dev)
             row_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
@@ -381,7 +425,7 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
 
 def build_pyramid_lanes(coords: torch.Tensor, status: torch.Tensor, feed: "SizeFeed", second_stream, third_stream,
                         strides: int = 4, on_level_dev=None, feats: torch.Tensor | None = None, tail_levels=(True, False),
-                        up_pairs_levels=()) -> Pyramid:
+                        up_pairs_levels=(), sorted_levels=()) -> Pyramid:
     """build_pyramid(read_free=True) with the work ordered by WHO WAITS FOR IT, and with EVERY map of LiDiff's networks queued
     up front (round 5).  Without a host read nothing about a map has to reach the host before it can be built, so nothing needs
     to be built "on demand" in the middle of the network any more (each such build stalled the network's queue for a chain of
@@ -402,28 +446,36 @@ def build_pyramid_lanes(coords: torch.Tensor, status: torch.Tensor, feed: "SizeF
     n, dev = coords.shape[0], coords.device
     lib = _lib.load()
     cur = torch.cuda.current_stream(dev)
-    counts = torch.zeros(strides + 3, dtype=torch.int32, device=dev)
-    cptr = lambda i: counts.data_ptr() + 4 * i
     i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
-    tables = [HashTable(n, dev) for _ in range(strides + 1)]
+    # Everything that starts as 0xFF bytes (hash tables, kernel_size-3 and kernel_size-2 neighbour tables of every level) lives in
+    # ONE pool cleared by ONE fill, everything that starts as zeros (the counts, the voxel-mean workspace) in a second one: two
+    # clears per pyramid where round 5 queued one per table (3 per hash table, 1 per neighbour table: ~30), VERDICT r5 #2
+    pool, zpool = BytePool(dev), BytePool(dev)
+    tables = [HashTable(n, dev, pool) for _ in range(strides + 1)]
+    nbr3 = [pool.reserve((27, n), torch.int32) for _ in range(strides + 1)]
+    down = [None] + [pool.reserve((8, n), torch.int32) for _ in range(strides)]           # down[lv]: level lv - 1 -> lv
+    pool.commit(0xFF)
+    nbr3, down = [pool.view(t) for t in nbr3], [None] + [pool.view(t) for t in down[1:]]
+    counts = zpool.reserve((strides + 3,), torch.int32)
+    mean_ws = zpool.reserve((lib.lidiff_vox_mean_workspace_bytes(n, feats.shape[1]),), torch.uint8) if feats is not None else None
+    zpool.commit(0)
+    counts, mean_ws = zpool.view(counts), (zpool.view(mean_ws) if mean_ws is not None else None)
+    cptr = lambda i: counts.data_ptr() + 4 * i
     rows = [i32(n, 4) for _ in range(strides + 1)]
     parents = [None] + [i32(n) for _ in range(strides)]
     keep = [_workspace(n, dev) for _ in range(strides + 1)]
     first_idx, inverse = i32(n), torch.empty(n, dtype=torch.int64, device=dev)
-    nbr3 = [i32(27, n) for _ in range(strides + 1)]
-    down = [None] + [i32(8, n) for _ in range(strides)]           # down[lv]: level lv - 1 -> lv
     up = [None] + [i32(8, n) for _ in range(strides)]             # up[lv]:   level lv -> lv - 1 (output rows: level lv - 1)
     tail_buf = [(torch.empty(lib.lidiff_tail_map_workspace_bytes(27, n), dtype=torch.uint8, device=dev), i32(28), i32(n + 1))
                 for _ in range(2)]
-    shared = ([counts, first_idx, inverse] + rows + parents[1:] + keep + nbr3 + down[1:] + up[1:]
-              + [q for tb in tables for q in (tb.keys, tb.vals)] + [q for tb in tail_buf for q in tb])
+    shared = ([pool.buf, zpool.buf, first_idx, inverse] + rows + parents[1:] + keep + up[1:] + [q for tb in tail_buf for q in tb])
     for t in shared:           # allocated under the current stream; the other lanes read / write them
         t.record_stream(third_stream)
         t.record_stream(second_stream)
 
     def kmap3(lv):
         call("lidiff_kernel_map_self_dev", ptr(rows[lv]), n, cptr(lv), ptr(tables[lv].keys), ptr(tables[lv].vals), tables[lv].cap,
-             1 << lv, ptr(nbr3[lv]), stream_ptr())
+             1 << lv, ptr(nbr3[lv]), 1, stream_ptr())
 
     def tail(lv, fill):
         ws, off, row_ptr = tail_buf[lv]
@@ -436,10 +488,10 @@ def build_pyramid_lanes(coords: torch.Tensor, status: torch.Tensor, feed: "SizeF
     out.ready, out.up_lists = {}, {}
     # ---- lane 1 (current stream): what the stem needs
     call("lidiff_vox_unique", ptr(coords), n, ptr(tables[0].keys), ptr(tables[0].vals), tables[0].cap, ptr(rows[0]),
-         ptr(first_idx), ptr(inverse), cptr(0), ptr(status), ptr(keep[0]), stream_ptr())
+         ptr(first_idx), ptr(inverse), cptr(0), ptr(status), ptr(keep[0]), 1, stream_ptr())
     ev = [torch.cuda.Event()]
     ev[0].record(cur)
-    out.feats0 = vox_mean(feats, inverse, n)[0] if feats is not None else None
+    out.feats0 = vox_mean(feats, inverse, n, zeroed_ws=mean_ws)[0] if feats is not None else None
     kmap3(0)
     tails = [tail(0, tail_levels[0])]
     out.ready[1] = out.fast = torch.cuda.Event()
@@ -449,14 +501,17 @@ def build_pyramid_lanes(coords: torch.Tensor, status: torch.Tensor, feed: "SizeF
     with torch.cuda.stream(third_stream):
         for lv in range(1, strides + 1):
             call("lidiff_map_stride_dev", ptr(rows[lv - 1]), n, cptr(lv - 1), 1 << lv, ptr(tables[lv].keys), ptr(tables[lv].vals),
-                 tables[lv].cap, ptr(rows[lv]), ptr(parents[lv]), cptr(lv), ptr(status), ptr(keep[lv]), stream_ptr())
+                 tables[lv].cap, ptr(rows[lv]), ptr(parents[lv]), cptr(lv), ptr(status), ptr(keep[lv]), 1, stream_ptr())
             ev.append(torch.cuda.Event())
             ev[lv].record(third_stream)
             call("lidiff_kernel_map_down_dev", ptr(rows[lv - 1]), ptr(parents[lv]), n, cptr(lv - 1), 1 << (lv - 1), n, ptr(down[lv]),
-                 stream_ptr())
+                 1, stream_ptr())
             kmap3(lv)
             if lv == 1:
                 tails.append(tail(1, tail_levels[1]))
+            if lv in sorted_levels:            # the row order the split-operand kernel skips blocks under (kept on the table tensor)
+                for t in mask_sorted_map(nbr3[lv]):
+                    t.record_stream(cur)
             out.ready[1 << lv] = torch.cuda.Event()
             out.ready[1 << lv].record(third_stream)
         third_stream.wait_event(out.fast)                   # (level 0's tail count is part of the record)
@@ -481,15 +536,18 @@ def build_pyramid_lanes(coords: torch.Tensor, status: torch.Tensor, feed: "SizeF
     return out
 
 
-def vox_mean(feats: torch.Tensor, inverse: torch.Tensor, m: int):
-    """UNWEIGHTED_AVERAGE features (pipeline:77).  Returns (out[M,C], counts[M]).  Deterministic (fixed-point sums)."""
+def vox_mean(feats: torch.Tensor, inverse: torch.Tensor, m: int, zeroed_ws: torch.Tensor | None = None):
+    """UNWEIGHTED_AVERAGE features (pipeline:77).  Returns (out[M,C], counts[M]).  Deterministic (fixed-point sums).
+    zeroed_ws: a workspace the caller has already zeroed (part of a pyramid's zero pool: no clear of its own)."""
     require_device(feats, inverse)
     feats = feats.contiguous().float()
     n, c = feats.shape
     out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
     counts = torch.empty(m, dtype=torch.float32, device=feats.device)
-    ws = torch.empty(_lib.load().lidiff_vox_mean_workspace_bytes(int(m), int(c)), dtype=torch.uint8, device=feats.device)
-    call("lidiff_vox_mean", ptr(feats), ptr(inverse), n, c, m, ptr(out), ptr(counts), ptr(ws), stream_ptr())
+    need = _lib.load().lidiff_vox_mean_workspace_bytes(int(m), int(c))
+    ws = zeroed_ws if zeroed_ws is not None else torch.empty(need, dtype=torch.uint8, device=feats.device)
+    assert ws.numel() >= need and ws.dtype == torch.uint8
+    call("lidiff_vox_mean", ptr(feats), ptr(inverse), n, c, m, ptr(out), ptr(counts), ptr(ws), int(zeroed_ws is not None), stream_ptr())
     return out, counts
 
 
@@ -524,7 +582,7 @@ def kernel_map_self_dev(coords_bound: torch.Tensor, d_rows: torch.Tensor, table:
     n = coords_bound.shape[0]
     nbr = torch.empty((27, n), dtype=torch.int32, device=coords_bound.device)
     call("lidiff_kernel_map_self_dev", ptr(coords_bound), n, ptr(d_rows), ptr(table.keys), ptr(table.vals), table.cap, int(step),
-         ptr(nbr), stream_ptr())
+         ptr(nbr), 0, stream_ptr())
     return nbr
 
 
@@ -535,7 +593,7 @@ def kernel_map_down_dev(fine_bound: torch.Tensor, parent_bound: torch.Tensor, d_
     assert parent_bound.dtype == torch.int32 and parent_bound.shape[0] == fine_bound.shape[0] and fine_bound.is_contiguous()
     nbr = torch.empty((8, m_coarse_bound), dtype=torch.int32, device=fine_bound.device)
     call("lidiff_kernel_map_down_dev", ptr(fine_bound), ptr(parent_bound), fine_bound.shape[0], ptr(d_rows_fine), int(ts_fine),
-         int(m_coarse_bound), ptr(nbr), stream_ptr())
+         int(m_coarse_bound), ptr(nbr), 0, stream_ptr())
     return nbr
 
 
@@ -1241,8 +1299,17 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
 # widths lidiff_spconv_fwd_split3 takes) through the three-way split bf16 kernel: fp32 in, fp32 out, fp32 accuracy (include/lidiff_amd.h).
 # LIDIFF_SPLIT3=0: every layer on the native fp32-MFMA kernel.
 SPLIT3 = os.environ.get("LIDIFF_SPLIT3", "1") != "0"
-SPLIT3_MIN_STRIDE = int(os.environ.get("LIDIFF_SPLIT3_MIN_STRIDE", "8"))
-SPLIT3_MIN_ROWS = 8192          # smaller maps (the condition encoders) do not fill the chip with 256-row tiles
+SPLIT3_MIN_STRIDE = int(os.environ.get("LIDIFF_SPLIT3_MIN_STRIDE", "4"))
+SPLIT3_MIN_TILES = 256          # fewer 256 x 128 tiles than compute units (the condition encoders, late steps' coarse levels): native kernel
+# ... with the rows of the map sorted by their neighbour sets (mask_sorted_map), so that the kernel skips whole 16-row blocks
+SPLIT3_SORTED = os.environ.get("LIDIFF_SPLIT3_SORTED", "1") != "0"
+
+
+def split3_layer(tensor_stride: int, rows: int, replicas: int, c_in_a: int, c_in_b: int, c_out: int) -> bool:
+    """Does the fused plan run a kernel_size-3 convolution of this shape on the split-operand kernel?  (rows: what the host
+    believes -- exact, or the same level of the role's previous pyramid)"""
+    return (SPLIT3 and tensor_stride >= SPLIT3_MIN_STRIDE and split3_conv_applies(c_in_a, c_in_b, c_out)
+            and -(-rows * replicas // 256) * (c_out // 128) >= SPLIT3_MIN_TILES)
 
 
 class split3:
@@ -1278,18 +1345,37 @@ def split3_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def mask_sorted_map(nbr: torch.Tensor):
+    """(nbr[:, order], order) with the rows of a neighbour table sorted by their neighbour sets (lidiff_row_mask_keys, stable
+    descending sort): the row order spconv_fwd_split3 skips whole 16-row blocks under.  Valid rows first (a table handed over at
+    its bound keeps its device-side count).  Cached on the table tensor."""
+    hit = getattr(nbr, "_lidiff_mask_sorted", None)
+    if hit is None:
+        require_device(nbr)
+        k, m = nbr.shape
+        keys = torch.empty(m, dtype=torch.int32, device=nbr.device)
+        call("lidiff_row_mask_keys", ptr(nbr), k, m, ptr(keys), stream_ptr())
+        order = torch.sort(keys, descending=True, stable=True).indices
+        hit = (nbr.index_select(1, order).contiguous(), order.to(torch.int32))
+        nbr._lidiff_mask_sorted = hit
+    return hit
+
+
 def split3_conv_applies(c_in_a: int, c_in_b: int, c_out: int) -> bool:
     return bool(_lib.load().lidiff_spconv_fwd_split3_supported(int(c_in_a), int(c_in_b), int(c_out)))
 
 
 def spconv_fwd_split3(in_a, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int, in_b=None, scale=None, shift=None,
                       residual=None, relu: bool = False, replicas: int = 1, d_rows: torch.Tensor | None = None,
-                      want_planes: bool = False) -> torch.Tensor:
+                      want_planes: bool = False, row_order: torch.Tensor | None = None) -> torch.Tensor:
     """spconv_fwd (fp32 in, fp32 out, fp32 accuracy) with the contraction on the bf16 matrix pipe from three-way split operands
     (lidiff_spconv_fwd_split3; include/lidiff_amd.h).  in_a / in_b: fp32 [R * M_in, C] (cut here, the cut cached on the
     tensor) or the bf16 [R * M_in, 3, C] pieces themselves.  want_planes: the result carries its own pieces
-    (`_lidiff_split3`, written by the kernel's epilogue) for the next dense convolution."""
-    require_device(w, nbr, scale, shift, residual)
+    (`_lidiff_split3`, written by the kernel's epilogue) for the next dense convolution.  row_order: int32 permutation of the
+    output rows with `nbr` holding its columns in that order (mask_sorted_map); results do not depend on it."""
+    require_device(w, nbr, scale, shift, residual, row_order)
+    if row_order is not None:
+        assert row_order.dtype == torch.int32 and row_order.shape == (m_out,) and row_order.is_contiguous() and nbr is not None
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
     k, c_in, c_out = w3.shape
     wp = packed_weights_bf16(w, planes=3)
@@ -1314,7 +1400,7 @@ def spconv_fwd_split3(in_a, w: torch.Tensor, nbr: torch.Tensor | None, m_out: in
         _lib.join_pending()
         start.record()
     call("lidiff_spconv_fwd_split3", ptr(a3), c_a, ptr(b3), c_b, ptr(wp), ptr(nbr), k, m_in, m_out, c_out, ptr(out), ptr(out3),
-         ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), ptr(d_rows), stream_ptr())
+         ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), ptr(d_rows), ptr(row_order), stream_ptr())
     if timed:
         end.record()
     if prof is not None:

@@ -789,6 +789,12 @@ def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout):
                 scale_out = want.abs().max().item()
                 assert e3 <= 1.5 * en + 1.2e-7 * scale_out, (cin, cout, m, e3, en)
                 worst[n_pts] = max(worst.get(n_pts, (0, 0)), (e3, en))
+            # rows sorted by their neighbour sets (whole 16-row blocks then lack an offset and are skipped): the same bits -- a
+            # skipped block contributes what the multiplied zeros contributed, nothing
+            nbr_s, order = ops.mask_sorted_map(nbr)
+            assert torch.equal(torch.sort(order.long()).values, torch.arange(m, device=device))
+            got_s = ops.spconv_fwd_split3(a, w.to(device), nbr_s, m, in_b=b, want_planes=True, row_order=order, **kw)
+            assert torch.equal(got_s, got) and torch.equal(got_s._lidiff_split3[1], got._lidiff_split3[1])
             planes = got._lidiff_split3[1].float()
             assert torch.equal(planes[:, 0] + planes[:, 1] + planes[:, 2], got)
             assert torch.equal(planes, ops.split3_rows(got.clone()).float())
@@ -803,6 +809,11 @@ def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout):
                 got_d = ops.spconv_fwd_split3(a, w.to(device), nbr_d, m, in_b=b, d_rows=rows, **kw)
                 for r in range(reps):
                     assert torch.equal(got_d[r * m:r * m + m - 77], got[r * m:r * m + m - 77])
+                nbr_ds, order_d = ops.mask_sorted_map(nbr_d)               # (valid rows first: the count still describes them)
+                assert int(order_d[:m - 77].max()) < m - 77
+                got_ds = ops.spconv_fwd_split3(a, w.to(device), nbr_ds, m, in_b=b, d_rows=rows, row_order=order_d, **kw)
+                for r in range(reps):
+                    assert torch.equal(got_ds[r * m:r * m + m - 77], got[r * m:r * m + m - 77])
     # kernel_size 1 (identity map)
     w1 = torch.randn(1, cin, cout, generator=g) / np.sqrt(cin)
     got1 = ops.spconv_fwd_split3(a, w1.to(device), None, m, in_b=b, replicas=reps)

@@ -120,7 +120,8 @@ def main():
             conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out, replicas=args.replicas, sparse_map=hint)
         elif args.kernel == "split3" and ops.split3_conv_applies(cin, 0, cout):
             x3 = ops.split3_rows(x)
-            conv = lambda: ops.spconv_fwd_split3(x3, w, nbr, m_out, replicas=args.replicas)
+            nbr_s, order_s = (ops.mask_sorted_map(nbr) if args.flags & 1 else (nbr, None))
+            conv = lambda: ops.spconv_fwd_split3(x3, w, nbr_s, m_out, replicas=args.replicas, row_order=order_s)
         elif args.kernel == "bf16" and ops.bf16_conv_applies(cin, 0, cout):
             xin = ops.cast_bf16(x) if args.rows16 else x
             conv = lambda: ops.spconv_fwd_bf16(xin, w, nbr, m_out, planes=args.planes, replicas=args.replicas,

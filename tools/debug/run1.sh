@@ -1,6 +1,8 @@
-cd $GRAFT_REPO_ROOT
-FAST="--no-cpu-baseline --no-coords-roofline --no-train --no-alt --no-closed-loop"
-for s in 1 0; do echo "== SPLIT3=$s"; LIDIFF_SPLIT3=$s timeout 900 python bench.py --steps 20 --warmup 5 $FAST --all-variants --layer-table gpurun_out/layer_table_split3_$s.txt 2>gpurun_out/bench_err_$s.txt | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d.get('roofline'))"; done
-LIDIFF_SPLIT3=1 timeout 1500 python -m pytest tests/test_gpu_network.py tests/test_gpu_baseline.py -x -q -k "golden or batch2 or realistic or completion_loop or cfg_pair or c1 or network_conv or closed" 2>&1 | tail -8
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+FAST="--no-cpu-baseline --no-coords-roofline --no-train --no-alt --no-closed-loop --no-kernel-events"
+rm -rf $R/gpurun_out/prof_r06
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r06 -o x -- python $R/bench.py --steps 20 --warmup 5 $FAST > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/bench_under_rocprof.err
+cd $R; python tools/rocpd_stats.py gpurun_out/prof_r06/x_results.db --top 45 > gpurun_out/r06_kernel_stats.md
+python tools/rocpd_main_queue.py gpurun_out/prof_r06/x_results.db > gpurun_out/r06_main_queue.txt 2>&1
+rm -rf gpurun_out/prof_r06

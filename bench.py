@@ -38,8 +38,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md "Pea
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0
 # what the path computes in when ops.SPLIT3 is on (the default): said in full, because it is NOT the plain fp32 MFMA everywhere
-DTYPE_SPLIT3 = ("f32 in / f32 out / f32 accumulate everywhere; kernel_size-3 convolutions of the dense levels (tensor stride >= 8, "
-                "C_out % 128 == 0): each fp32 operand cut into 3 bf16 pieces (exact sum), the 6 piece products with i + j <= 2 on "
+DTYPE_SPLIT3 = ("f32 in / f32 out / f32 accumulate everywhere; kernel_size-3 convolutions on maps of tensor stride >= 4 with C_out % 64 == 0 "
+                "that fill the chip (>= 256 tiles): each fp32 operand cut into 3 bf16 pieces (exact sum), the 6 piece products with i + j <= 2 on "
                 "v_mfma_f32_16x16x32_bf16, dropped terms < 2^-24 |x w| -- error vs float64 equal to the native fp32 MFMA kernel's "
                 "(tests/test_gpu_kernels.py::test_spconv_split3_is_an_fp32_convolution; the whole GPU parity suite runs in this mode at "
                 "the native kernel's bars); every other kernel: native fp32 (v_mfma_f32_16x16x4_f32 / VALU). LIDIFF_SPLIT3=0: native "
@@ -743,8 +743,10 @@ def main():
             "achieved_note": ("algorithmic: 6 bf16 MFMA products per fp32 product x 2 P C_in C_out per launch / HIP-event time, against the "
                               "dense bf16 MFMA peak" if s3 else "algorithmic 2 P C_in C_out per launch / HIP-event time, against the fp32 MFMA peak"),
             "fp32_equivalent_tflops": tflops, "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "fp32_equivalent_over_fp32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS,
-            "executed_mfma_tflops": d["mfma_flops_timed"] / (d["ms"] * 1e-3) / 1e12,
-            "executed_note": "what the matrix pipe runs, rows without a neighbour included (the wide tiles multiply them as zeros)" if s3 else None,
+            "all_rows_all_offsets_tflops": d["mfma_flops_timed"] / (d["ms"] * 1e-3) / 1e12 if s3 else None,
+            "all_rows_all_offsets_note": ("6 products x every row of every 256-row tile x every offset / time: what the matrix pipe WOULD run "
+                                          "without the kernel's block masks (16-row blocks that lack an offset are skipped: 30 % of them at stride "
+                                          "8, 70 % at stride 4 under mask-sorted rows) -- an upper bound of the executed rate, not the rate") if s3 else None,
             "traffic": traffic, "launches": d["timed"], "avg_us": 1e3 * d["ms"] / max(1, d["timed"]),
             "traffic_unit": "GB per launch (HBM-side, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": None if traffic is None else f"static: {traffic_src} (tools/pmc_bench.sh over this bench "

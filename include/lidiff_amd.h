@@ -290,7 +290,7 @@ int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b,
  *   lidiff_spconv_fwd_split3: in_a3 / in_b3 = split matrices of `replicas` stacked feature matrices (fused ME.cat as in
  *   lidiff_spconv_fwd), nbr / k_vol / m_in / m_out / epilogue / replicas / d_m_out / row_order as there; out_planes (nullable): the
  *   output ALSO as bf16 [replicas * m_out][3][c_out] -- the next dense convolution's operand, cut in the epilogue.
- *   Shapes: c_in_a, c_in_b multiples of 32, c_out a multiple of 128 (lidiff_spconv_fwd_split3_supported). */
+ *   Shapes: c_in_a, c_in_b multiples of 32, c_out a multiple of 64 (lidiff_spconv_fwd_split3_supported). */
 int lidiff_split3_rows(const float* src, int64_t m, int32_t c, void* dst, void* stream);
 int32_t lidiff_spconv_fwd_split3_supported(int32_t c_in_a, int32_t c_in_b, int32_t c_out);
 int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const void* in_b3, int32_t c_in_b, const void* w_packed3,

@@ -89,19 +89,22 @@ __global__ void row_mask_keys_kernel(const int32_t* __restrict__ nbr, int k_vol,
     keys[r] = key;
 }
 
+#ifndef LIDIFF_S3_CBW
+#define LIDIFF_S3_CBW 2          // column blocks per wave on 128-column tiles (4 = 64 x 64 wave tiles: fewer LDS reads, measured +1.5 % SLOWER)
+#endif
 template <int BN>
 __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams p_launch) {
-    constexpr int BM = 256, KS = 32, NW = 8, RG = 2, CG = 4;
-    constexpr int RBW = (BM / 16) / RG;                     // row blocks per wave (8)
-    constexpr int CBW = (BN / 16) / CG;                     // column blocks per wave (2)
+    // 8 waves as RG row groups x CG column groups, a wave = RBW row blocks x 2 column blocks: 128 columns -> 2 x 4 (8 x 2 blocks),
+    // 64 columns -> 4 x 2 (4 x 2 blocks)
+    constexpr int BM = 256, KS = 32, NW = 8, CBW = (BN == 128 ? LIDIFF_S3_CBW : 2), CG = (BN / 16) / CBW, RG = NW / CG;
+    constexpr int RBW = (BM / 16) / RG;                     // row blocks per wave (8 / 4)
     constexpr int APLANE = BM * KS * 2;                     // one piece of the stage's rows: 16 KB
     constexpr int ABYTES = 3 * APLANE;
     constexpr int WBLK = 3 * (BN / 16);                     // 1 KB W blocks per stage: [column block][piece]
     constexpr int WBYTES = WBLK * 1024;
     constexpr int STAGE = ABYTES + WBYTES;
     constexpr int NCHK = 4, RPI = 16, T = (BM / RPI) / NW;  // row requests per wave, piece and stage (2)
-    constexpr int TW = WBLK / NW;                           // W requests per wave and stage (3)
-    static_assert(WBLK % NW == 0 && (BM / RPI) % NW == 0 && RBW == 8, "request split");
+    static_assert((BM / RPI) % NW == 0 && RBW % 2 == 0 && CG * RG == NW && (BN == 128 || BN == 64), "request split");
     ConvParams p = p_launch;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* act = reinterpret_cast<int32_t*>(smem + 2 * STAGE);          // offsets with a neighbour in the tile; act[31] = count
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     // the requests of one stage, in two parts (placed separately in the wave's instruction stream, see the loop): next_stage()
     // fixes what they ask for -- (offset, slab), the gather rows -- and moves the cursor on
     int i_oi = 0, i_slab = 0;
-    int n_slot = 0, n_ws = 0, n_cw = 0, n_cb = 0;
+    int n_slot = 0, n_ws = 0, n_cw = 0, n_cb = 0, n_k = 0;
     unsigned n_bm = 0;                                       // the requested stage's block mask
     bool n_from_a = true;
     auto next_stage = [&](int sg) {
@@ -222,9 +225,10 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         if (i_slab == 0) {                                   // a new offset: its rows were requested one offset ago
             take_rows(i_oi);
             request_rows(i_oi + 1);
+            n_k = to_sgpr(act[i_oi]);                        // (looked up once per offset, not per stage: two LDS round trips at the
+            n_bm = (unsigned)to_sgpr(bmask[n_k]);            //  head of a stage, in front of its requests)
         }
-        const int k = to_sgpr(act[i_oi]);
-        n_bm = (unsigned)to_sgpr(bmask[k]);
+        const int k = n_k;
         n_ws = (k * nslab + i_slab) * w_slab_bytes;
         const int k0 = i_slab * KS;
         n_from_a = k0 < p.c_in_a;
@@ -234,10 +238,8 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     };
     auto issue_w = [&]() {
 #pragma unroll
-        for (int j = 0; j < TW; ++j) {
-            const int b = wave + NW * j;
+        for (int b = wave; b < WBLK; b += NW)
             s3_dma16(rsrc_w, s_base + n_slot * STAGE + ABYTES + b * 1024, (((n0 >> 4) * 3 + b) * 64 + lane) * 16, n_ws);
-        }
     };
     auto issue_a = [&]() {
         int soff[3];
@@ -273,8 +275,20 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (nst > 0) { next_stage(0); issue_a(); issue_w(); }
     int c_slab = 0;
+    const int abl = p.flags;                                 // measurement aid (LIDIFF_S3_ABLATE; results are wrong with any bit set)
+#ifdef LIDIFF_CONV_PROBE
+    long long tq_bar = 0, tq_head = 0, tq_dma = 0, tq_w = 0, tq_mma = 0, tq_fold = 0;
+    const long long tq_start = __builtin_readcyclecounter();
+#define S3_T(var) { const long long now_ = __builtin_readcyclecounter(); var += now_ - tq_last; tq_last = now_; }
+#else
+#define S3_T(var)
+#endif
     for (int sg = 0; sg < nst; ++sg) {
-        LIDIFF_S3_BARRIER();                                 // stage sg has landed for every wave; the other slot is free
+#ifdef LIDIFF_CONV_PROBE
+        long long tq_last = __builtin_readcyclecounter();
+#endif
+        if (!(abl & 4)) LIDIFF_S3_BARRIER();                 // stage sg has landed for every wave; the other slot is free
+        S3_T(tq_bar);
         const bool more = sg + 1 < nst;
         const unsigned c_bm = n_bm;                          // the block mask of the stage being multiplied
         // The requests of the next stage: the first row group issues them in front of its MFMAs, the second one -- the SIMD
@@ -285,55 +299,50 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         // the range MI355X_MICROARCH.md quotes for tuned bf16 attention (1.25-1.48) -- with all gather traffic switched off the
         // same launch takes 3.33 ms.  So the lever is the NUMBER of MFMAs: the block masks.
         if (more) next_stage(sg + 1);
-        if (more && rg == 0) { issue_a(); issue_w(); }
+        S3_T(tq_head);
+        if (more && wave < NW / 2 && !(abl & 1)) { issue_a(); issue_w(); }
+        S3_T(tq_dma);
         const char* st = smem + (sg & 1) * STAGE;
         const char* wsrc = st + ABYTES + (CBW * cg) * 3 * 1024 + lane * 16;
-        // this wave's row blocks: 2 j + rg, j = 0 .. 7 (interleaved between the two row groups: under sorted rows the blocks that
-        // hold an offset are neighbours, and both waves of a SIMD should get their share of them)
+        // this wave's row blocks: RG j + rg, j = 0 .. RBW - 1 (interleaved between the row groups: under sorted rows the blocks that
+        // hold an offset are neighbours, and every wave should get its share of them)
         const char* asrc = st + rg * (16 * KS * 2) + foff;
         bf16x8 w[CBW][3];
 #pragma unroll
         for (int c = 0; c < CBW; ++c)
 #pragma unroll
             for (int q = 0; q < 3; ++q) w[c][q] = *reinterpret_cast<const bf16x8*>(wsrc + (c * 3 + q) * 1024);
-        // the six products, smallest first; swapped operands (W fragment first): a lane ends up with 4 channels of one row
+        // Row block after row block: the fragment reads of block j + 1 are issued (always -- a block that is skipped costs three
+        // idle LDS reads) in front of the twelve MFMAs of block j (only if the block holds a neighbour under this offset: a
+        // wave-uniform branch), so that no MFMA group waits for its own reads.  The six products, smallest first; swapped operands
+        // (W fragment first): a lane ends up with 4 channels of one row.
 #define LIDIFF_S3_PRODUCT(J, A, QA, QW)                                                                                    \
     _Pragma("unroll") for (int c = 0; c < CBW; ++c)                                                                        \
         acc_k[J][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][QW], A[QA], acc_k[J][c], 0, 0, 0)
         auto read_block = [&](int j, bf16x8* a) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(asrc + q * APLANE + (2 * j) * (16 * KS * 2));
+            for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(asrc + q * APLANE + (RG * j) * (16 * KS * 2));
         };
-        auto blocks = [&](auto p_tag) {                      // row blocks j = 2 P, 2 P + 1 of this wave, each only if it holds a neighbour
-            constexpr int J0 = 2 * decltype(p_tag)::value, J1 = J0 + 1;
-            const unsigned sel = ((c_bm >> (2 * J0 + rg)) & 1u) | (((c_bm >> (2 * J1 + rg)) & 1u) << 1);
-            if (sel == 3u) {
-                bf16x8 a0[3], a1[3];
-                read_block(J0, a0);
-                read_block(J1, a1);
-                LIDIFF_S3_PRODUCT(J0, a0, 2, 0); LIDIFF_S3_PRODUCT(J1, a1, 2, 0);
-                LIDIFF_S3_PRODUCT(J0, a0, 0, 2); LIDIFF_S3_PRODUCT(J1, a1, 0, 2);
-                LIDIFF_S3_PRODUCT(J0, a0, 1, 1); LIDIFF_S3_PRODUCT(J1, a1, 1, 1);
-                LIDIFF_S3_PRODUCT(J0, a0, 1, 0); LIDIFF_S3_PRODUCT(J1, a1, 1, 0);
-                LIDIFF_S3_PRODUCT(J0, a0, 0, 1); LIDIFF_S3_PRODUCT(J1, a1, 0, 1);
-                LIDIFF_S3_PRODUCT(J0, a0, 0, 0); LIDIFF_S3_PRODUCT(J1, a1, 0, 0);
-            } else if (sel == 1u) {
-                bf16x8 a0[3];
-                read_block(J0, a0);
-                LIDIFF_S3_PRODUCT(J0, a0, 2, 0); LIDIFF_S3_PRODUCT(J0, a0, 0, 2); LIDIFF_S3_PRODUCT(J0, a0, 1, 1);
-                LIDIFF_S3_PRODUCT(J0, a0, 1, 0); LIDIFF_S3_PRODUCT(J0, a0, 0, 1); LIDIFF_S3_PRODUCT(J0, a0, 0, 0);
-            } else if (sel == 2u) {
-                bf16x8 a1[3];
-                read_block(J1, a1);
-                LIDIFF_S3_PRODUCT(J1, a1, 2, 0); LIDIFF_S3_PRODUCT(J1, a1, 0, 2); LIDIFF_S3_PRODUCT(J1, a1, 1, 1);
-                LIDIFF_S3_PRODUCT(J1, a1, 1, 0); LIDIFF_S3_PRODUCT(J1, a1, 0, 1); LIDIFF_S3_PRODUCT(J1, a1, 0, 0);
+        bf16x8 fa[2][3];
+        auto block = [&](auto j_tag) {
+            constexpr int J = decltype(j_tag)::value;
+            if constexpr (J + 1 < RBW) read_block(J + 1, fa[(J + 1) & 1]);
+            if (((c_bm >> (RG * J + rg)) & 1u) && !(abl & 2)) {
+                LIDIFF_S3_PRODUCT(J, fa[J & 1], 2, 0); LIDIFF_S3_PRODUCT(J, fa[J & 1], 0, 2); LIDIFF_S3_PRODUCT(J, fa[J & 1], 1, 1);
+                LIDIFF_S3_PRODUCT(J, fa[J & 1], 1, 0); LIDIFF_S3_PRODUCT(J, fa[J & 1], 0, 1); LIDIFF_S3_PRODUCT(J, fa[J & 1], 0, 0);
             }
         };
-        blocks(ic<0>{});
-        blocks(ic<1>{});
-        if (more && rg == 1) { issue_a(); issue_w(); }
-        blocks(ic<2>{});
-        blocks(ic<3>{});
+        S3_T(tq_w);
+        read_block(0, fa[0]);
+        block(ic<0>{});
+        block(ic<1>{});
+        if constexpr (RBW >= 8) { block(ic<2>{}); block(ic<3>{}); }
+        S3_T(tq_mma);
+        if (more && wave >= NW / 2 && !(abl & 1)) { issue_a(); issue_w(); }
+        S3_T(tq_dma);
+        if constexpr (RBW >= 8) { block(ic<4>{}); block(ic<5>{}); block(ic<6>{}); block(ic<7>{}); }
+        else { block(ic<2>{}); block(ic<3>{}); }
+        S3_T(tq_mma);
 #undef LIDIFF_S3_PRODUCT
         if (++c_slab == nslab) {                             // the offset is complete: its sums join the others'
             c_slab = 0;
@@ -345,10 +354,18 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
                     acc_k[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
         }
+        S3_T(tq_fold);
     }
 #undef LIDIFF_S3_BARRIER
+#ifdef LIDIFF_CONV_PROBE
+    if (p.timeline != nullptr && lane == 0 && (wave == 0 || wave == NW / 2)) {
+        long long* d = p.timeline + ((int64_t)bid * 2 + (wave != 0)) * 10;
+        d[0] = __builtin_readcyclecounter() - tq_start; d[1] = tq_bar; d[2] = tq_head; d[3] = tq_dma; d[4] = tq_w; d[5] = tq_mma;
+        d[6] = tq_fold; d[7] = nst; d[8] = tq_start - __builtin_readcyclecounter(); d[9] = 1;
+    }
+#endif
 
-    // ---- epilogue straight from the registers: lane (li, lq) holds channels n0 + 16 (CBW cg + c) + 4 lq .. + 3 of tile row 16 (2 j + rg) + li
+    // ---- epilogue straight from the registers: lane (li, lq) holds channels n0 + 16 (CBW cg + c) + 4 lq .. + 3 of tile row 16 (RG j + rg) + li
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
         const int col = n0 + 16 * (CBW * cg + c) + 4 * lq;
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + col);
 #pragma unroll
         for (int j = 0; j < RBW; ++j) {
-            const int r = 16 * (2 * j + rg) + li;
+            const int r = 16 * (RG * j + rg) + li;
             if (r >= rows_here) continue;
             const int64_t orow = p.row_order ? (int64_t)p.row_order[row0 + r] : row0 + r;     // tile row -> output row
             const int64_t o = orow * p.c_out + col;
@@ -412,6 +429,11 @@ static int launch_split3(const ConvParams& p, hipStream_t st) {
 
 using namespace lidiff;
 
+#ifdef LIDIFF_CONV_PROBE
+static long long* g_s3_timeline = nullptr;
+extern "C" void lidiff_debug_set_split3_timeline(long long* buf) { g_s3_timeline = buf; }
+#endif
+
 extern "C" int lidiff_split3_rows(const float* src, int64_t m, int32_t c, void* dst, void* stream) {
     LIDIFF_CHECK_ARG(m >= 0 && c > 0 && c % 8 == 0, "rows >= 0, channels a multiple of 8");
     if (m == 0) return 0;
@@ -432,7 +454,7 @@ extern "C" int lidiff_row_mask_keys(const int32_t* nbr, int32_t k_vol, int64_t m
 }
 
 extern "C" int32_t lidiff_spconv_fwd_split3_supported(int32_t c_in_a, int32_t c_in_b, int32_t c_out) {
-    return c_in_a > 0 && c_in_a % 32 == 0 && c_in_b >= 0 && c_in_b % 32 == 0 && c_out > 0 && c_out % 128 == 0;
+    return c_in_a > 0 && c_in_a % 32 == 0 && c_in_b >= 0 && c_in_b % 32 == 0 && c_out > 0 && c_out % 64 == 0;
 }
 
 extern "C" int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const void* in_b3, int32_t c_in_b, const void* w_packed3,
@@ -441,7 +463,7 @@ extern "C" int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const
                                         int32_t relu, int32_t replicas, const int32_t* d_m_out, const int32_t* row_order, void* stream) {
     LIDIFF_CHECK_ARG(in_a3 != nullptr && w_packed3 != nullptr && out != nullptr, "null pointer");
     LIDIFF_CHECK_ARG((in_b3 == nullptr) == (c_in_b == 0), "in_b3 and c_in_b must agree");
-    LIDIFF_CHECK_ARG(lidiff_spconv_fwd_split3_supported(c_in_a, c_in_b, c_out), "widths: inputs multiples of 32, c_out a multiple of 128");
+    LIDIFF_CHECK_ARG(lidiff_spconv_fwd_split3_supported(c_in_a, c_in_b, c_out), "widths: inputs multiples of 32, c_out a multiple of 64");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
     LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
     LIDIFF_CHECK_ARG(replicas >= 1 && m_out >= 0 && m_in >= 0, "bad shape");
@@ -462,5 +484,9 @@ extern "C" int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const
     p.m_in = m_in; p.m_out = m_out; p.d_m_out = d_m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
     p.k_vol = k_vol; p.relu = relu; p.replicas = replicas;
-    return launch_split3<128>(p, (hipStream_t)stream);
+#ifdef LIDIFF_CONV_PROBE
+    p.timeline = g_s3_timeline;
+#endif
+    { static const int abl = [] { const char* e = getenv("LIDIFF_S3_ABLATE"); return e ? atoi(e) : 0; }(); p.flags = abl; }
+    return c_out % 128 == 0 ? launch_split3<128>(p, (hipStream_t)stream) : launch_split3<64>(p, (hipStream_t)stream);
 }

@@ -155,7 +155,7 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
             hints["tail_hint"] = mgr.tail_rows(ts_out)
         f = ops.spconv_centre_tail(x.F, conv.kernel, mgr.tail_map(ts_out), m_out, in_b=extra, scale=scale, shift=shift,
                                    residual=residual, relu=relu, replicas=x.replicas, **hints)
-    elif (not hint and conv.kernel_size == 3 and not conv.transposed and order is None and nbr is not None
+    elif (conv.kernel_size == 3 and not conv.transposed and order is None and nbr is not None
           and ops.split3_layer(x.tensor_stride, rows_out, x.replicas, x.F.shape[1], 0 if extra is None else extra.shape[1],
                                conv.out_channels)):
         # the dense levels: the contraction on the bf16 matrix pipe from three-way split operands (fp32 accuracy, ops.SPLIT3), the

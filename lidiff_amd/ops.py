@@ -1309,7 +1309,7 @@ def split3_layer(tensor_stride: int, rows: int, replicas: int, c_in_a: int, c_in
     """Does the fused plan run a kernel_size-3 convolution of this shape on the split-operand kernel?  (rows: what the host
     believes -- exact, or the same level of the role's previous pyramid)"""
     return (SPLIT3 and tensor_stride >= SPLIT3_MIN_STRIDE and split3_conv_applies(c_in_a, c_in_b, c_out)
-            and -(-rows * replicas // 256) * (c_out // 128) >= SPLIT3_MIN_TILES)
+            and -(-rows * replicas // 256) * (c_out // (128 if c_out % 128 == 0 else 64)) >= SPLIT3_MIN_TILES)
 
 
 class split3:

@@ -751,7 +751,8 @@ def test_spconv_256_row_tiles_vs_128_row_tiles_and_oracle(device, cin, split, co
         assert torch.allclose(got[:m][rows].cpu().double(), want, rtol=RTOL, atol=ATOL)
 
 
-@pytest.mark.parametrize("cin,split,cout", [(128, 0, 128), (256, 0, 256), (384, 256, 256), (128, 0, 256), (192, 128, 128), (64, 0, 128)])
+@pytest.mark.parametrize("cin,split,cout", [(128, 0, 128), (256, 0, 256), (384, 256, 256), (128, 0, 256), (192, 128, 128), (64, 0, 128),
+                                            (64, 0, 64), (32, 0, 64), (96, 64, 192)])
 def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout):
     """lidiff_spconv_fwd_split3 (round 6): fp32 in / fp32 out with the contraction on the bf16 matrix pipe from three-way split
     operands -- against the float64 oracle at the NATIVE fp32 kernel's own bars (RTOL / ATOL of this file), and its worst error

@@ -1,8 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-FAST="--no-cpu-baseline --no-coords-roofline --no-train --no-alt --no-closed-loop --no-kernel-events"
-rm -rf $R/gpurun_out/prof_r06
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r06 -o x -- python $R/bench.py --steps 20 --warmup 5 $FAST > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/bench_under_rocprof.err
-cd $R; python tools/rocpd_stats.py gpurun_out/prof_r06/x_results.db --top 45 > gpurun_out/r06_kernel_stats.md
-python tools/rocpd_main_queue.py gpurun_out/prof_r06/x_results.db > gpurun_out/r06_main_queue.txt 2>&1
-rm -rf gpurun_out/prof_r06
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_kernels.py -k "split3" -x -q 2>&1 | tail -3
+timeout 600 python tools/conv_probe.py --replicas 2 --kernel split3 --cases "3,256,256,k3,0,1;4,256,256,k3,0,1;3,128,128,k3,0,1;2,128,128,k3,0,1;3,384,256,k3,0,1" 2>&1 | grep avg_us
+for a in 2 3; do echo "ablate=$a: $(LIDIFF_S3_ABLATE=$a timeout 600 python tools/conv_probe.py --replicas 2 --kernel split3 --cases '3,256,256,k3,0,1' 2>&1 | grep avg_us | sed 's/.*avg_us/avg_us/')"; done

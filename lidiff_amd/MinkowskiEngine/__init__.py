@@ -44,7 +44,7 @@ class MinkowskiAlgorithm(enum.Enum):
 # ----------------------------------------------------------------------------------------
 # coordinate manager
 # ----------------------------------------------------------------------------------------
-_SPLIT_PYRAMID = __import__("os").environ.get("LIDIFF_SPLIT_PYRAMID", "1") != "0"
+_SPLIT_PYRAMID = True
 # a host-read-free pyramid queued in three lanes ordered by who waits for what (ops.build_pyramid_lanes); 0: one chain
 _PYRAMID_LANES = __import__("os").environ.get("LIDIFF_PYRAMID_LANES", "1") != "0"
 

@@ -1875,9 +1875,9 @@ static bool fps_coop_plan(int64_t n_points, int* grid_out, int* pt_out) {
         return false;
     // as FEW workgroups as the registers allow (kFpsCoopPt points per thread): a selection costs one device-wide barrier, and a
     // barrier among 15 workgroups (119 035 points) is far cheaper than one among 256 -- the arithmetic per selection is ~100 cycles
-    // per thread either way (round 4; LIDIFF_FPS_GRID_ALL=1 in the environment: one workgroup per compute unit, the round-3 plan)
+    // per thread either way (round 4; all_cus: one workgroup per compute unit, the round-3 plan)
     const int64_t blocks = ceil_div(n_points, kFpsBlock);
-    static const bool all_cus = getenv("LIDIFF_FPS_GRID_ALL") != nullptr;
+    constexpr bool all_cus = false;
     const int64_t fewest = ceil_div(n_points, (int64_t)kFpsBlock * kFpsCoopPt);
     const int grid = (int)(all_cus ? (blocks < cus ? blocks : cus) : (fewest < cus ? fewest : cus));
     const int64_t pt = ceil_div(n_points, (int64_t)grid * kFpsBlock);

@@ -1039,12 +1039,12 @@ int64_t dw_pairs_per_slot(int64_t n_pairs, int64_t slices, int k_vol) {
 
 int64_t dw_slices(int c_in, int c_out, int k_vol, int64_t n_pairs, int cit, int cot) {
     const int tiles = (int)(ceil_div(c_in, cit) * ceil_div(c_out, cot));
-    // workgroups per launch (LIDIFF_DW_TARGET).  With EQUAL slices per offset, whose pair counts differ widely (the centre offset
+    // workgroups per launch.  With EQUAL slices per offset, whose pair counts differ widely (the centre offset
     // holds every row), many short slices balanced best: 2 048 (bf16 step 1 024: 104.7 ms, 2 048: 102.0, 4 096: 103.4, 8 192: 107.1).
     // With slots handed out in proportion to the pair counts (dw_pairs_per_slot) every workgroup has the same work, and fewer, longer
     // slots win -- less partial-tile traffic through the workspace: 2 048: 84.1 ms, 1 024: 80.7, 768: 80.2, 512: 79.8, 384: 80.4
     // (fp32: 164 / 160 / - / 162) -- but at least 4 chunks each
-    static const int64_t target = [] { const char* e = getenv("LIDIFF_DW_TARGET"); return e ? (int64_t)atoi(e) : (int64_t)768; }();
+    constexpr int64_t target = 768;
     int64_t slices = ceil_div(target, (int64_t)tiles * k_vol);
     const int64_t max_slices = max((int64_t)1, n_pairs / k_vol / (4 * kDwPairs));
     return max((int64_t)1, min(slices, max_slices));

@@ -409,13 +409,9 @@ static int launch_bf16(const ConvParams& p, hipStream_t st) {
 
 template <int P>
 static int dispatch_bf16(const ConvParams& p, bool ks64, hipStream_t st) {
-    static const int tile_rows = [] { const char* e = getenv("LIDIFF_BF16_TILE"); return e ? atoi(e) : 128; }();
-    static const int tile_ks = [] { const char* e = getenv("LIDIFF_BF16_KS"); return e ? atoi(e) : 64; }();
     // three planes: 32-channel stages only (the W registers of a 64-channel stage would not fit beside the accumulators)
 #define LIDIFF_BF16(BM, WC, WR) \
     return ks64 && P < 3 ? launch_bf16<BM, WC, WR, (P < 3 ? 64 : 32), P>(p, st) : launch_bf16<BM, WC, WR, 32, P>(p, st)
-    if (P == 1 && tile_rows == 64 && p.c_out % 128 == 0)
-        return ks64 && tile_ks == 64 ? launch_bf16<64, 4, 2, 64, 1>(p, st) : launch_bf16<64, 4, 2, 32, 1>(p, st);
     if (p.c_out % 128 == 0) LIDIFF_BF16(128, 4, 2);
     if (p.c_out % 96 == 0) LIDIFF_BF16(128, 3, 2);
     if (p.c_out % 64 == 0) LIDIFF_BF16(128, 2, 4);
@@ -893,12 +889,9 @@ static int dispatch_bf16_rows(const ConvParams& p, bool ks64, int mode, hipStrea
     // 64 -> 64 183 -> 184, 96 -> 96 at stride 2 302 -> 247: both kernels move the same 6.3 GB per 256 -> 256 launch between L2 and
     // the CUs (8.4 TB/s: half of it W fragments, re-read by every tile), which is what bounds them once the latency is hidden --
     // the ring wins where stages are nearly empty (few pairs per offset, 32-channel slabs anyway): the 96-column tiles take it
-    // (LIDIFF_BF16_RING = 1: every tile width, 0: none)
-    static const int ring_default = [] { const char* e = getenv("LIDIFF_BF16_RING"); return e ? atoi(e) : -1; }();
-    const bool ring = mode == 2 || (mode == 1 && (ring_default > 0 || (ring_default < 0 && p.c_out % 128 != 0 && p.c_out % 96 == 0)));
+    const bool ring = mode == 2 || (mode == 1 && p.c_out % 128 != 0 && p.c_out % 96 == 0);
     // (in_bf16: 1 = this rule, 2 = ring, 3 = two stages, 4 = wide register tiles where the width allows)
-    static const int wide_default = [] { const char* e = getenv("LIDIFF_BF16_WIDE"); return e ? atoi(e) : 0; }();
-    if (mode == 4 || (mode == 1 && wide_default)) {
+    if (mode == 4) {
         if (p.c_out % 256 == 0) return launch_bf16_wide<256>(p, st);
         if (p.c_out % 128 == 0) return launch_bf16_wide<128>(p, st);
         if (p.c_out % 96 == 0) return launch_bf16_wide<96, 4>(p, st);

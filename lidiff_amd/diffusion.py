@@ -93,8 +93,8 @@ class DiffusionPoints(nn.Module):
 
     # The part -> full matches of the five levels (minkunet.py:403-416: exhaustive arg-min, 0.8 ms each at B = 2 x 180 000 points)
     # need only coordinates: queued on a side stream as soon as both pyramids exist, they run under the condition encoder;
-    # MinkUNetDiff.match_index makes the consuming stream wait for its level's event.  LIDIFF_MATCHES_AHEAD=0: inline.
-    matches_ahead = os.environ.get("LIDIFF_MATCHES_AHEAD", "1") != "0"
+    # MinkUNetDiff.match_index makes the consuming stream wait for its level's event.  (matches_ahead = False: inline.)
+    matches_ahead = True
 
     def _matches_ahead(self, x_full, x_part):
         if not self.matches_ahead or x_full.F.device.type != "cuda" or x_part.coordinate_manager.maps[1].coords.shape[0] <= 1:

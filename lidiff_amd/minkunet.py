@@ -92,7 +92,7 @@ _CENTRE_TAIL = True
 
 # transposed (kernel_size 2 / stride 2) convolutions with their output rows grouped by kernel offset (CoordinateManager.up_order):
 # 128 pairs of ONE offset per tile instead of ~16 of each of the eight
-_UP_ORDERED = os.environ.get("LIDIFF_UP_ORDERED", "1") != "0"
+_UP_ORDERED = True
 
 
 _ME_BN = (ME.MinkowskiBatchNorm, ME.MinkowskiSyncBatchNorm)     # exact types whose .bn batch_norm_train() may stand in for
@@ -273,9 +273,9 @@ def _run_up(up, x, skip):
 
 
 # training path: the conditioning MLPs' row-wise Linears in front of the gather (see MinkUNetDiff._condition)
-_COMMUTE_TRAIN = os.environ.get("LIDIFF_COMMUTE_TRAIN", "1") != "0"
+_COMMUTE_TRAIN = True
 # ... and the rest of the conditioning MLP on the (part row, batch) pair table (see MinkUNetDiff._condition)
-_PAIR_TABLE_TRAIN = os.environ.get("LIDIFF_PAIR_TABLE_TRAIN", "1") != "0"
+_PAIR_TABLE_TRAIN = True
 
 
 def _run_mlp(mlp, x):

@@ -128,7 +128,7 @@ def _trace(label):
         PYRAMID_TRACE.append((label, time.perf_counter(), ev))
 
 
-PINNED_READ = os.environ.get("LIDIFF_PINNED_READ", "1") != "0"
+PINNED_READ = True
 _PINNED: dict = {}
 
 
@@ -163,7 +163,7 @@ class SizeFeed:
         import ctypes
         dptr = ctypes.c_void_p()
         rc = _lib.load().lidiff_host_device_pointer(ctypes.c_void_p(self.ring.data_ptr()), ctypes.byref(dptr))
-        self.dev_base = dptr.value if rc == 0 and dptr.value and os.environ.get("LIDIFF_FEED_COPY", "0") != "1" else None
+        self.dev_base = dptr.value if rc == 0 and dptr.value else None
         self.seq = 0                 # records announced so far
         self.seq_base = 0            # records before this one belong to an earlier scan (reset())
         self.done = {}               # seq -> (status, [sizes]) read back or pushed
@@ -387,7 +387,7 @@ def build_pyramid(coords: torch.Tensor, status: torch.Tensor, strides: int = 4, 
         _trace("done")
         return out
     # THE host read of this pyramid: into a pinned buffer, the host spinning on an event query (torch's tolist() goes through a
-    # pageable staging copy and a blocking synchronise: ~0.1 ms later at the next launch; LIDIFF_PINNED_READ=0 keeps that form)
+    # pageable staging copy and a blocking synchronise: ~0.1 ms later at the next launch; PINNED_READ = False keeps that form)
     if PINNED_READ:
         import threading
         key = (counts.numel(), str(dev), threading.get_ident())       # (one staging buffer per size, device AND thread: ADVICE r4)
@@ -806,7 +806,7 @@ PROFILER: ConvProfiler | None = None
 # weight gradients: pair slices summed in slice order through a workspace (bit-reproducible); False = fp32 atomics
 DETERMINISTIC_DW = True
 # extra lidiff_spconv_fwd flag bits (include/lidiff_amd.h LIDIFF_CONV_*), e.g. 8 = LIDIFF_CONV_TILE_ONLY
-CONV_FLAGS = int(os.environ.get("LIDIFF_CONV_FLAGS", "0"))
+CONV_FLAGS = 0
 
 
 def conv_variant(c_out: int, kernel_id: int = 0) -> str:
@@ -943,7 +943,7 @@ def spconv_fwd(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | None, m_
 
 
 # training-mode BatchNorm through the HIP kernels of norm.hip (False: torch's batch_norm kernels)
-FUSED_BN_TRAIN = os.environ.get("LIDIFF_FUSED_BN", "1") != "0"
+FUSED_BN_TRAIN = True
 
 
 def bn_train_applies(x: torch.Tensor) -> bool:
@@ -1183,7 +1183,7 @@ class train_operands:
 # the faster one (profiles/r02_bf16_conv_sweep.txt) and those layers kept it.  Round 5: with bf16 shadow rows, W fragments through
 # LDS and the 16-byte flush the bf16 kernel wins there too in aggregate (training step 120.3 -> 117.9 ms), so EVERY eligible layer
 # runs in bf16 -- which is also what the oracle's emulation of the bf16 step assumes ("0": the former rule).
-BF16_SPARSE_MAPS = os.environ.get("LIDIFF_BF16_SPARSE_MAPS", "1") == "1"
+BF16_SPARSE_MAPS = True
 
 
 def bf16_conv_applies(c_a: int, c_b: int, c_out: int, sparse_map: bool = False) -> bool:
@@ -1217,7 +1217,7 @@ def packed_weights_bf16(w: torch.Tensor, transposed: bool = False, flip: bool = 
 
 # bf16 training: the convolutions gather bf16 SHADOW rows of their inputs (cast once per tensor, used by the forward, the input
 # gradient and the weight gradient) instead of rounding the fp32 rows inside every kernel (False: as rounds 2-4)
-BF16_ROWS = os.environ.get("LIDIFF_BF16_ROWS", "1") != "0"
+BF16_ROWS = True
 
 
 BF16_ROWS_KERNEL = {None: 1, "ring": 2, "two_stage": 3, "wide": 4}
@@ -1225,7 +1225,7 @@ BF16_ROWS_KERNEL = {None: 1, "ring": 2, "two_stage": 3, "wide": 4}
 # per output over all offsets and channels: 256 -> 256 at stride 8 738 -> 378 us, 96 -> 96 at stride 2 201 -> 102, 32 -> 64 120 ->
 # 45); the stride-2 maps (8 offsets, 1-2.6 pairs per row: 22 vs 28 us, 55 vs 64) keep the pair-list kernels.  False: the two-stage /
 # ring kernels everywhere, whose sums -- per offset first -- are bit-identical to the fp32-row form
-BF16_WIDE = os.environ.get("LIDIFF_BF16_WIDE", "1") != "0"
+BF16_WIDE = True
 
 
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
@@ -1622,7 +1622,7 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, m: int) -> torch.Tens
     return torch.zeros((m, c), dtype=torch.float32, device=src.device)
 
 
-FPS_COOPERATIVE = os.environ.get("LIDIFF_FPS_COOPERATIVE", "1") != "0"
+FPS_COOPERATIVE = True
 
 
 def _inv_resolution(resolution: float) -> float:
@@ -1702,7 +1702,7 @@ def farthest_point_sample(points: torch.Tensor, n_samples: int) -> torch.Tensor:
 
 
 # nn_dist goes through the uniform grid (lidiff_nn_dist_grid: same results, bit for bit) from this many point pairs on
-NN_GRID_MIN_PAIRS = int(float(os.environ.get("LIDIFF_NN_GRID_MIN_PAIRS", "2e8")))
+NN_GRID_MIN_PAIRS = int(2e8)
 NN_GRID_CELL = 0.5          # metres (LiDiff's clouds): ~25 surface points per cell at the scans' density; results do not depend on it
 
 

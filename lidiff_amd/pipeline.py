@@ -74,8 +74,8 @@ class DiffCompletion(nn.Module):
     # The boundary between two steps -- guidance, DPM-Solver++ update, the next field's points and voxel coordinates -- as ONE
     # launch (ops.cfg_dpm_step / step.hip) instead of ~25 elementwise torch launches, and points_to_tensor as one launch
     # (ops.points_to_field) instead of six; same values bit for bit (test_fused_step_boundary_equals_the_torch_sequence).
-    # LIDIFF_FUSED_STEP=0: the torch sequence.
-    fused_step = os.environ.get("LIDIFF_FUSED_STEP", "1") != "0"
+    # fused_step = False: the torch sequence.
+    fused_step = True
 
     # -- a denoising step WITHOUT a host read ---------------------------------------------
     # Every step rebuilds three coordinate pyramids, and the sizes of their maps used to come back to the host (one blocking read
@@ -173,13 +173,13 @@ class DiffCompletion(nn.Module):
     # x_t's maps built ON DEMAND on the side streams while the network's first layers already run (round 3): with the condition
     # encoders issued one step ahead nothing else hides the chain behind x_t's points (voxelise -> 4 strided maps -> 13 kernel
     # maps -> tail maps -> up orders -> 5 matches: 2.2-3 ms with its map-size reads, profiles/r03_step_boundary_trace.txt),
-    # but the stem needs only the first ~0.4 ms of it.  LIDIFF_LAZY_XT=0: the whole pyramid first (round-2 behaviour).
-    lazy_x_t = os.environ.get("LIDIFF_LAZY_XT", "1") != "0"
+    # but the stem needs only the first ~0.4 ms of it.  lazy_x_t = False: the whole pyramid first (round-2 behaviour).
+    lazy_x_t = True
     # every field's pyramid (voxel map, four strided maps, the first two levels' kernel_size-3 maps and tail-map counts) queued
     # with the row counts staying on the device and ONE host read at its end (ops.build_pyramid) instead of seven
-    single_read = os.environ.get("LIDIFF_SINGLE_READ", "1") != "0"
-    overlap_maps = os.environ.get("LIDIFF_OVERLAP_MAPS", "1") not in ("0", "lazy")
-    eager_maps = os.environ.get("LIDIFF_OVERLAP_MAPS", "1") != "lazy"      # False: maps are built when a layer first asks
+    single_read = True
+    overlap_maps = True
+    eager_maps = True              # False: maps are built when a layer first asks
 
     # (Round 4 measured the main path on a HIGH-priority stream, so that the side streams' kernels would only fill the chip's idle
     # corners instead of taking compute units from the convolutions: 37.86 vs 38.01 ms per step with per-launch events, 37.84 vs
@@ -259,8 +259,8 @@ class DiffCompletion(nn.Module):
 
     # x_t's part -> full matches queued INSIDE its pyramid chain, reading the row counts from the device (lidiff_nn_match_dev):
     # they run while the host is still blocked in the pyramid's size read, and the host goes from that read straight to the first
-    # convolutions instead of first queuing five searches (profiles/r04_step_boundary.txt).  LIDIFF_MATCH_IN_CHAIN=0: behind the read.
-    match_in_chain = os.environ.get("LIDIFF_MATCH_IN_CHAIN", "1") != "0"
+    # convolutions instead of first queuing five searches (profiles/r04_step_boundary.txt).  match_in_chain = False: behind the read.
+    match_in_chain = True
 
     def _match_level_dev(self, parts, ts, rows_bound, d_count):
         from . import ops
@@ -293,8 +293,8 @@ class DiffCompletion(nn.Module):
     # The encoders of the NEXT step's conditions and (with next_t) its conditioning tables, queued on the side stream under this
     # step's UNet as well (round 3).  Nothing is cached: every step still rebuilds its conditions from the points and encodes them
     # (pipeline:86-90,140-146) -- the work is only issued one step ahead, where ~150 launches that cannot fill the chip (3.2 ms on
-    # the main stream, profiles/r03_step_timeline.txt) run beside convolutions that can.  Off: LIDIFF_ENCODE_AHEAD=0.
-    encode_ahead = os.environ.get("LIDIFF_ENCODE_AHEAD", "1") != "0"
+    # the main stream, profiles/r03_step_timeline.txt) run beside convolutions that can.  Off: encode_ahead = False.
+    encode_ahead = True
 
     # pipeline:86-90
     def reset_partial_pcd(self, x_part, x_uncond, next_t=None):

@@ -131,6 +131,15 @@ def _layer_case(device, scene, level, kind, cin, cout, split, replicas=1):
     # rounding (~1e-6 relative) is far inside the tolerance
     pairs = m_out if nbr_np is None else int((nbr_np >= 0).sum())
     odt = torch.float64 if float(pairs) * cin * cout < 5e10 else torch.float32
+    # the layers the fused plan runs on the split-operand kernel (ops.split3_layer: kernel_size 3, stride >= 4, widths it takes)
+    # ALSO through that kernel, rows sorted by neighbour sets as the plan does -- same oracle, same bar as the native kernel
+    got3 = None
+    if kind == "k3" and (1 << level) >= ops.SPLIT3_MIN_STRIDE and ops.split3_conv_applies(split or cin, cin - split if split else 0, cout):
+        nbr_s, order = ops.mask_sorted_map(nbr)
+        got3 = ops.spconv_fwd_split3(xd[:, :split].contiguous() if split else xd, w.to(device), nbr_s, m_out,
+                                     in_b=xd[:, split:].contiguous() if split else None, scale=scale.to(device),
+                                     shift=shift.to(device), residual=res.to(device), relu=True, replicas=replicas,
+                                     row_order=order).cpu().double()
     for r in range(replicas):
         want = me.conv_forward(x[r * m_in:(r + 1) * m_in].to(odt), (w if k > 1 else w[0]).to(odt), nbr_np).double()
         want = torch.relu(want * scale.double() + shift.double() + res[r * m_out:(r + 1) * m_out].double())
@@ -141,6 +150,13 @@ def _layer_case(device, scene, level, kind, cin, cout, split, replicas=1):
                       replica=r, max_abs_err=err, max_abs_out=want.abs().max().item(), worst_tolerance_fraction=frac)
         assert torch.allclose(got[r * m_out:(r + 1) * m_out], want, rtol=LAYER_TOL, atol=LAYER_TOL), \
             f"level {level} {kind} {cin}->{cout} hint={hint} replica {r}: max err {err}"
+        if got3 is not None:
+            d3 = (got3[r * m_out:(r + 1) * m_out] - want).abs()
+            record_parity("conv_layer_on_bench_maps_split3", sigma=scene.sigma, level=level, kind=kind, c_in=cin, c_out=cout,
+                          replica=r, max_abs_err=d3.max().item(), max_abs_err_native=err, max_abs_out=want.abs().max().item(),
+                          worst_tolerance_fraction=(d3 / (LAYER_TOL + LAYER_TOL * want.abs())).max().item())
+            assert torch.allclose(got3[r * m_out:(r + 1) * m_out], want, rtol=LAYER_TOL, atol=LAYER_TOL), \
+                f"split3 level {level} {cin}->{cout} replica {r}: max err {d3.max().item()} (native {err})"
     return hint
 
 

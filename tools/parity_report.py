@@ -21,6 +21,15 @@ def main(path):
             for r in sorted(rs, key=lambda r: (r["sigma"], r["level"], r["kind"], r["c_in"], r["c_out"], r["replica"])):
                 print(f"  sigma {r['sigma']:<4} level {int(r['level'])} {r['kind']:<4} {int(r['c_in']):>3}->{int(r['c_out']):<3} hint {int(r['hint'])} "
                       f"replica {int(r['replica'])}: max|err| {r['max_abs_err']:.2e}  max|out| {r['max_abs_out']:.2f}")
+        elif name == "conv_layer_on_bench_maps_split3":
+            print(f"\n## {name}: the layers the fused plan runs on the split-operand kernel (rows sorted by neighbour sets), same inputs, same "
+                  f"float64 oracle, same bar as the native fp32 kernel: max|err| split3 / native")
+            print(f"worst split3 max|err| {max(r['max_abs_err'] for r in rs):.3e} (native on the same cases {max(r['max_abs_err_native'] for r in rs):.3e}); "
+                  f"worst ratio split3 / native {max(r['max_abs_err'] / max(r['max_abs_err_native'], 1e-12) for r in rs):.2f}; "
+                  f"worst fraction of the bar {max(r['worst_tolerance_fraction'] for r in rs):.3f}")
+            for r in sorted(rs, key=lambda r: (r["sigma"], r["level"], r["c_in"], r["c_out"], r["replica"])):
+                print(f"  sigma {r['sigma']:<4} level {int(r['level'])} {int(r['c_in']):>3}->{int(r['c_out']):<3} replica {int(r['replica'])}: "
+                      f"split3 {r['max_abs_err']:.2e}  native {r['max_abs_err_native']:.2e}  max|out| {r['max_abs_out']:.2f}")
         elif name == "bf16_block":
             print(f"\n## {name}: bf16 training blocks, device vs oracle emulation (float64 sums) from identical inputs")
             for r in rs:

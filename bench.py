@@ -168,7 +168,8 @@ def emit(line: str):
 
 
 VARIANT_KERNELS = {"bn128": ("<128, 8, 1",), "bn96": ("<128, 6, 1", "<128, 3, 2"), "bn64": ("<128, 4, 2",),
-                   "bn32": ("<128, 2, 4",), "bn16": ("<128, 1, 8",), "rows": ("spconv_rows_kernel",), "thin": ("spconv_thin_kernel",)}
+                   "bn32": ("<128, 2, 4",), "bn16": ("<128, 1, 8",), "rows": ("spconv_rows_kernel",), "thin": ("spconv_thin_kernel",),
+                   "split3": ("spconv_fwd_split3_kernel",)}
 COORD_KERNELS = ("insert_kernel", "flag_count_kernel", "scan_write_kernel", "inverse_kernel", "mean_", "kernel_map_",
                  "floor_kernel")
 
@@ -206,7 +207,8 @@ def traffic_from_profile(variants, per="launch"):
         want = VARIANT_KERNELS.get(variants[0], ("?",))[0]
         return (js["traffic_bytes_per_launch"] / 1e9, src) if want in js.get("kernel", "") else (None, None)
     keys = [p for v in variants for p in VARIANT_KERNELS.get(v, ())]
-    rows = [v for k, v in js["kernels"].items() if ("spconv_fwd_kernel" in k or "spconv_rows_kernel" in k or "spconv_thin_kernel" in k) and any(p in k for p in keys)]
+    rows = [v for k, v in js["kernels"].items() if ("spconv_fwd_kernel" in k or "spconv_rows_kernel" in k or "spconv_thin_kernel" in k or "spconv_fwd_split3_kernel" in k)
+            and any(p in k for p in keys)]
     if not rows:
         return None, None
     total = sum(r["traffic_bytes_total"] for r in rows)

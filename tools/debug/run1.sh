@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python tools/split3_table.py 2>&1 | grep -v amdgpu | tee gpurun_out/r06_split3.txt
-timeout 900 python -m pytest tests/test_gpu_baseline.py -x -q -k "network_conv or cfg_pair" 2>&1 | tail -3
-python tools/parity_report.py gpurun_out/parity_errors.jsonl > gpurun_out/r06_parity_errors_layers.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+bash tools/pmc_mfma.sh > gpurun_out/pmc_mfma.log 2>&1; tail -25 gpurun_out/pmc_mfma/summary.txt
+PMC_STEPS=20 PMC_WARMUP=5 bash tools/pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1; head -8 gpurun_out/pmc_bench.log

@@ -38,7 +38,7 @@ for k, (kb, n) in res.get("FETCH_SIZE", {}).items():
                   "write_bytes_per_launch": 1024.0 * w[0] / max(1, w[1]),
                   "traffic_bytes_per_launch": 2048.0 * kb / n + 1024.0 * w[0] / max(1, w[1]),
                   "traffic_bytes_total": 2048.0 * kb + 1024.0 * w[0]}
-conv = {k: v for k, v in kernels.items() if "spconv_fwd_kernel" in k}
+conv = {k: v for k, v in kernels.items() if "spconv_fwd_kernel" in k or "spconv_fwd_split3_kernel" in k}
 dom = max(conv, key=lambda k: conv[k]["traffic_bytes_total"], default=None)
 js = {"command": f"python bench.py --steps $STEPS --warmup $WARM (all {int('$STEPS') + int('$WARM')} steps counted)",
       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "

@@ -210,7 +210,7 @@ class CoordinateManager:
             ups = tuple(lv for lv in range(1, levels + 1) if self.lane_up_orders and h[lv - 1] >= self.UP_ORDER_MIN_ROWS)
             with self.building():
                 sorted_lv = tuple(lv for lv in range(levels + 1)
-                                  if ops.SPLIT3_SORTED and ops.split3_layer(1 << lv, h[lv], 2, 128, 0, 128))
+                                  if ops.SPLIT3_SORTED and ops.SPLIT3_PRESORT and ops.split3_layer(1 << lv, h[lv], 2, 128, 0, 128))
                 pyr = ops.build_pyramid_lanes(coords_i32, self.status, self.feed, second, third, strides=levels, on_level_dev=hook,
                                               feats=feats, tail_levels=sparse, up_pairs_levels=ups, sorted_levels=sorted_lv)
             # every map of the networks exists now and is handed over through per-level events (_acquire): no blanket join
@@ -441,6 +441,9 @@ class CoordinateManager:
             out += [m.coords, m.table.keys, m.table.vals]
         out += list(self.parents.values())
         out += [t for t in self.kmaps.values() if isinstance(t, torch.Tensor)]
+        for t in self.kmaps.values():          # (the mask-sorted twin of a table and its row order hang on the table: ops.mask_sorted_map)
+            if isinstance(t, torch.Tensor) and getattr(t, "_lidiff_mask_sorted", None) is not None:
+                out += list(t._lidiff_mask_sorted)
         for v in self.aux.values():
             for t in (v if isinstance(v, (tuple, list)) else [v]):
                 if isinstance(t, torch.Tensor):

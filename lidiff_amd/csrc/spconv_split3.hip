@@ -89,6 +89,9 @@ __global__ void row_mask_keys_kernel(const int32_t* __restrict__ nbr, int k_vol,
     keys[r] = key;
 }
 
+#ifndef LIDIFF_S3_NRQ
+#define LIDIFF_S3_NRQ 4
+#endif
 #ifndef LIDIFF_S3_CBW
 #define LIDIFF_S3_CBW 2          // column blocks per wave on 128-column tiles (4 = 64 x 64 wave tiles: fewer LDS reads, measured +1.5 % SLOWER)
 #endif
@@ -103,8 +106,9 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     constexpr int WBLK = 3 * (BN / 16);                     // 1 KB W blocks per stage: [column block][piece]
     constexpr int WBYTES = WBLK * 1024;
     constexpr int STAGE = ABYTES + WBYTES;
-    constexpr int NCHK = 4, RPI = 16, T = (BM / RPI) / NW;  // row requests per wave, piece and stage (2)
-    static_assert((BM / RPI) % NW == 0 && RBW % 2 == 0 && CG * RG == NW && (BN == 128 || BN == 64), "request split");
+    constexpr int NRQ = LIDIFF_S3_NRQ;                      // waves that issue requests (8: all; 4: the first wave of every SIMD only)
+    constexpr int NCHK = 4, RPI = 16, T = (BM / RPI) / NRQ; // row requests per issuing wave, piece and stage
+    static_assert((BM / RPI) % NRQ == 0 && RBW % 2 == 0 && CG * RG == NW && (BN == 128 || BN == 64), "request split");
     ConvParams p = p_launch;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* act = reinterpret_cast<int32_t*>(smem + 2 * STAGE);          // offsets with a neighbour in the tile; act[31] = count
@@ -185,8 +189,9 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     const i32x4 rsrc_b = in_b ? rsrc(in_b, p.m_in * (int64_t)pitch_b) : rsrc_a;
     auto swz = [](int r) { return (r >> 2) & 2; };          // (ds_read_b128's lane groups: see spconv_fwd_bf16_kernel)
     int chb[T];
+    const int rqw = wave % NRQ;                              // (waves behind NRQ mirror one of the issuing waves' bookkeeping and issue nothing)
 #pragma unroll
-    for (int j = 0; j < T; ++j) chb[j] = 16 * ((lane % NCHK) ^ swz(RPI * (wave + NW * j) + lane / NCHK));
+    for (int j = 0; j < T; ++j) chb[j] = 16 * ((lane % NCHK) ^ swz(RPI * (rqw + NRQ * j) + lane / NCHK));
     const int foff = li * (KS * 2) + 16 * (lq ^ swz(li));
     const unsigned s_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
 
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     auto take_rows = [&](int oi) {
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            const int r = RPI * (wave + NW * j) + lane / NCHK;
+            const int r = RPI * (rqw + NRQ * j) + lane / NCHK;
             row_cur[j] = r >= rows_here ? -1 : p.nbr ? rowbuf[(oi & 1) * BM + r] : (int32_t)(row0 + r);
         }
     };
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     };
     auto issue_w = [&]() {
 #pragma unroll
-        for (int b = wave; b < WBLK; b += NW)
+        for (int b = rqw; b < WBLK; b += NRQ)
             s3_dma16(rsrc_w, s_base + n_slot * STAGE + ABYTES + b * 1024, (((n0 >> 4) * 3 + b) * 64 + lane) * 16, n_ws);
     };
     auto issue_a = [&]() {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         for (int q = 0; q < 3; ++q) soff[q] = n_cb + q * n_cw;
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            const int t = wave + NW * j;                     // a request = one 16-row block of one piece
+            const int t = rqw + NRQ * j;                     // a request = one 16-row block of one piece
             if (!((n_bm >> t) & 1u)) continue;               // (no neighbour in the block under this offset: not requested, not multiplied)
             const int voff = row_cur[j] >= 0 ? row_cur[j] * (3 * n_cw) + chb[j] : (int)0x80000000;    // no neighbour: zeros, no bytes moved
 #pragma unroll
@@ -273,9 +278,16 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         for (int c = 0; c < CBW; ++c) acc_k[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     request_rows(0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (nst > 0) { next_stage(0); issue_a(); issue_w(); }
+    if (nst > 0) {
+        next_stage(0);
+        if (wave < NRQ) { issue_a(); issue_w(); }
+    }
     int c_slab = 0;
-    const int abl = p.flags;                                 // measurement aid (LIDIFF_S3_ABLATE; results are wrong with any bit set)
+#ifdef LIDIFF_CONV_PROBE
+    const int abl = p.flags;                                 // probe build only (LIDIFF_S3_ABLATE; results are wrong with any bit set):
+#else                                                        // 1 no requests, 2 no MFMAs, 4 no barrier, 8 / 16 no A / W fragment reads
+    constexpr int abl = 0;
+#endif
 #ifdef LIDIFF_CONV_PROBE
     long long tq_bar = 0, tq_head = 0, tq_dma = 0, tq_w = 0, tq_mma = 0, tq_fold = 0;
     const long long tq_start = __builtin_readcyclecounter();
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         // same launch takes 3.33 ms.  So the lever is the NUMBER of MFMAs: the block masks.
         if (more) next_stage(sg + 1);
         S3_T(tq_head);
-        if (more && wave < NW / 2 && !(abl & 1)) { issue_a(); issue_w(); }
+        if (more && wave < NW / 2 && wave < NRQ && !(abl & 1)) { issue_a(); issue_w(); }
         S3_T(tq_dma);
         const char* st = smem + (sg & 1) * STAGE;
         const char* wsrc = st + ABYTES + (CBW * cg) * 3 * 1024 + lane * 16;
@@ -308,10 +320,12 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         // hold an offset are neighbours, and every wave should get its share of them)
         const char* asrc = st + rg * (16 * KS * 2) + foff;
         bf16x8 w[CBW][3];
+        if (!(abl & 16)) {
 #pragma unroll
-        for (int c = 0; c < CBW; ++c)
+            for (int c = 0; c < CBW; ++c)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) w[c][q] = *reinterpret_cast<const bf16x8*>(wsrc + (c * 3 + q) * 1024);
+                for (int q = 0; q < 3; ++q) w[c][q] = *reinterpret_cast<const bf16x8*>(wsrc + (c * 3 + q) * 1024);
+        }
         // Row block after row block: the fragment reads of block j + 1 are issued (always -- a block that is skipped costs three
         // idle LDS reads) in front of the twelve MFMAs of block j (only if the block holds a neighbour under this offset: a
         // wave-uniform branch), so that no MFMA group waits for its own reads.  The six products, smallest first; swapped operands
@@ -320,6 +334,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     _Pragma("unroll") for (int c = 0; c < CBW; ++c)                                                                        \
         acc_k[J][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][QW], A[QA], acc_k[J][c], 0, 0, 0)
         auto read_block = [&](int j, bf16x8* a) {
+            if (abl & 8) return;
 #pragma unroll
             for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(asrc + q * APLANE + (RG * j) * (16 * KS * 2));
         };
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         block(ic<1>{});
         if constexpr (RBW >= 8) { block(ic<2>{}); block(ic<3>{}); }
         S3_T(tq_mma);
-        if (more && wave >= NW / 2 && !(abl & 1)) { issue_a(); issue_w(); }
+        if (more && wave >= NW / 2 && wave < NRQ && !(abl & 1)) { issue_a(); issue_w(); }
         S3_T(tq_dma);
         if constexpr (RBW >= 8) { block(ic<4>{}); block(ic<5>{}); block(ic<6>{}); block(ic<7>{}); }
         else { block(ic<2>{}); block(ic<3>{}); }
@@ -486,7 +501,7 @@ extern "C" int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const
     p.k_vol = k_vol; p.relu = relu; p.replicas = replicas;
 #ifdef LIDIFF_CONV_PROBE
     p.timeline = g_s3_timeline;
-#endif
     { static const int abl = [] { const char* e = getenv("LIDIFF_S3_ABLATE"); return e ? atoi(e) : 0; }(); p.flags = abl; }
+#endif
     return c_out % 128 == 0 ? launch_split3<128>(p, (hipStream_t)stream) : launch_split3<64>(p, (hipStream_t)stream);
 }

@@ -1303,6 +1303,12 @@ SPLIT3_MIN_STRIDE = int(os.environ.get("LIDIFF_SPLIT3_MIN_STRIDE", "4"))
 SPLIT3_MIN_TILES = 256          # fewer 256 x 128 tiles than compute units (the condition encoders, late steps' coarse levels): native kernel
 # ... with the rows of the map sorted by their neighbour sets (mask_sorted_map), so that the kernel skips whole 16-row blocks
 SPLIT3_SORTED = os.environ.get("LIDIFF_SPLIT3_SORTED", "1") != "0"
+# Where a table is sorted: at its first use, on the consumer's stream (3 x ~0.1 ms per step on the denoiser's stream).  Sorting on
+# the map lane of a pyramid built in lanes (True) takes it off that stream, but made the loop with side streams differ from the
+# serial loop in the last bit of a few points once in ~10 runs (tests/test_gpu_network.py::test_overlapped_coordinate_pipeline_
+# equals_the_serial_one; neither an event of the sort itself nor record_stream on its results cured it, a device synchronise did):
+# off until that is understood.
+SPLIT3_PRESORT = False
 
 
 def split3_layer(tensor_stride: int, rows: int, replicas: int, c_in_a: int, c_in_b: int, c_out: int) -> bool:

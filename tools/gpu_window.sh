@@ -9,8 +9,8 @@ env "$@" timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python 
 cd $R
 DB=$(find $O/prof -name "*results.db" | head -1)
 python tools/rocpd_stats.py $DB --top 45 > $O/rocprofv3_kernel_stats.md 2>&1
-python tools/rocpd_gaps.py $DB --last-ms 760 --top 15 > $O/idle_gaps.txt 2>&1
-python tools/rocpd_main_queue.py $DB --last-ms 760 > $O/main_queue.txt 2>&1
-python tools/rocpd_window.py $DB --nth 3 --ms 3.0 > $O/step_boundary_window.txt 2>&1
-rm -rf $O/prof
+python tools/rocpd_gaps.py $DB --last-ms ${LAST_MS:-560} --top 15 > $O/idle_gaps.txt 2>&1
+python tools/rocpd_main_queue.py $DB --last-ms ${LAST_MS:-560} > $O/main_queue.txt 2>&1
+python tools/rocpd_window.py $DB --after cfg_dpm_step_kernel --nth 3 --ms 4.0 > $O/step_boundary_window.txt 2>&1
+if [ -z "${KEEP_DB:-}" ]; then rm -rf $O/prof; fi
 cut -c1-200 $O/bench_under_rocprof.json; head -12 $O/main_queue.txt

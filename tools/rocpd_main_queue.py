@@ -21,7 +21,7 @@ def main():
     rows = [r for r in rows if r[0] >= t_end - last_ms * 1e6]
     per_q = collections.Counter()
     for s, e, n, q in rows:
-        if "spconv_fwd_kernel<128, 8, 1" in n:
+        if "spconv_fwd" in n:
             per_q[q] += e - s
     mainq = per_q.most_common(1)[0][0]
     mq = [r for r in rows if r[3] == mainq]

@@ -195,6 +195,21 @@ def mfma_busy_profile():
                        for k, v in js["layers"].items()}}
 
 
+def dense_gemm_tflops(dev, m=8192, k=8192, n=16384, iters=10):
+    """What a dense bf16 GEMM reaches on this chip through torch.matmul (hipBLASLt): the practical ceiling of the bf16 matrix pipe."""
+    a = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(k, n, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        a @ b
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        a @ b
+    e.record()
+    torch.cuda.synchronize()
+    return 2.0 * m * k * n * iters / (s.elapsed_time(e) * 1e-3) / 1e12
+
+
 def traffic_from_profile(variants, per="launch"):
     """HBM-side bytes of the conv variants `variants` from the committed PMC passes: FETCH_SIZE x2 (gfx950 correction) +
     WRITE_SIZE, summed over their kernel instantiations -- per launch, or in total over the profiled command.  PMC counters
@@ -750,6 +765,12 @@ def main():
             "all_rows_all_offsets_note": ("6 products x every row of every 256-row tile x every offset / time: what the matrix pipe WOULD run "
                                           "without the kernel's block masks (16-row blocks that lack an offset are skipped: 30 % of them at stride "
                                           "8, 70 % at stride 4 under mask-sorted rows) -- an upper bound of the executed rate, not the rate") if s3 else None,
+            "executed": None if not s3 else (lambda ex, gemm: {
+                "tflops": ex, "dense_gemm_bf16_tflops": gemm, "over_dense_gemm": ex / gemm,
+                "note": "6 products x the 16-row blocks the kernel multiplies (those that hold a neighbour under the offset) / time: the "
+                        "rate the matrix pipe runs at in this kernel, next to what torch.matmul (hipBLASLt) reaches on a dense bf16 "
+                        "[8192 x 8192] @ [8192 x 16384] product measured in this process -- the practical ceiling of the pipe on this "
+                        "chip (its nominal peak is `peak`)"})(d.get("executed_flops_timed", 0.0) / (d["ms"] * 1e-3) / 1e12, dense_gemm_tflops(device)),
             "traffic": traffic, "launches": d["timed"], "avg_us": 1e3 * d["ms"] / max(1, d["timed"]),
             "traffic_unit": "GB per launch (HBM-side, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": None if traffic is None else f"static: {traffic_src} (tools/pmc_bench.sh over this bench "

@@ -725,6 +725,15 @@ class ConvProfiler:
                 if ck not in counts:
                     counts[ck] = int((nbr[k // 2] >= 0).sum().item())
                 ex = 6 * 2.0 * reps * (-(-counts[ck] // 256) * 256) * k * c_in * c_out
+                # ... and what it executes WITH the block masks: the 16-row blocks that hold a neighbour under an offset
+                bk = ("blocks", key)
+                if bk not in counts:
+                    mp = (nbr.shape[1] // 16) * 16
+                    n_blk = int((nbr[:, :mp] >= 0).view(k, -1, 16).any(2).sum().item())
+                    if mp < nbr.shape[1]:
+                        n_blk += int((nbr[:, mp:] >= 0).any(1).sum().item())
+                    counts[bk] = n_blk
+                d["executed_flops_timed"] = d.get("executed_flops_timed", 0.0) + (6 * 2.0 * reps * 16 * counts[bk] * c_in * c_out if start is not None else 0.0)
             d["launches"] += 1
             if start is not None:
                 d["timed"] += 1

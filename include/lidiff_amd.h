@@ -297,9 +297,10 @@ int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const void* in_b
                              const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                              void* out_planes, const float* ep_scale, const float* ep_shift, const float* residual,
                              int32_t relu, int32_t replicas, const int32_t* d_m_out, const int32_t* row_order, void* stream);
-/* Rows sorted by their neighbour sets: lidiff_row_mask_keys writes, per row of a table nbr [k_vol][m], bit k = "has a neighbour
- * under offset k" (the centre offset also as bit 27: a descending sort puts the valid rows of a table handed over at its bound
- * first).  The caller sorts (stable, descending), permutes the table's columns (nbr[:, order]) and passes `row_order` = order
+/* Rows sorted by their neighbour sets: lidiff_row_mask_keys writes, per row of a table nbr [k_vol][m], one bit per offset = "has
+ * a neighbour under it" (k_vol = 27: the offsets present least often on a scan's surfaces -- out of the horizontal plane, corners
+ * before edges before faces -- in the leading bits; otherwise bit k for offset k; the centre offset also as bit 27: a descending
+ * sort puts the valid rows of a table handed over at its bound first).  The caller sorts (stable, descending), permutes the table's columns (nbr[:, order]) and passes `row_order` = order
  * (tile row -> output row) to lidiff_spconv_fwd_split3: results are the same values, but whole 16-row blocks of a tile then lack
  * an offset and are neither gathered nor multiplied (the kernel's block masks) -- 30 % fewer MFMAs at stride 8, 70 % at stride 4. */
 int lidiff_row_mask_keys(const int32_t* nbr, int32_t k_vol, int64_t m, int32_t* keys, void* stream);

@@ -1057,9 +1057,11 @@ class _BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
-        # bf16 training: the layer's output goes into a convolution next -- its bf16 shadow is written by the same launch
+        # bf16 training: a normalise + ReLU output goes into a convolution next (the block's second convolution, the next block's
+        # first) -- its bf16 shadow is written by the same launch.  Without the ReLU the output is a shortcut on its way into an
+        # add: no shadow (a convolution that does gather such a tensor casts it itself, ops.cast_bf16)
         ctx.shadow = TRAIN_OPERANDS == "bf16" and BF16_ROWS and c % 32 == 0
-        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=dev) if ctx.shadow else None
+        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=dev) if ctx.shadow and relu else None
         call("lidiff_bn_apply", ptr(x), m, c, ptr(stats[0]), ptr(stats[2]), ptr(w), ptr(b), ptr(residual), int(bool(relu)), ptr(y),
              ptr(y16), stream_ptr())
         if y16 is not None:

@@ -107,6 +107,8 @@ def run_steps(pipe, x_init, xs, tvals, first, count, cache_condition=False):
         if parts is None:
             x_cond, x_uncond = pipe.reset_partial_pcd(x_cond, x_uncond, next_t=tvals[j + 1] if j + 1 < first + count else None)
     why = pipe.read_free_check()
+    from lidiff_amd import ops
+    ops.split_check()
     if why is not None:
         raise RuntimeError("host-read-free steps voided: " + why + " (LIDIFF_READ_FREE=0 runs every step with its host read)")
     return x_t
@@ -712,6 +714,19 @@ def main():
                 torch.cuda.synchronize()
                 alt = (time.perf_counter() - t0, aprof)
                 ops.PROFILER = None
+        # ... and with the split-operand layers on TWO fp16 pieces per operand (opt-in, ops.split_pieces(2) / LIDIFF_SPLIT_PIECES=2)
+        alt16 = None
+        if world == 1 and not args.no_alt and ops.SPLIT3 and ops.SPLIT_PIECES == 3:
+            with ops.split_pieces(2):
+                run_steps(pipe, x_init, wx, wt, 0, 1)
+                hprof = None if args.no_kernel_events else ops.ConvProfiler({"split3"}, sample=3)
+                ops.PROFILER = hprof
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_steps(pipe, x_init, xs, tvals, 0, args.steps)
+                torch.cuda.synchronize()
+                alt16 = (time.perf_counter() - t0, hprof)
+                ops.PROFILER = None
     elapsed = ldist.max_over_ranks(elapsed, device=device)
     if args.cached_condition:
         elapsed_cached = ldist.max_over_ranks(elapsed_cached, device=device)
@@ -854,6 +869,25 @@ def main():
                     "kernel": "spconv_fwd_kernel, BN=128 output-channel tile (bn128)", "bound": "mfma", "achieved": tf,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "launches": d["timed"],
                     "avg_us": 1e3 * d["ms"] / max(1, d["timed"])}
+    if alt16 is not None:
+        h_elapsed, hprof = alt16
+        out["f16x2"] = {
+            "dtype": "f32 in / f32 out / f32 accumulate; the split-operand layers with each fp32 operand cut into 2 fp16 pieces (22 bits of "
+                     "the operand; weights pre-scaled by a power of two), the 3 products x0 w1, x1 w0, x0 w0 on v_mfma_f32_16x16x32_f16 -- "
+                     "half the matrix work of the default; OPT-IN (LIDIFF_SPLIT_PIECES=2 / ops.split_pieces(2)): measured errors against "
+                     "float64 equal the native fp32 MFMA kernel's (profiles/r06_f16x2.txt), but the operands are 22-bit, not 24-bit, "
+                     "and fp16's range applies to the features (a value beyond 65504 raises) -- which is why it is not the default",
+            "value": args.steps / h_elapsed, "unit": "steps/s", "ms_per_step": 1e3 * h_elapsed / args.steps,
+            "note": "the same K steps, same process; informational, never `value`"}
+        if hprof is not None:
+            d = hprof.summary().get("split3")
+            if d and d["ms"] > 0:
+                tf = d["flops_timed"] / (d["ms"] * 1e-3) / 1e12
+                out["f16x2"]["roofline"] = {
+                    "kernel": "spconv_fwd_split3_kernel<128, 2> (3 products per block on v_mfma_f32_16x16x32_f16)", "bound": "mfma",
+                    "achieved": 3.0 * tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 3.0 * tf / PEAK_BF16_MFMA_TFLOPS,
+                    "fp32_equivalent_tflops": tf, "executed_tflops": d.get("executed_flops_timed", 0.0) / 2.0 / (d["ms"] * 1e-3) / 1e12,
+                    "launches": d["timed"], "avg_us": 1e3 * d["ms"] / max(1, d["timed"])}
     if world == 1 and not args.no_coords_roofline:
         with torch.no_grad():
             out["roofline_hbm"] = coords_roofline(scan_np, device)

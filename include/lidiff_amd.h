@@ -28,10 +28,11 @@
 extern "C" {
 #endif
 
-#define LIDIFF_ABI_VERSION 27
+#define LIDIFF_ABI_VERSION 28
 #define LIDIFF_STATUS_KEY_RANGE 1   /* *d_status bit: a coordinate left the 16-bit key range */
 #define LIDIFF_STATUS_HASH_FULL 2
                                     /* *d_status bit: hash table too small (cap < 2*rows)     */
+#define LIDIFF_STATUS_F16_RANGE 8 /* *d_status bit: a value beyond fp16's range (or Inf / NaN) met the two-piece fp16 split (lidiff_split3_rows / lidiff_spconv_fwd_split3 with pieces = 2) */
 #define LIDIFF_STATUS_BOUND 4       /* *d_status bit: a device-side count exceeded the bound the host sized a buffer for (host-read-free
                                        steps, lidiff_tail_map_fill_bounded): nothing was overrun, the results of the step are void */
 #define LIDIFF_CONV_SPARSE_MAP 1    /* lidiff_spconv_fwd flags: low-density kernel map (hint) */
@@ -285,18 +286,30 @@ int lidiff_spconv_fwd_bf16(const float* in_a, int32_t c_in_a, const float* in_b,
  * the exact sum of three bf16 pieces x0 + x1 + x2 (round to nearest even at each cut); the six products x_i w_j with i + j <= 2 --
  * each exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16 -- leave out only terms below 2^-24 |x w|: the error against
  * float64 equals the fp32 MFMA's own (tests/test_gpu_kernels.py::test_spconv_split3_*; profiles/r06_split3.txt).
- *   lidiff_split3_rows: fp32 [m][c] -> bf16 [m][3][c] (the operand layout; c % 8 == 0);
+ *   lidiff_split3_rows: fp32 [m][c] -> bf16 [m][3][c] (pieces = 3; the operand layout; c % 8 == 0);
  *   weights: lidiff_spconv_pack_weights_bf16 with planes = 3;
  *   lidiff_spconv_fwd_split3: in_a3 / in_b3 = split matrices of `replicas` stacked feature matrices (fused ME.cat as in
  *   lidiff_spconv_fwd), nbr / k_vol / m_in / m_out / epilogue / replicas / d_m_out / row_order as there; out_planes (nullable): the
  *   output ALSO as bf16 [replicas * m_out][3][c_out] -- the next dense convolution's operand, cut in the epilogue.
  *   Shapes: c_in_a, c_in_b multiples of 32, c_out a multiple of 64 (lidiff_spconv_fwd_split3_supported). */
-int lidiff_split3_rows(const float* src, int64_t m, int32_t c, void* dst, void* stream);
+int lidiff_split3_rows(const float* src, int64_t m, int32_t c, int32_t pieces, void* dst, int32_t* d_status, const int32_t* d_rows,
+                       int64_t pitch, void* stream);   /* d_rows / pitch (pieces = 2, nullable): replicas of `pitch` rows with *d_rows valid ones each -- rows behind them are not cut (uninitialised memory must not raise the range flag) */
 int32_t lidiff_spconv_fwd_split3_supported(int32_t c_in_a, int32_t c_in_b, int32_t c_out);
 int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const void* in_b3, int32_t c_in_b, const void* w_packed3,
                              const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                              void* out_planes, const float* ep_scale, const float* ep_shift, const float* residual,
-                             int32_t relu, int32_t replicas, const int32_t* d_m_out, const int32_t* row_order, void* stream);
+                             int32_t relu, int32_t replicas, const int32_t* d_m_out, const int32_t* row_order, int32_t pieces,
+                             float out_scale, int32_t* d_status, void* stream);
+/* pieces = 2 (opt-in; pieces = 3 is everything described above): the same kernel on TWO fp16 pieces per operand and three
+ * products (x0 w1, x1 w0, x0 w0) -- half the matrix work, 4 instead of 6 bytes per gathered element.  The operands then carry 22
+ * bits (fp32: 24): a reduction of precision, small beside the rounding of the fp32 sums (profiles/r06_f16x2.txt), but a
+ * reduction; fp16's range applies to the features (|x| <= 65504: a value beyond it, Inf or NaN raises LIDIFF_STATUS_F16_RANGE in
+ * *d_status -- nullable -- and the results are void).  Layouts: fp16 [m][2][c] rows (lidiff_split3_rows, or cut by the kernel's
+ * epilogue into out_planes), weights packed by lidiff_spconv_pack_weights_f16x2 AFTER multiplication by `scale`, a power of two the
+ * caller picks so that the second pieces are normal fp16 numbers (max |w| * scale in [2^11, 2^12) works); out_scale = 1 / scale
+ * undoes it in the epilogue (exact). */
+int lidiff_spconv_pack_weights_f16x2(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out, float scale, void* w_packed,
+                                     int32_t* d_status, void* stream);
 /* Rows sorted by their neighbour sets: lidiff_row_mask_keys writes, per row of a table nbr [k_vol][m], one bit per offset = "has
  * a neighbour under it" (k_vol = 27: the offsets present least often on a scan's surfaces -- out of the horizontal plane, corners
  * before edges before faces -- in the leading bits; otherwise bit k for offset k; the centre offset also as bit 27: a descending

@@ -50,9 +50,10 @@ SIGNATURES = {
     "lidiff_spconv_pack_weights_bf16": (_i32, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "lidiff_spconv_fwd_bf16": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "lidiff_cast_bf16": (_i32, [_p, _i64, _p, _p]),
-    "lidiff_split3_rows": (_i32, [_p, _i64, _i32, _p, _p]),
+    "lidiff_split3_rows": (_i32, [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _p]),
     "lidiff_spconv_fwd_split3_supported": (_i32, [_i32, _i32, _i32]),
-    "lidiff_spconv_fwd_split3": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p]),
+    "lidiff_spconv_fwd_split3": (_i32, [_p, _i32, _p, _i32, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _i32, C.c_float, _p, _p]),
+    "lidiff_spconv_pack_weights_f16x2": (_i32, [_p, _i32, _i32, _i32, C.c_float, _p, _p, _p]),
     "lidiff_row_mask_keys": (_i32, [_p, _i32, _i64, _p, _p]),
     "lidiff_spconv_bwd_w_workspace_floats": (_i64, [_i32, _i32, _i32, _i64]),
     "lidiff_spconv_bwd_w": (_i32, [_p, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p]),
@@ -94,7 +95,7 @@ SIGNATURES = {
     "lidiff_nn_dist_grid": (_i32, [_p, _i64, _p, _i64, _i32, C.c_double, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 _lib = None
 
 

@@ -32,6 +32,8 @@ struct ConvParams {
                                 //   pitch of nbr / of the stacked replicas and bounds the grid): tiles behind it leave at once
     int c_in_a, c_in_b, c_in, c_out, k_vol, relu;
     int tiles_m, tiles_n, flags, replicas;
+    float out_scale;          // spconv_fwd_split3_kernel<BN, 2>: the inverse of the power of two the fp16 weights were packed with
+    int32_t* status;          //   ... and where a value beyond fp16's range is reported (LIDIFF_STATUS_F16_RANGE; nullable)
     int probe;                // LIDIFF_CONV_PROBE builds only: bit 0 = no A gather, 1 = no W loads,
                               // 2 = no barrier, 4 = no flush
     long long* timeline;      // LIDIFF_CONV_PROBE builds only: 8 cycle counters per workgroup (tools/conv_probe.py)

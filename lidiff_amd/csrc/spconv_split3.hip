@@ -30,6 +30,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int kStatusF16Range = 8;                          // LIDIFF_STATUS_F16_RANGE (include/lidiff_amd.h)
+
+__device__ __forceinline__ f32x4 s3_mfma(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 s3_mfma(const f16x8 a, const f16x8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ void s3_dma16(const i32x4 rsrc, const unsigned lds_addr, const int voff, const int soff) {
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -51,6 +61,67 @@ __device__ __forceinline__ void split3(const float x, __bf16& p0, __bf16& p1, __
     const float r1 = x - (float)p0;
     p1 = (__bf16)r1;
     p2 = (__bf16)(r1 - (float)p1);
+}
+
+// Two fp16 pieces (round to nearest even; the residual is exact in fp32): 22 bits of the operand, fp16's range (|x| <= 65504; the
+// second piece of a value below 0.125 is an fp16 denormal, which v_mfma_f32_16x16x32_f16 honours: tools/micro/f16_split.hip).
+// `bad` collects values the format cannot hold (beyond the range, Inf, NaN).
+__device__ __forceinline__ void split2h(const float x, _Float16& p0, _Float16& p1, bool& bad) {
+    bad |= !(fabsf(x) <= 65504.f);
+    p0 = (_Float16)x;
+    p1 = (_Float16)(x - (float)p0);
+}
+
+// fp32 rows [m][c] -> fp16 [m][2][c]
+// (d_rows / pitch: the matrix is `pitch`-row replicas handed over at their bound with *d_rows valid rows each -- what lies behind them
+//  is uninitialised and must not raise the range flag)
+__global__ void split2h_rows_kernel(const float* __restrict__ src, int64_t m, int c, _Float16* __restrict__ dst, int32_t* __restrict__ status,
+                                    const int32_t* __restrict__ d_rows, int64_t pitch) {
+    const int c8 = c >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * c8) return;
+    const int64_t row = i / c8;
+    if (d_rows != nullptr && row % pitch >= (int64_t)*d_rows) return;
+    const int cb = (int)(i % c8) * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src + row * c + cb), b = *reinterpret_cast<const float4*>(src + row * c + cb + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 q0, q1;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 p0, p1;
+        split2h(v[e], p0, p1, bad);
+        q0[e] = p0; q1[e] = p1;
+    }
+    _Float16* d = dst + row * 2 * c + cb;
+    *reinterpret_cast<f16x8*>(d) = q0;
+    *reinterpret_cast<f16x8*>(d + c) = q1;
+    if (bad && status) atomicOr(status, kStatusF16Range);
+}
+
+// packed weights of the two-piece kernel: the fragment order of pack_weights_bf16_kernel (spconv_bf16.hip) with planes = 2, fp16
+// pieces of w * scale (scale: a power of two chosen by the caller so that the second pieces are normal numbers)
+__global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, int k_vol, int c_in, int c_out, int nslab, float scale,
+                                          _Float16* __restrict__ wp, int64_t total, int32_t* __restrict__ status) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    int64_t rest = idx >> 9;
+    const int plane = (int)(rest % 2);
+    rest /= 2;
+    const int nt16 = c_out >> 4;
+    const int nt = (int)(rest % nt16);
+    rest /= nt16;
+    const int slab = (int)(rest % nslab);
+    const int k = (int)(rest / nslab);
+    const int kin = 32 * slab + 8 * (lane >> 4) + i;
+    const int col = 16 * nt + (lane & 15);
+    const float v = kin < c_in ? scale * w[((int64_t)k * c_in + kin) * c_out + col] : 0.f;
+    _Float16 p0, p1;
+    bool bad = false;
+    split2h(v, p0, p1, bad);
+    wp[idx] = plane ? p1 : p0;
+    if (bad && status) atomicOr(status, kStatusF16Range);
 }
 
 // fp32 rows [m][c] -> bf16 [m][3][c]
@@ -101,15 +172,19 @@ __global__ void row_mask_keys_kernel(const int32_t* __restrict__ nbr, int k_vol,
 #ifndef LIDIFF_S3_CBW
 #define LIDIFF_S3_CBW 2          // column blocks per wave on 128-column tiles (4 = 64 x 64 wave tiles: fewer LDS reads, measured +1.5 % SLOWER)
 #endif
-template <int BN>
+// NP = 3: bf16 pieces, six products (the default: fp32 accuracy).  NP = 2: fp16 pieces of 22-bit operands, three products -- half the
+// matrix work, 4 instead of 6 bytes per gathered element; p.out_scale undoes the power of two the weights were packed with.
+template <int BN, int NP = 3>
 __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams p_launch) {
+    using piece_t = typename std::conditional<NP == 3, __bf16, _Float16>::type;
+    using frag_t = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     // 8 waves as RG row groups x CG column groups, a wave = RBW row blocks x 2 column blocks: 128 columns -> 2 x 4 (8 x 2 blocks),
     // 64 columns -> 4 x 2 (4 x 2 blocks)
     constexpr int BM = 256, KS = 32, NW = 8, CBW = (BN == 128 ? LIDIFF_S3_CBW : 2), CG = (BN / 16) / CBW, RG = NW / CG;
     constexpr int RBW = (BM / 16) / RG;                     // row blocks per wave (8 / 4)
     constexpr int APLANE = BM * KS * 2;                     // one piece of the stage's rows: 16 KB
-    constexpr int ABYTES = 3 * APLANE;
-    constexpr int WBLK = 3 * (BN / 16);                     // 1 KB W blocks per stage: [column block][piece]
+    constexpr int ABYTES = NP * APLANE;
+    constexpr int WBLK = NP * (BN / 16);                    // 1 KB W blocks per stage: [column block][piece]
     constexpr int WBYTES = WBLK * 1024;
     constexpr int STAGE = ABYTES + WBYTES;
     constexpr int NRQ = LIDIFF_S3_NRQ;                      // waves that issue requests (8: all; 4: the first wave of every SIMD only)
@@ -129,12 +204,12 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     const int tiles_live = p.d_m_out ? (int)((m_valid + BM - 1) / BM) : p.tiles_m;
     if (tmr >= tiles_live * p.replicas) return;
     const int rep = tmr / tiles_live, tm = tmr - rep * tiles_live;
-    const int pitch_a = 3 * p.c_in_a * 2, pitch_b = 3 * p.c_in_b * 2;    // bytes per row of the split matrices
+    const int pitch_a = NP * p.c_in_a * 2, pitch_b = NP * p.c_in_b * 2;  // bytes per row of the split matrices
     const char* in_a = reinterpret_cast<const char*>(p.in_a) + (int64_t)rep * p.m_in * pitch_a;
     const char* in_b = p.in_b ? reinterpret_cast<const char*>(p.in_b) + (int64_t)rep * p.m_in * pitch_b : nullptr;
     p.out += (int64_t)rep * p.m_out * p.c_out;
     if (p.residual) p.residual += (int64_t)rep * p.m_out * p.c_out;
-    __bf16* out3 = p.out_planes ? reinterpret_cast<__bf16*>(p.out_planes) + (int64_t)rep * p.m_out * 3 * p.c_out : nullptr;
+    piece_t* out3 = p.out_planes ? reinterpret_cast<piece_t*>(p.out_planes) + (int64_t)rep * p.m_out * NP * p.c_out : nullptr;
     const int64_t row0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
     const int rows_here = (int)min((int64_t)BM, m_valid - row0);
@@ -182,7 +257,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     const int nslab = p.c_in / KS;
     const int nst = nact * nslab;
     const int nt16 = p.c_out >> 4;
-    const int w_slab_bytes = nt16 * 3 * 1024;
+    const int w_slab_bytes = nt16 * NP * 1024;
     auto rsrc = [](const void* base, int64_t bytes) {
         const uint64_t a = (uint64_t)(uintptr_t)base;
         i32x4 d = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
@@ -250,19 +325,19 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
     auto issue_w = [&]() {
 #pragma unroll
         for (int b = rqw; b < WBLK; b += NRQ)
-            s3_dma16(rsrc_w, s_base + n_slot * STAGE + ABYTES + b * 1024, (((n0 >> 4) * 3 + b) * 64 + lane) * 16, n_ws);
+            s3_dma16(rsrc_w, s_base + n_slot * STAGE + ABYTES + b * 1024, (((n0 >> 4) * NP + b) * 64 + lane) * 16, n_ws);
     };
     auto issue_a = [&]() {
-        int soff[3];
+        int soff[NP];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) soff[q] = n_cb + q * n_cw;
+        for (int q = 0; q < NP; ++q) soff[q] = n_cb + q * n_cw;
 #pragma unroll
         for (int j = 0; j < T; ++j) {
             const int t = rqw + NRQ * j;                     // a request = one 16-row block of one piece
             if (!((n_bm >> t) & 1u)) continue;               // (no neighbour in the block under this offset: not requested, not multiplied)
-            const int voff = row_cur[j] >= 0 ? row_cur[j] * (3 * n_cw) + chb[j] : (int)0x80000000;    // no neighbour: zeros, no bytes moved
+            const int voff = row_cur[j] >= 0 ? row_cur[j] * (NP * n_cw) + chb[j] : (int)0x80000000;   // no neighbour: zeros, no bytes moved
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < NP; ++q)
                 s3_dma16(n_from_a ? rsrc_a : rsrc_b, s_base + n_slot * STAGE + q * APLANE + t * 1024, voff, soff[q]);
         }
     };
@@ -321,16 +396,16 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         if (more && wave < NW / 2 && wave < NRQ && !(abl & 1)) { issue_a(); issue_w(); }
         S3_T(tq_dma);
         const char* st = smem + (sg & 1) * STAGE;
-        const char* wsrc = st + ABYTES + (CBW * cg) * 3 * 1024 + lane * 16;
+        const char* wsrc = st + ABYTES + (CBW * cg) * NP * 1024 + lane * 16;
         // this wave's row blocks: RG j + rg, j = 0 .. RBW - 1 (interleaved between the row groups: under sorted rows the blocks that
         // hold an offset are neighbours, and every wave should get its share of them)
         const char* asrc = st + rg * (16 * KS * 2) + foff;
-        bf16x8 w[CBW][3];
+        frag_t w[CBW][NP];
         if (!(abl & 16)) {
 #pragma unroll
             for (int c = 0; c < CBW; ++c)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) w[c][q] = *reinterpret_cast<const bf16x8*>(wsrc + (c * 3 + q) * 1024);
+                for (int q = 0; q < NP; ++q) w[c][q] = *reinterpret_cast<const frag_t*>(wsrc + (c * NP + q) * 1024);
         }
         // Row block after row block: the fragment reads of block j + 1 are issued (always -- a block that is skipped costs three
         // idle LDS reads) in front of the twelve MFMAs of block j (only if the block holds a neighbour under this offset: a
@@ -338,18 +413,20 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
         // (W fragment first): a lane ends up with 4 channels of one row.
 #define LIDIFF_S3_PRODUCT(J, A, QA, QW)                                                                                    \
     _Pragma("unroll") for (int c = 0; c < CBW; ++c)                                                                        \
-        acc_k[J][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][QW], A[QA], acc_k[J][c], 0, 0, 0)
-        auto read_block = [&](int j, bf16x8* a) {
+        acc_k[J][c] = s3_mfma(w[c][QW], A[QA], acc_k[J][c])
+        auto read_block = [&](int j, frag_t* a) {
             if (abl & 8) return;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(asrc + q * APLANE + (RG * j) * (16 * KS * 2));
+            for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const frag_t*>(asrc + q * APLANE + (RG * j) * (16 * KS * 2));
         };
-        bf16x8 fa[2][3];
+        frag_t fa[2][NP];
         auto block = [&](auto j_tag) {
             constexpr int J = decltype(j_tag)::value;
             if constexpr (J + 1 < RBW) read_block(J + 1, fa[(J + 1) & 1]);
             if (((c_bm >> (RG * J + rg)) & 1u) && !(abl & 2)) {
-                LIDIFF_S3_PRODUCT(J, fa[J & 1], 2, 0); LIDIFF_S3_PRODUCT(J, fa[J & 1], 0, 2); LIDIFF_S3_PRODUCT(J, fa[J & 1], 1, 1);
+                if constexpr (NP == 3) {
+                    LIDIFF_S3_PRODUCT(J, fa[J & 1], 2, 0); LIDIFF_S3_PRODUCT(J, fa[J & 1], 0, 2); LIDIFF_S3_PRODUCT(J, fa[J & 1], 1, 1);
+                }
                 LIDIFF_S3_PRODUCT(J, fa[J & 1], 1, 0); LIDIFF_S3_PRODUCT(J, fa[J & 1], 0, 1); LIDIFF_S3_PRODUCT(J, fa[J & 1], 0, 0);
             }
         };
@@ -400,6 +477,7 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
             const int64_t orow = p.row_order ? (int64_t)p.row_order[row0 + r] : row0 + r;     // tile row -> output row
             const int64_t o = orow * p.c_out + col;
             float4 v = make_float4(acc[j][c][0], acc[j][c][1], acc[j][c][2], acc[j][c][3]);
+            if constexpr (NP == 2) { v.x *= p.out_scale; v.y *= p.out_scale; v.z *= p.out_scale; v.w *= p.out_scale; }   // (a power of two: exact)
             if (p.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
             if (p.shift) { v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w; }
             if (p.residual) {
@@ -412,26 +490,41 @@ __global__ __launch_bounds__(512) void spconv_fwd_split3_kernel(const ConvParams
             *reinterpret_cast<float4*>(p.out + o) = v;
             if (out3) {                                      // the next dense convolution's operand, cut here
                 const float vv[4] = {v.x, v.y, v.z, v.w};
-                bf16x4 q0, q1, q2;
+                if constexpr (NP == 3) {
+                    bf16x4 q0, q1, q2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __bf16 p0, p1, p2;
-                    split3(vv[e], p0, p1, p2);
-                    q0[e] = p0; q1[e] = p1; q2[e] = p2;
+                    for (int e = 0; e < 4; ++e) {
+                        __bf16 p0, p1, p2;
+                        split3(vv[e], p0, p1, p2);
+                        q0[e] = p0; q1[e] = p1; q2[e] = p2;
+                    }
+                    __bf16* d = out3 + orow * 3 * p.c_out + col;
+                    *reinterpret_cast<bf16x4*>(d) = q0;
+                    *reinterpret_cast<bf16x4*>(d + p.c_out) = q1;
+                    *reinterpret_cast<bf16x4*>(d + 2 * p.c_out) = q2;
+                } else {
+                    f16x4 q0, q1;
+                    bool bad = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 p0, p1;
+                        split2h(vv[e], p0, p1, bad);
+                        q0[e] = p0; q1[e] = p1;
+                    }
+                    _Float16* d = out3 + orow * 2 * p.c_out + col;
+                    *reinterpret_cast<f16x4*>(d) = q0;
+                    *reinterpret_cast<f16x4*>(d + p.c_out) = q1;
+                    if (bad && p.status) atomicOr(p.status, kStatusF16Range);
                 }
-                __bf16* d = out3 + orow * 3 * p.c_out + col;
-                *reinterpret_cast<bf16x4*>(d) = q0;
-                *reinterpret_cast<bf16x4*>(d + p.c_out) = q1;
-                *reinterpret_cast<bf16x4*>(d + 2 * p.c_out) = q2;
             }
         }
     }
 }
 
-template <int BN>
+template <int BN, int NP>
 static int launch_split3(const ConvParams& p, hipStream_t st) {
-    constexpr size_t lds = 2 * (size_t)(3 * 256 * 32 * 2 + 3 * (BN / 16) * 1024) + 2 * 32 * 4 + 2 * 256 * 4;
-    auto kern = spconv_fwd_split3_kernel<BN>;
+    constexpr size_t lds = 2 * (size_t)(NP * 256 * 32 * 2 + NP * (BN / 16) * 1024) + 2 * 32 * 4 + 2 * 256 * 4;
+    auto kern = spconv_fwd_split3_kernel<BN, NP>;
     static thread_local bool configured = false;
     if (!configured) {
         LIDIFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -455,12 +548,33 @@ static long long* g_s3_timeline = nullptr;
 extern "C" void lidiff_debug_set_split3_timeline(long long* buf) { g_s3_timeline = buf; }
 #endif
 
-extern "C" int lidiff_split3_rows(const float* src, int64_t m, int32_t c, void* dst, void* stream) {
+extern "C" int lidiff_split3_rows(const float* src, int64_t m, int32_t c, int32_t pieces, void* dst, int32_t* d_status,
+                                  const int32_t* d_rows, int64_t pitch, void* stream) {
     LIDIFF_CHECK_ARG(m >= 0 && c > 0 && c % 8 == 0, "rows >= 0, channels a multiple of 8");
+    LIDIFF_CHECK_ARG(pieces == 3 || pieces == 2, "pieces: 3 (bf16) or 2 (fp16)");
     if (m == 0) return 0;
     LIDIFF_CHECK_ARG(src != nullptr && dst != nullptr, "null pointer");
     LIDIFF_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "pointers must be 16-byte aligned");
-    split3_rows_kernel<<<(unsigned)ceil_div(m * (c / 8), 256), 256, 0, (hipStream_t)stream>>>(src, m, c, (__bf16*)dst);
+    const unsigned grid = (unsigned)ceil_div(m * (c / 8), 256);
+    if (pieces == 3) split3_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, m, c, (__bf16*)dst);
+    else {
+        LIDIFF_CHECK_ARG(d_rows == nullptr || (pitch > 0 && m % pitch == 0), "d_rows: the matrix must be whole replicas of `pitch` rows");
+        split2h_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, m, c, (_Float16*)dst, d_status, d_rows, pitch);
+    }
+    LIDIFF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lidiff_spconv_pack_weights_f16x2(const float* w, int32_t k_vol, int32_t c_in, int32_t c_out, float scale, void* w_packed,
+                                                int32_t* d_status, void* stream) {
+    LIDIFF_CHECK_ARG(w != nullptr && w_packed != nullptr, "null pointer");
+    LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27 && c_in > 0, "kernel volume must be 1..27, c_in > 0");
+    LIDIFF_CHECK_ARG(c_out > 0 && c_out % 16 == 0, "c_out must be a multiple of 16");
+    LIDIFF_CHECK_ARG(scale > 0.f && frexpf(scale, (int[1]){0}) == 0.5f, "scale must be a power of two");
+    const int nslab = (c_in + 31) / 32;
+    const int64_t total = (int64_t)k_vol * nslab * 32 * c_out * 2;
+    pack_weights_f16x2_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(w, k_vol, c_in, c_out, nslab, scale,
+                                                                                              (_Float16*)w_packed, total, d_status);
     LIDIFF_CHECK_LAUNCH();
     return 0;
 }
@@ -481,22 +595,24 @@ extern "C" int32_t lidiff_spconv_fwd_split3_supported(int32_t c_in_a, int32_t c_
 extern "C" int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const void* in_b3, int32_t c_in_b, const void* w_packed3,
                                         const int32_t* nbr, int32_t k_vol, int64_t m_in, int64_t m_out, int32_t c_out, float* out,
                                         void* out_planes, const float* ep_scale, const float* ep_shift, const float* residual,
-                                        int32_t relu, int32_t replicas, const int32_t* d_m_out, const int32_t* row_order, void* stream) {
+                                        int32_t relu, int32_t replicas, const int32_t* d_m_out, const int32_t* row_order, int32_t pieces,
+                                        float out_scale, int32_t* d_status, void* stream) {
     LIDIFF_CHECK_ARG(in_a3 != nullptr && w_packed3 != nullptr && out != nullptr, "null pointer");
     LIDIFF_CHECK_ARG((in_b3 == nullptr) == (c_in_b == 0), "in_b3 and c_in_b must agree");
     LIDIFF_CHECK_ARG(lidiff_spconv_fwd_split3_supported(c_in_a, c_in_b, c_out), "widths: inputs multiples of 32, c_out a multiple of 64");
     LIDIFF_CHECK_ARG(k_vol >= 1 && k_vol <= 27, "kernel volume must be 1..27");
     LIDIFF_CHECK_ARG(nbr != nullptr || (k_vol == 1 && m_in == m_out), "identity map needs K=1, m_in==m_out");
     LIDIFF_CHECK_ARG(replicas >= 1 && m_out >= 0 && m_in >= 0, "bad shape");
+    LIDIFF_CHECK_ARG(pieces == 3 || (pieces == 2 && out_scale > 0.f), "pieces: 3 (bf16), or 2 (fp16) with the inverse of the weights' scale");
     if (m_out == 0) return 0;
     LIDIFF_CHECK_ARG(m_in > 0, "outputs without inputs");
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     LIDIFF_CHECK_ARG(al16(in_a3) && al16(in_b3) && al16(w_packed3) && al16(out) && al16(out_planes) && al16(ep_scale) && al16(ep_shift) &&
                          al16(residual), "pointers must be 16-byte aligned");
-    LIDIFF_CHECK_ARG(m_in * (int64_t)c_in_a * 6 < (1ll << 31) && m_in * (int64_t)c_in_b * 6 < (1ll << 31),
+    LIDIFF_CHECK_ARG(m_in * (int64_t)c_in_a * 2 * pieces < (1ll << 31) && m_in * (int64_t)c_in_b * 2 * pieces < (1ll << 31),
                      "a split feature matrix exceeds the 2 GiB buffer-descriptor range");
     LIDIFF_CHECK_ARG(nbr == nullptr || (int64_t)k_vol * m_out * 4 < (1ll << 31), "the neighbour table exceeds the 2 GiB buffer-descriptor range");
-    LIDIFF_CHECK_ARG(lidiff_spconv_packed_weight_bf16_elems(k_vol, c_in_a + c_in_b, c_out, 3) * 2 < (1ll << 31),
+    LIDIFF_CHECK_ARG(lidiff_spconv_packed_weight_bf16_elems(k_vol, c_in_a + c_in_b, c_out, pieces) * 2 < (1ll << 31),
                      "packed weights exceed the 2 GiB buffer-descriptor range");
     ConvParams p{};
     p.in_a = reinterpret_cast<const float*>(in_a3); p.in_b = reinterpret_cast<const float*>(in_b3);
@@ -504,10 +620,11 @@ extern "C" int lidiff_spconv_fwd_split3(const void* in_a3, int32_t c_in_a, const
     p.scale = ep_scale; p.shift = ep_shift; p.residual = residual;
     p.m_in = m_in; p.m_out = m_out; p.d_m_out = d_m_out;
     p.c_in_a = c_in_a; p.c_in_b = c_in_b; p.c_in = c_in_a + c_in_b; p.c_out = c_out;
-    p.k_vol = k_vol; p.relu = relu; p.replicas = replicas;
+    p.k_vol = k_vol; p.relu = relu; p.replicas = replicas; p.out_scale = out_scale; p.status = d_status;
 #ifdef LIDIFF_CONV_PROBE
     p.timeline = g_s3_timeline;
     { static const int abl = [] { const char* e = getenv("LIDIFF_S3_ABLATE"); return e ? atoi(e) : 0; }(); p.flags = abl; }
 #endif
-    return c_out % 128 == 0 ? launch_split3<128>(p, (hipStream_t)stream) : launch_split3<64>(p, (hipStream_t)stream);
+    if (pieces == 2) return c_out % 128 == 0 ? launch_split3<128, 2>(p, (hipStream_t)stream) : launch_split3<64, 2>(p, (hipStream_t)stream);
+    return c_out % 128 == 0 ? launch_split3<128, 3>(p, (hipStream_t)stream) : launch_split3<64, 3>(p, (hipStream_t)stream);
 }

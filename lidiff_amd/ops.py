@@ -7,6 +7,7 @@ relative to /root/reference/lidiff).
 from __future__ import annotations
 
 import contextlib
+import math
 import os
 
 import torch
@@ -16,6 +17,7 @@ from ._lib import call, ptr, require_device, stream_ptr
 
 STATUS_KEY_RANGE = 1
 STATUS_HASH_FULL = 2
+STATUS_F16_RANGE = 8      # a value beyond fp16's range met the two-piece fp16 split (spconv_fwd_split3 with SPLIT_PIECES = 2)
 STATUS_BOUND = 4          # a device-side count exceeded the bound a buffer was sized for (host-read-free steps)
 
 
@@ -1329,6 +1331,27 @@ def split3_layer(tensor_stride: int, rows: int, replicas: int, c_in_a: int, c_in
             and -(-rows * replicas // 256) * (c_out // (128 if c_out % 128 == 0 else 64)) >= SPLIT3_MIN_TILES)
 
 
+# Pieces per operand of the split-operand kernel: 3 (bf16; fp32 accuracy: the default) or 2 (fp16; 22-bit operands, three products
+# instead of six -- opt-in: a reduction of precision, DESIGN.md 4.3, profiles/r06_f16x2.txt)
+SPLIT_PIECES = int(os.environ.get("LIDIFF_SPLIT_PIECES", "3"))
+
+
+class split_pieces:
+    """Context manager: `with ops.split_pieces(2):` runs the split-operand layers on two fp16 pieces (A/B measurements, tests)."""
+
+    def __init__(self, n: int):
+        assert n in (2, 3)
+        self.n = int(n)
+
+    def __enter__(self):
+        global SPLIT_PIECES
+        self.prev, SPLIT_PIECES = SPLIT_PIECES, self.n
+
+    def __exit__(self, *exc):
+        global SPLIT_PIECES
+        SPLIT_PIECES = self.prev
+
+
 class split3:
     """Context manager: `with ops.split3(False):` runs the native fp32 kernel everywhere (A/B measurements, parity tests)."""
 
@@ -1344,22 +1367,74 @@ class split3:
         SPLIT3 = self.prev
 
 
-def split3_rows(x: torch.Tensor) -> torch.Tensor:
-    """fp32 rows [M, C] -> bf16 [M, 3, C]: every value as the exact sum of three bf16 pieces (lidiff_split3_rows) -- the operand
-    layout of spconv_fwd_split3.  Kept on the tensor object (`_lidiff_split3`): consumers of one tensor share the cut."""
+def split3_rows(x: torch.Tensor, pieces: int | None = None, d_rows: torch.Tensor | None = None, replicas: int = 1) -> torch.Tensor:
+    """fp32 rows [M, C] -> bf16 [M, 3, C] (pieces = 3: every value as the exact sum of three bf16 pieces) or fp16 [M, 2, C] (pieces = 2:
+    22 bits of every value) (lidiff_split3_rows) -- the operand layout of spconv_fwd_split3.  Kept on the tensor object
+    (`_lidiff_split3`): consumers of one tensor share the cut."""
+    pieces = SPLIT_PIECES if pieces is None else int(pieces)
     hit = getattr(x, "_lidiff_split3", None)
-    if hit is not None and hit[0] == (x.data_ptr(), x._version, tuple(x.shape)):
+    if hit is not None and hit[0] == (x.data_ptr(), x._version, tuple(x.shape), pieces):
         return hit[1]
     require_device(x)
-    assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 8 == 0
-    x = x.contiguous()
-    out = torch.empty((x.shape[0], 3, x.shape[1]), dtype=torch.bfloat16, device=x.device)
-    call("lidiff_split3_rows", ptr(x), x.shape[0], x.shape[1], ptr(out), stream_ptr())
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] % 8 == 0
+    out = torch.empty((x.shape[0], pieces, x.shape[1]), dtype=torch.bfloat16 if pieces == 3 else torch.float16, device=x.device)
+    # (d_rows: a matrix handed over at its bound -- the rows behind the device-side count are uninitialised and are left alone)
+    call("lidiff_split3_rows", ptr(x), x.shape[0], x.shape[1], pieces, ptr(out), ptr(split_status(x.device)) if pieces == 2 else None,
+         ptr(d_rows), x.shape[0] // max(1, replicas), stream_ptr())
     try:
-        x._lidiff_split3 = ((x.data_ptr(), x._version, tuple(x.shape)), out)
+        x._lidiff_split3 = ((x.data_ptr(), x._version, tuple(x.shape), pieces), out)
     except AttributeError:
         pass
     return out
+
+
+_SPLIT_STATUS = {}
+
+
+def split_status(device) -> torch.Tensor:
+    """The device word the two-piece fp16 kernels report values beyond fp16's range in (split_check reads it)."""
+    idx = torch.cuda.current_device() if getattr(device, "index", None) is None else device.index
+    if idx not in _SPLIT_STATUS:
+        _SPLIT_STATUS[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    return _SPLIT_STATUS[idx]
+
+
+def split_check() -> None:
+    """Raises if a two-piece fp16 convolution since the last call met a value it cannot hold (one host read; a no-op when the mode was
+    never used).  DiffCompletion calls it at the end of a scan."""
+    for t in _SPLIT_STATUS.values():
+        flags = int(t.item())
+        if flags:
+            t.zero_()
+        if flags & STATUS_F16_RANGE:
+            raise RuntimeError("a feature or weight beyond fp16's range (|x| > 65504, Inf or NaN) reached the two-piece fp16 convolution "
+                               "(LIDIFF_SPLIT_PIECES=2): results are void -- run with the default three bf16 pieces")
+
+
+def packed_weights_split(w: torch.Tensor, pieces: int):
+    """(packed weights, out_scale) of spconv_fwd_split3: three bf16 pieces (out_scale 1), or two fp16 pieces of w * 2^k with 2^k
+    putting max |w| into [2^11, 2^12) -- every second piece a normal fp16 number, products far inside fp32's range -- and out_scale =
+    2^-k.  Cached on the Parameter (the scale costs one host read per weight version)."""
+    if pieces == 3:
+        return packed_weights_bf16(w, planes=3), 1.0
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    key = (w.data_ptr(), w._version, tuple(w3.shape), w.device)
+    hit = getattr(w, "_lidiff_packed_f16x2", None)
+    if hit is None or hit[0] != key:
+        src = w3.detach().contiguous().float()
+        k, c_in, c_out = src.shape
+        top = float(src.abs().max())
+        if not math.isfinite(top):
+            raise RuntimeError("non-finite convolution weights")
+        scale = 2.0 ** (11 - math.floor(math.log2(top))) if top > 0.0 else 1.0
+        wp = torch.empty(_lib.load().lidiff_spconv_packed_weight_bf16_elems(k, c_in, c_out, 2), dtype=torch.float16, device=w.device)
+        call("lidiff_spconv_pack_weights_f16x2", ptr(src), k, c_in, c_out, float(scale), ptr(wp), ptr(split_status(w.device)), stream_ptr())
+        hit = (key, wp, 1.0 / scale)
+        try:
+            setattr(w, "_lidiff_packed_f16x2", hit)
+        except AttributeError:
+            pass
+    return hit[1], hit[2]
 
 
 def mask_sorted_map(nbr: torch.Tensor):
@@ -1384,21 +1459,27 @@ def split3_conv_applies(c_in_a: int, c_in_b: int, c_out: int) -> bool:
 
 def spconv_fwd_split3(in_a, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int, in_b=None, scale=None, shift=None,
                       residual=None, relu: bool = False, replicas: int = 1, d_rows: torch.Tensor | None = None,
-                      want_planes: bool = False, row_order: torch.Tensor | None = None) -> torch.Tensor:
+                      want_planes: bool = False, row_order: torch.Tensor | None = None, pieces: int | None = None) -> torch.Tensor:
     """spconv_fwd (fp32 in, fp32 out, fp32 accuracy) with the contraction on the bf16 matrix pipe from three-way split operands
     (lidiff_spconv_fwd_split3; include/lidiff_amd.h).  in_a / in_b: fp32 [R * M_in, C] (cut here, the cut cached on the
     tensor) or the bf16 [R * M_in, 3, C] pieces themselves.  want_planes: the result carries its own pieces
     (`_lidiff_split3`, written by the kernel's epilogue) for the next dense convolution.  row_order: int32 permutation of the
-    output rows with `nbr` holding its columns in that order (mask_sorted_map); results do not depend on it."""
+    output rows with `nbr` holding its columns in that order (mask_sorted_map); results do not depend on it.  pieces: 3 bf16 (default,
+    ops.SPLIT_PIECES) or 2 fp16 pieces per operand."""
     require_device(w, nbr, scale, shift, residual, row_order)
+    pieces = SPLIT_PIECES if pieces is None else int(pieces)
+    pdt = torch.bfloat16 if pieces == 3 else torch.float16
     if row_order is not None:
         assert row_order.dtype == torch.int32 and row_order.shape == (m_out,) and row_order.is_contiguous() and nbr is not None
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
     k, c_in, c_out = w3.shape
-    wp = packed_weights_bf16(w, planes=3)
-    a3 = in_a if in_a.dtype == torch.bfloat16 else split3_rows(in_a)
-    b3 = None if in_b is None else (in_b if in_b.dtype == torch.bfloat16 else split3_rows(in_b))
-    assert a3.dim() == 3 and a3.shape[1] == 3 and a3.is_contiguous() and a3.shape[0] % replicas == 0
+    wp, out_scale = packed_weights_split(w, pieces)
+    # (for a kernel_size-3 map onto itself the inputs' valid rows are the outputs': d_rows describes both)
+    in_rows = d_rows if (nbr is None or in_a.shape[0] == replicas * m_out) else None
+    a3 = in_a if in_a.dtype == pdt else split3_rows(in_a, pieces, in_rows, replicas)
+    b3 = None if in_b is None else (in_b if in_b.dtype == pdt else split3_rows(in_b, pieces, in_rows, replicas))
+    assert a3.dim() == 3 and a3.shape[1] == pieces and a3.dtype == pdt and a3.is_contiguous() and a3.shape[0] % replicas == 0
+    assert b3 is None or (b3.dim() == 3 and b3.shape[1] == pieces and b3.dtype == pdt)
     c_a, c_b = a3.shape[2], 0 if b3 is None else b3.shape[2]
     assert c_a + c_b == c_in, f"channel mismatch {c_a}+{c_b} != {c_in}"
     m_in = a3.shape[0] // replicas
@@ -1408,7 +1489,7 @@ def spconv_fwd_split3(in_a, w: torch.Tensor, nbr: torch.Tensor | None, m_out: in
         residual = residual.contiguous()
         assert residual.shape == (replicas * m_out, c_out)
     out = torch.empty((replicas * m_out, c_out), dtype=torch.float32, device=a3.device)
-    out3 = torch.empty((replicas * m_out, 3, c_out), dtype=torch.bfloat16, device=a3.device) if want_planes else None
+    out3 = torch.empty((replicas * m_out, pieces, c_out), dtype=pdt, device=a3.device) if want_planes else None
     prof = PROFILER
     timed = prof is not None and prof.wants("split3")
     start = end = None
@@ -1417,13 +1498,14 @@ def spconv_fwd_split3(in_a, w: torch.Tensor, nbr: torch.Tensor | None, m_out: in
         _lib.join_pending()
         start.record()
     call("lidiff_spconv_fwd_split3", ptr(a3), c_a, ptr(b3), c_b, ptr(wp), ptr(nbr), k, m_in, m_out, c_out, ptr(out), ptr(out3),
-         ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), ptr(d_rows), ptr(row_order), stream_ptr())
+         ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), int(replicas), ptr(d_rows), ptr(row_order), pieces, float(out_scale),
+         ptr(split_status(a3.device)) if pieces == 2 else None, stream_ptr())
     if timed:
         end.record()
     if prof is not None:
         prof.launches.append(("split3", start, end, m_in, m_out, c_in, c_out, k, nbr, replicas))
     if out3 is not None:
-        out._lidiff_split3 = ((out.data_ptr(), out._version, tuple(out.shape)), out3)
+        out._lidiff_split3 = ((out.data_ptr(), out._version, tuple(out.shape), pieces), out3)
     return out
 
 

@@ -577,13 +577,19 @@ class DiffCompletion(nn.Module):
         that way from the start."""
         self.read_free_reset()          # the first pyramid of every role in this loop is built with its host read
         if not (self.read_free and x_t.F.device.type == "cuda"):
-            return self._completion_loop(x_init, x_t, x_cond, x_uncond, noises)
+            out = self._completion_loop(x_init, x_t, x_cond, x_uncond, noises)
+            if x_t.F.device.type == "cuda":
+                from . import ops
+                ops.split_check()                    # (two-piece fp16 mode only: a value beyond its range voids the scan, loudly)
+            return out
         sch = self.dpm_scheduler
         saved = {k: (list(v) if isinstance(v, list) else v) for k, v in sch.__dict__.items()}
         rng = torch.cuda.get_rng_state(self.device) if noises is None else None
         try:
             out = self._completion_loop(x_init, x_t, x_cond, x_uncond, noises, check=False)
             why = self.read_free_check()
+            from . import ops
+            ops.split_check()                        # (two-piece fp16 mode only: a value beyond its range voids the scan, loudly)
         except RuntimeError as e:                    # (a consumer tripped over the same overflow before the host looked)
             if "bound" not in str(e):
                 raise

@@ -751,15 +751,24 @@ def test_spconv_256_row_tiles_vs_128_row_tiles_and_oracle(device, cin, split, co
         assert torch.allclose(got[:m][rows].cpu().double(), want, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("pieces", [3, 2])
 @pytest.mark.parametrize("cin,split,cout", [(128, 0, 128), (256, 0, 256), (384, 256, 256), (128, 0, 256), (192, 128, 128), (64, 0, 128),
                                             (64, 0, 64), (32, 0, 64), (96, 64, 192)])
-def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout):
+def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout, pieces):
     """lidiff_spconv_fwd_split3 (round 6): fp32 in / fp32 out with the contraction on the bf16 matrix pipe from three-way split
     operands -- against the float64 oracle at the NATIVE fp32 kernel's own bars (RTOL / ATOL of this file), and its worst error
     next to the native kernel's on the same inputs (recorded; asserted within 1.5x + one ulp of the output scale): dense and
     nearly empty maps, tiles without a pair, the CFG pair stacked, a ragged last tile, fused ME.cat, every epilogue, a
     device-side row count, the identity map (kernel_size 1), and the pieces of the OUTPUT written by the epilogue (their sum is
-    the fp32 output, bit for bit)."""
+    the fp32 output, bit for bit).  pieces = 2: the opt-in mode on two fp16 pieces per operand (22-bit operands, three products) --
+    the SAME bars, the same checks (its pieces sum to the output to 2^-21)."""
+    from lidiff_amd import ops
+    with ops.split_pieces(pieces):
+        _split_conv_case(device, cin, split, cout, pieces)
+    ops.split_check()
+
+
+def _split_conv_case(device, cin, split, cout, pieces):
     from lidiff_amd import ops
     g = torch.Generator().manual_seed(5 + cin + cout)
     worst = {}
@@ -797,7 +806,10 @@ def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout):
             got_s = ops.spconv_fwd_split3(a, w.to(device), nbr_s, m, in_b=b, want_planes=True, row_order=order, **kw)
             assert torch.equal(got_s, got) and torch.equal(got_s._lidiff_split3[1], got._lidiff_split3[1])
             planes = got._lidiff_split3[1].float()
-            assert torch.equal(planes[:, 0] + planes[:, 1] + planes[:, 2], got)
+            if pieces == 3:
+                assert torch.equal(planes[:, 0] + planes[:, 1] + planes[:, 2], got)
+            else:
+                assert planes.shape[1] == 2 and bool(((planes[:, 0] + planes[:, 1] - got).abs() <= got.abs() * 2.0 ** -21 + 2.0 ** -25).all())
             assert torch.equal(planes, ops.split3_rows(got.clone()).float())
             # no epilogue
             plain = ops.spconv_fwd_split3(a, w.to(device), nbr, m, in_b=b, replicas=reps)
@@ -820,7 +832,33 @@ def test_spconv_split3_is_an_fp32_convolution(device, cin, split, cout):
     got1 = ops.spconv_fwd_split3(a, w1.to(device), None, m, in_b=b, replicas=reps)
     want1 = x.double() @ w1[0].double()
     assert torch.allclose(got1.cpu().double(), want1, rtol=RTOL, atol=ATOL)
-    record_parity(f"split3_{cin}_{cout}", **{f"err_split3_vs_native_{k}": v for k, v in worst.items()})
+    record_parity(f"split3_{cin}_{cout}" if pieces == 3 else f"split_f16x2_{cin}_{cout}", **{f"err_split3_vs_native_{k}": v for k, v in worst.items()})
+
+
+def test_two_piece_fp16_split_reports_values_beyond_its_range(device):
+    """The opt-in two-piece fp16 mode holds |x| <= 65504: a feature beyond that (or Inf / NaN) raises LIDIFF_STATUS_F16_RANGE on the
+    device and ops.split_check() turns it into an exception -- from the row cut and from the epilogue's cut of an output alike;
+    the default three-piece bf16 mode has fp32's range and reports nothing."""
+    from lidiff_amd import ops
+    x = torch.randn(4096, 64, device=device)
+    w = torch.randn(1, 64, 64, device=device) / 8
+    with ops.split_pieces(2):
+        ops.spconv_fwd_split3(x, w, None, 4096, want_planes=True)
+        ops.split_check()                                                   # in range: silent
+        bad = x.clone()
+        bad[17, 3] = 7.0e4
+        ops.spconv_fwd_split3(bad, w, None, 4096)
+        with pytest.raises(RuntimeError, match="fp16's range"):
+            ops.split_check()
+        ops.split_check()                                                   # (the word was cleared)
+        big = ops.spconv_fwd_split3(x, w * 3.0e4, None, 4096, want_planes=True)      # outputs of ~1e5: the epilogue's cut overflows
+        assert float(big.abs().max()) > 65504
+        with pytest.raises(RuntimeError, match="fp16's range"):
+            ops.split_check()
+    with ops.split_pieces(3):
+        got = ops.spconv_fwd_split3(bad, w, None, 4096, want_planes=True)
+        ops.split_check()
+    assert bool(torch.isfinite(got).all())
 
 
 @pytest.mark.parametrize("m,c", [(2, 32), (37, 96), (5000, 256), (120001, 64), (70000, 128), (9, 4)])

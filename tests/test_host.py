@@ -34,7 +34,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
             assert (a is want) if want is not None else a in (C.c_int32, C.c_int64), (name, q, a)
             if want is None:
                 assert a is (C.c_int64 if q.startswith("int64_t") else C.c_int32), (name, q, a)
-    assert lib.lidiff_abi_version() == _lib.ABI_VERSION == 27
+    assert lib.lidiff_abi_version() == _lib.ABI_VERSION == 28
     assert lib.lidiff_hash_capacity(180000) == 524288 and lib.lidiff_hash_capacity(1) == 1024
     assert lib.lidiff_unique_workspace_bytes(1000) >= 1000 * 4
     # host-side argument validation reaches the error string without touching a device

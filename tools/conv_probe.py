@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--lpt", action="store_true", help="128-row tiles in descending pair-count order (row_order + permuted table)")
     ap.add_argument("--sparse-hint", type=int, default=-1, help="force the sparse-map hint (0/1); default: the manager's rule")
     ap.add_argument("--kernel", default="tile", choices=["tile", "bf16", "split3"], help="kernel of the dense 128-column layers")
+    ap.add_argument("--pieces", type=int, default=3, choices=[2, 3], help="--kernel split3: 3 bf16 pieces (default) or 2 fp16 pieces per operand")
     ap.add_argument("--rows16", action="store_true", help="--kernel bf16: gather bf16 shadow rows (ops.cast_bf16) instead of fp32 rows")
     ap.add_argument("--planes", type=int, default=1, help="--kernel bf16: bf16 pieces per operand (1 = rounded, 2 / 3 = split)")
     ap.add_argument("--centre-tail", action="store_true", help="k3 layers as centre pass + tail rows (ops.spconv_centre_tail)")
@@ -119,9 +120,9 @@ def main():
             tmap = ops.TailMap(nbr)
             conv = lambda: ops.spconv_centre_tail(x, w, tmap, m_out, replicas=args.replicas, sparse_map=hint)
         elif args.kernel == "split3" and ops.split3_conv_applies(cin, 0, cout):
-            x3 = ops.split3_rows(x)
+            x3 = ops.split3_rows(x, args.pieces)
             nbr_s, order_s = (ops.mask_sorted_map(nbr) if args.flags & 1 else (nbr, None))
-            conv = lambda: ops.spconv_fwd_split3(x3, w, nbr_s, m_out, replicas=args.replicas, row_order=order_s)
+            conv = lambda: ops.spconv_fwd_split3(x3, w, nbr_s, m_out, replicas=args.replicas, row_order=order_s, pieces=args.pieces)
         elif args.kernel == "bf16" and ops.bf16_conv_applies(cin, 0, cout):
             xin = ops.cast_bf16(x) if args.rows16 else x
             conv = lambda: ops.spconv_fwd_bf16(xin, w, nbr, m_out, planes=args.planes, replicas=args.replicas,

@@ -39,6 +39,7 @@ def block_fraction(nbr, blk=16, tile=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sigmas", default="1.0,0.3,0.05")
+    ap.add_argument("--f16x2", action="store_true", help="also the opt-in two-piece fp16 mode (ops.split_pieces(2)): time and error columns")
     args = ap.parse_args()
     from lidiff_amd import ops
     import lidiff_amd.MinkowskiEngine as ME
@@ -47,7 +48,7 @@ def main():
     layers = [(3, 256, 256), (3, 384, 256), (4, 256, 256), (3, 128, 128), (4, 128, 256), (2, 128, 128), (2, 192, 128), (2, 64, 64), (2, 32, 64)]
     print("# split-operand kernel vs native fp32 kernel, bench scan, CFG pair stacked (replicas 2); errors vs a float64 reference on 4096 output rows")
     print("# sigma level cin->cout | rows pairs occupancy | executed block fraction: table order / sorted | native us TF | split3 table-order us | "
-          "split3 sorted us TF-equivalent | speed-up | max|err| native / split3 (outputs up to)")
+          "split3 sorted us TF-equivalent | speed-up | max|err| native / split3 (outputs up to)" + (" | f16x2 sorted us TF-equivalent | max|err|" if args.f16x2 else ""))
     for sigma in [float(v) for v in args.sigmas.split(",")]:
         rng = np.random.default_rng(0)
         pts = np.tile(scan, (10, 1)) + sigma * rng.standard_normal((180000, 3)).astype(np.float32)
@@ -84,9 +85,17 @@ def main():
             en = (out_n[:m][rows].double() - ref).abs().max().item()
             es = (out_s[:m][rows].double() - ref).abs().max().item()
             fl = 2.0 * 2 * pairs * cin * cout
+            extra = ""
+            if args.f16x2:
+                x2 = ops.split3_rows(x, 2)
+                t_h = timed(lambda: ops.spconv_fwd_split3(x2, w, nbr_s, m, replicas=2, row_order=order, pieces=2))
+                out_h = ops.spconv_fwd_split3(x2, w, nbr_s, m, replicas=2, row_order=order, pieces=2)
+                eh = (out_h[:m][rows].double() - ref).abs().max().item()
+                ops.split_check()
+                extra = f" | {t_h:7.1f} {fl / t_h / 1e6:6.1f} | {eh:.2e}"
             print(f"{sigma:<4} {level} {cin:>3}->{cout:<3} | {m:>6} {pairs:>8} {pairs / (27.0 * m):.3f} | {block_fraction(nbr):.3f} / {block_fraction(nbr_s):.3f} | "
                   f"{t_nat:7.1f} {fl / t_nat / 1e6:6.1f} | {t_tab:7.1f} | {t_srt:7.1f} {fl / t_srt / 1e6:6.1f} | {t_nat / t_srt:4.2f}x | "
-                  f"{en:.2e} / {es:.2e} ({ref.abs().max().item():.1f})", flush=True)
+                  f"{en:.2e} / {es:.2e} ({ref.abs().max().item():.1f})" + extra, flush=True)
 
 
 if __name__ == "__main__":

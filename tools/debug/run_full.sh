@@ -6,3 +6,4 @@ timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench_defaul
 cut -c1-200 gpurun_out/r06_bench_default.json
 python tools/split3_table.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_split3.txt; tail -3 gpurun_out/r06_split3.txt | cut -c1-160
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+LIDIFF_SPLIT_PIECES=2 LIDIFF_PARITY_LOG=$PWD/gpurun_out/parity_f16x2.jsonl timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee gpurun_out/r06_pytest_gpu_f16x2_summary.txt

@@ -1313,6 +1313,7 @@ def spconv_fwd_bf16(in_a: torch.Tensor, w: torch.Tensor, nbr: torch.Tensor | Non
 # LIDIFF_SPLIT3=0: every layer on the native fp32-MFMA kernel.
 SPLIT3 = os.environ.get("LIDIFF_SPLIT3", "1") != "0"
 SPLIT3_MIN_STRIDE = int(os.environ.get("LIDIFF_SPLIT3_MIN_STRIDE", "4"))
+SPLIT3_K1_MIN_CIN = 256         # kernel_size-1 shortcuts narrower than this stay on the streaming row kernel (too little work per tile)
 SPLIT3_MIN_TILES = 256          # fewer 256 x 128 tiles than compute units (the condition encoders, late steps' coarse levels): native kernel
 # ... with the rows of the map sorted by their neighbour sets (mask_sorted_map), so that the kernel skips whole 16-row blocks
 SPLIT3_SORTED = os.environ.get("LIDIFF_SPLIT3_SORTED", "1") != "0"
@@ -1459,7 +1460,8 @@ def split3_conv_applies(c_in_a: int, c_in_b: int, c_out: int) -> bool:
 
 def spconv_fwd_split3(in_a, w: torch.Tensor, nbr: torch.Tensor | None, m_out: int, in_b=None, scale=None, shift=None,
                       residual=None, relu: bool = False, replicas: int = 1, d_rows: torch.Tensor | None = None,
-                      want_planes: bool = False, row_order: torch.Tensor | None = None, pieces: int | None = None) -> torch.Tensor:
+                      want_planes: bool = False, row_order: torch.Tensor | None = None, pieces: int | None = None,
+                      d_in_rows: torch.Tensor | None = None) -> torch.Tensor:
     """spconv_fwd (fp32 in, fp32 out, fp32 accuracy) with the contraction on the bf16 matrix pipe from three-way split operands
     (lidiff_spconv_fwd_split3; include/lidiff_amd.h).  in_a / in_b: fp32 [R * M_in, C] (cut here, the cut cached on the
     tensor) or the bf16 [R * M_in, 3, C] pieces themselves.  want_planes: the result carries its own pieces
@@ -1475,7 +1477,7 @@ def spconv_fwd_split3(in_a, w: torch.Tensor, nbr: torch.Tensor | None, m_out: in
     k, c_in, c_out = w3.shape
     wp, out_scale = packed_weights_split(w, pieces)
     # (for a kernel_size-3 map onto itself the inputs' valid rows are the outputs': d_rows describes both)
-    in_rows = d_rows if (nbr is None or in_a.shape[0] == replicas * m_out) else None
+    in_rows = d_in_rows if d_in_rows is not None else (d_rows if (nbr is None or in_a.shape[0] == replicas * m_out) else None)
     a3 = in_a if in_a.dtype == pdt else split3_rows(in_a, pieces, in_rows, replicas)
     b3 = None if in_b is None else (in_b if in_b.dtype == pdt else split3_rows(in_b, pieces, in_rows, replicas))
     assert a3.dim() == 3 and a3.shape[1] == pieces and a3.dtype == pdt and a3.is_contiguous() and a3.shape[0] % replicas == 0

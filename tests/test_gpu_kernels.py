@@ -827,6 +827,22 @@ def _split_conv_case(device, cin, split, cout, pieces):
                 got_ds = ops.spconv_fwd_split3(a, w.to(device), nbr_ds, m, in_b=b, d_rows=rows, row_order=order_d, **kw)
                 for r in range(reps):
                     assert torch.equal(got_ds[r * m:r * m + m - 77], got[r * m:r * m + m - 77])
+    # the transposed stride-2 map (8 offsets, ONE neighbour per output row: the decoder's up-convolutions): rows grouped by offset
+    # (the mask sort of a one-neighbour table) == table order, bit for bit; against the oracle at the same bars
+    coarse, _ = me.stride_map(uniq, 2)
+    up_np = me.transpose_kernel_map(me.kernel_map(uniq, coarse, 2, 1), m)
+    mc = coarse.shape[0]
+    xc = torch.randn(reps * mc, cin, generator=g)
+    w8 = torch.randn(8, cin, cout, generator=g) / np.sqrt(cin)
+    up = dev_i32(up_np, device)
+    ac = xc.to(device)[:, :split].contiguous() if split else xc.to(device)
+    bc = xc.to(device)[:, split:].contiguous() if split else None
+    got8 = ops.spconv_fwd_split3(ac, w8.to(device), up, m, in_b=bc, replicas=reps, relu=True)
+    up_s, order8 = ops.mask_sorted_map(up)
+    assert torch.equal(ops.spconv_fwd_split3(ac, w8.to(device), up_s, m, in_b=bc, replicas=reps, relu=True, row_order=order8), got8)
+    for r in range(reps):
+        want8 = torch.relu(me.conv_forward(xc[r * mc:(r + 1) * mc].double(), w8.double(), up_np))
+        assert torch.allclose(got8[r * m:(r + 1) * m].cpu().double(), want8, rtol=RTOL, atol=ATOL)
     # kernel_size 1 (identity map)
     w1 = torch.randn(1, cin, cout, generator=g) / np.sqrt(cin)
     got1 = ops.spconv_fwd_split3(a, w1.to(device), None, m, in_b=b, replicas=reps)

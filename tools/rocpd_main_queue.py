@@ -52,6 +52,22 @@ def main():
         if q != mainq:
             other[q] += e - s
     print("other queues busy (ms):", {f"q{q}": round(v / 1e6, 2) for q, v in other.items()})
+    # the long gaps of the main queue: between which kernels, and what the other queues ran meanwhile
+    gaps = sorted(((s1 - e0, e0, s1, n0, n1) for (s0, e0, n0, _), (s1, e1, n1, _) in zip(mq, mq[1:]) if s1 - e0 > 100e3), reverse=True)
+    pair = collections.defaultdict(lambda: [0, 0.0])
+    for g, e0, s1, n0, n1 in gaps:
+        a = pair[(short(n0)[:40], short(n1)[:40])]
+        a[0] += 1
+        a[1] += g
+    print("main-queue gaps > 100 us by (kernel before -> kernel after):")
+    for (n0, n1), (c, t) in sorted(pair.items(), key=lambda kv: -kv[1][1])[:8]:
+        print(f"  {t / 1e6:8.3f} ms in {c:4d} gaps | {n0}  ->  {n1}")
+    if gaps:
+        g, e0, s1, n0, n1 = gaps[len(gaps) // 2]
+        print(f"inside a median long gap ({g / 1e3:.0f} us, after {short(n0)[:40]}): kernels of the other queues")
+        for s, e, n, q in rows:
+            if q != mainq and e > e0 and s < s1:
+                print(f"    {(s - e0) / 1e3:8.1f} us  +{(e - s) / 1e3:7.1f}  q{q}  {short(n)[:70]}")
 
 
 if __name__ == "__main__":

@@ -1389,6 +1389,10 @@ def split3_rows(x: torch.Tensor, pieces: int | None = None, d_rows: torch.Tensor
     return out
 
 
+class SplitRangeError(RuntimeError):
+    """A value beyond fp16's range met the two-piece fp16 convolution: the results since the last split_check() are void."""
+
+
 _SPLIT_STATUS = {}
 
 
@@ -1408,7 +1412,7 @@ def split_check() -> None:
         if flags:
             t.zero_()
         if flags & STATUS_F16_RANGE:
-            raise RuntimeError("a feature or weight beyond fp16's range (|x| > 65504, Inf or NaN) reached the two-piece fp16 convolution "
+            raise SplitRangeError("a feature or weight beyond fp16's range (|x| > 65504, Inf or NaN) reached the two-piece fp16 convolution "
                                "(LIDIFF_SPLIT_PIECES=2): results are void -- run with the default three bf16 pieces")
 
 

@@ -571,6 +571,27 @@ class DiffCompletion(nn.Module):
 
     # pipeline:155-169
     def completion_loop(self, x_init, x_t, x_cond, x_uncond, noises=None):
+        """_completion_loop_checked; in the opt-in two-piece fp16 mode (ops.SPLIT_PIECES = 2) a scan during which a value left fp16's
+        range is redone from the same inputs, scheduler state and random draws on the default three bf16 pieces (a warning says
+        so): the mode is never wrong, at worst slower."""
+        from . import ops
+        if not (ops.SPLIT_PIECES == 2 and x_t.F.device.type == "cuda"):
+            return self._completion_loop_checked(x_init, x_t, x_cond, x_uncond, noises)
+        sch = self.dpm_scheduler
+        saved = {k: (list(v) if isinstance(v, list) else v) for k, v in sch.__dict__.items()}
+        rng = torch.cuda.get_rng_state(self.device) if noises is None else None
+        try:
+            return self._completion_loop_checked(x_init, x_t, x_cond, x_uncond, noises)
+        except ops.SplitRangeError as e:
+            import warnings
+            warnings.warn(f"two-piece fp16 scan voided ({e}); redone on three bf16 pieces")
+        sch.__dict__.update({k: (list(v) if isinstance(v, list) else v) for k, v in saved.items()})
+        if rng is not None:
+            torch.cuda.set_rng_state(rng, self.device)
+        with ops.split_pieces(3):
+            return self._completion_loop_checked(x_init, x_t, x_cond, x_uncond, noises)
+
+    def _completion_loop_checked(self, x_init, x_t, x_cond, x_uncond, noises=None):
         """The loop runs host-read-free where it can (read_free above); if the device later reports that an assumption of those
         steps did not hold (a tail map above its pair bound, a condition latent of another size than the step before), the whole
         loop is redone from the same inputs, scheduler state and random draws with exact sizes -- same results as if it had run

@@ -264,3 +264,35 @@ def test_a_voided_read_free_loop_is_redone_with_exact_sizes(device, models, fps_
             x_c = pipe.points_to_tensor(other, role="cond")
     why = pipe.read_free_check()
     assert why is not None and "cond" in why and "exact" in why, why
+
+
+def test_two_piece_fp16_scan_is_redone_on_three_pieces_when_a_value_leaves_its_range(device, models, fps_scan, monkeypatch):
+    """The opt-in two-piece fp16 mode (ops.split_pieces(2)) reports a value beyond fp16's range through a device flag; completion_loop
+    then warns and redoes the scan -- same inputs, scheduler state and draws -- on the default three bf16 pieces (every split-operand
+    launch after the warning runs on three pieces; the result is the default mode's to the bars of the loop tests -- not bit for
+    bit: the redone loop reuses the input fields' maps, so its second step takes exact sizes where a fresh loop takes hints).  The
+    flag is raised by hand here: the networks' activations stay far inside the range.  Without the flag the mode runs to the end
+    and agrees with the default to the same bars."""
+    from lidiff_amd import ops
+    steps = 3
+    scan = torch.from_numpy(np.tile(fps_scan, (10, 1))).double()[None].to(device)
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x0 = (scan.cpu() + torch.randn(scan.shape, generator=g, dtype=torch.float64)).to(device)
+    zs = [torch.randn(scan.shape, generator=g, dtype=torch.float64).to(device) for _ in range(steps)]
+    with ops.split_pieces(3):
+        want = _loop(_pipe(device, models, steps, read_free=True), scan, x0, zs)
+    used = []
+    inner = ops.spconv_fwd_split3
+    monkeypatch.setattr(ops, "spconv_fwd_split3", lambda *a, **k: (used.append(ops.SPLIT_PIECES), inner(*a, **k))[1])
+    with ops.split_pieces(2):
+        fast = _loop(_pipe(device, models, steps, read_free=True), scan, x0, zs)
+        n = len(used)
+        assert n and set(used) == {2}
+        ops.split_status(device).fill_(ops.STATUS_F16_RANGE)
+        with pytest.warns(UserWarning, match="three bf16 pieces"):
+            redone = _loop(_pipe(device, models, steps, read_free=True), scan, x0, zs)
+        assert set(used[n:2 * n]) == {2} and len(used) > 2 * n and set(used[2 * n:]) == {3}       # the attempt on 2 pieces, the redo on 3
+    for name, got in (("redone", redone), ("two_piece", fast)):
+        err = np.abs(got - want).max(axis=1)
+        record_parity(f"{name}_fp16_loop_vs_default_T{steps}", max_err_m=float(err.max()), median_err_m=float(np.median(err)))
+        assert np.median(err) <= 1e-5, (name, np.median(err))

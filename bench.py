@@ -39,11 +39,24 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA ~2.5 PF de
 PEAK_HBM_GBS = 8000.0
 # what the path computes in when ops.SPLIT3 is on (the default): said in full, because it is NOT the plain fp32 MFMA everywhere
 DTYPE_SPLIT3 = ("f32 in / f32 out / f32 accumulate everywhere; kernel_size-3 convolutions on maps of tensor stride >= 4 with C_out % 64 == 0 "
-                "that fill the chip (>= 256 tiles): each fp32 operand cut into 3 bf16 pieces (exact sum), the 6 piece products with i + j <= 2 on "
+                "that fill the chip (>= 256 tiles), and the 1 x 1 shortcut with C_in >= 256 there: each fp32 operand cut into 3 bf16 pieces (exact sum), the 6 piece products with i + j <= 2 on "
                 "v_mfma_f32_16x16x32_bf16, dropped terms < 2^-24 |x w| -- error vs float64 equal to the native fp32 MFMA kernel's "
                 "(tests/test_gpu_kernels.py::test_spconv_split3_is_an_fp32_convolution; the whole GPU parity suite runs in this mode at "
                 "the native kernel's bars); every other kernel: native fp32 (v_mfma_f32_16x16x4_f32 / VALU). LIDIFF_SPLIT3=0: native "
                 "fp32 MFMA everywhere -- that number is `native_fp32` in this line")
+# ... and when the opt-in two-piece fp16 mode is switched on (LIDIFF_SPLIT_PIECES=2): never the default, said in full as well
+DTYPE_F16X2 = ("f32 in / f32 out / f32 accumulate; the split-operand layers (kernel_size-3 convolutions on maps of tensor stride >= 4 that fill "
+               "the chip, the widest 1 x 1 shortcut) with each fp32 operand cut into 2 fp16 pieces (22 bits of the operand; weights pre-scaled "
+               "by a power of two), the 3 products x0 w1, x1 w0, x0 w0 on v_mfma_f32_16x16x32_f16 -- half the matrix work of the default; "
+               "OPT-IN (LIDIFF_SPLIT_PIECES=2 / ops.split_pieces(2)): measured errors against float64 equal the native fp32 MFMA kernel's "
+               "(profiles/r06_f16x2.txt; the whole GPU suite passes under the switch), but the operands are 22-bit, not 24-bit, and fp16's "
+               "range applies to the features (a scan that exceeds 65504 is redone on three bf16 pieces) -- which is why it is not the default")
+
+
+def path_dtype(ops):
+    return "f32" if not ops.SPLIT3 else DTYPE_F16X2 if ops.SPLIT_PIECES == 2 else DTYPE_SPLIT3
+
+
 N_POINTS = 180000
 T_STEPS = 50
 
@@ -503,6 +516,7 @@ def pipeline_main(args, rank, world, device):
     refinement), scans sharded round-robin over the ranks (dist.shard_items: scan i -> rank i mod N), no collective on the data
     path; barrier + synchronize on both sides, MAX over ranks, ONE line from rank 0: scans/s of the whole job and s/scan."""
     from lidiff_amd import dist as ldist
+    from lidiff_amd import ops
     ranks_seen = int(ldist.sum_over_ranks(1.0, device=device))
     pipe = build_pipeline(device)
     total = world * args.scans
@@ -522,7 +536,7 @@ def pipeline_main(args, rank, world, device):
         "metric": "completed scans/sec (FPS + T=50 CFG denoising + refinement) on 180k-pt scans", "value": total / elapsed,
         "unit": "scans/s", "n_gpus": world, "rccl_ranks_seen": ranks_seen, "visible_devices": torch.cuda.device_count(),
         "scans": total, "scans_per_gpu": args.scans, "s_per_scan": elapsed / args.scans, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_SPLIT3 if ops.SPLIT3 else "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": path_dtype(ops), "data": "synthetic",
         "denoising_steps_per_s": total * T_STEPS / elapsed,
         "config": {"workload": "configs[2]: independent 180000-point scans (bundled scan, own noise seed each) sharded one per GPU, "
                                "DiffCompletion.complete_scan = range filter + FPS 18000 + T=50 sde-dpmsolver++ CFG loop (closed) + "
@@ -738,7 +752,7 @@ def main():
         "n_gpus": world, "rccl_ranks_seen": ranks_seen, "visible_devices": torch.cuda.device_count(),
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": DTYPE_SPLIT3 if ops.SPLIT3 else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": path_dtype(ops), "data": "synthetic",
         "config": {"workload": "configs[1]: one 180000-point scan (bundled scan FPS 18000 x10), voxel 0.05 m, "
                                "T=50 sde-dpmsolver++ trajectory, CFG w=6 (2 forwards/step), fp32, "
                                "random-init weights, offsets sigma_t*N(0,I) per step",
@@ -872,11 +886,7 @@ def main():
     if alt16 is not None:
         h_elapsed, hprof = alt16
         out["f16x2"] = {
-            "dtype": "f32 in / f32 out / f32 accumulate; the split-operand layers with each fp32 operand cut into 2 fp16 pieces (22 bits of "
-                     "the operand; weights pre-scaled by a power of two), the 3 products x0 w1, x1 w0, x0 w0 on v_mfma_f32_16x16x32_f16 -- "
-                     "half the matrix work of the default; OPT-IN (LIDIFF_SPLIT_PIECES=2 / ops.split_pieces(2)): measured errors against "
-                     "float64 equal the native fp32 MFMA kernel's (profiles/r06_f16x2.txt), but the operands are 22-bit, not 24-bit, "
-                     "and fp16's range applies to the features (a value beyond 65504 raises) -- which is why it is not the default",
+            "dtype": DTYPE_F16X2,
             "value": args.steps / h_elapsed, "unit": "steps/s", "ms_per_step": 1e3 * h_elapsed / args.steps,
             "note": "the same K steps, same process; informational, never `value`"}
         if hprof is not None:

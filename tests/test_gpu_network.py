@@ -1115,3 +1115,23 @@ def test_bench_n_rank_path_with_two_ranks_sharing_the_gpu(device):
     assert js["n_gpus"] == 2 and js["rccl_ranks_seen"] == 2 and js["steps"] == 3 and js["scaling"] == "weak"
     assert js["value"] > 0 and abs(js["value"] - 2 * 3 / (js["ms_per_step"] * 3e-3)) < 1e-6 * js["value"]
     assert "roofline" in js and "cpu_baseline" not in js and "train" not in js          # N = 1 legs stay at N = 1
+
+
+def test_bench_whole_scan_form_prints_one_line(device):
+    """`python bench.py --pipeline --scans 1` (BASELINE configs[2] / [3]'s unit of work: whole scans through complete_scan) run for
+    real: ONE JSON line with scans/s and the dtype the path computes in (the --dry-run form of tests/test_host.py stops before the
+    line is assembled)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--pipeline", "--scans", "1"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]
+    js = json.loads(lines[0])
+    assert js["unit"] == "scans/s" and js["scans"] == 1 and js["n_gpus"] == 1 and js["value"] > 0
+    from lidiff_amd import ops
+    assert abs(js["value"] * js["s_per_scan"] - 1.0) < 1e-6 and ("3 bf16 pieces" in js["dtype"]) == (ops.SPLIT_PIECES == 3)

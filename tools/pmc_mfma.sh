@@ -13,6 +13,8 @@ CASES=(
  "s8_256_256_k27_split3|--level 3 --cin 256 --cout 256 --kernel split3 --flags 1"
  "s16_256_256_k27_split3|--level 4 --cin 256 --cout 256 --kernel split3 --flags 1"
  "s4_128_128_k27_split3|--level 2 --cin 128 --cout 128 --kernel split3 --flags 1"
+ "s8_256_256_k27_split_f16x2|--level 3 --cin 256 --cout 256 --kernel split3 --pieces 2 --flags 1"
+ "s4_128_128_k27_split_f16x2|--level 2 --cin 128 --cout 128 --kernel split3 --pieces 2 --flags 1"
  "s8_256_256_k27|--level 3 --cin 256 --cout 256"
  "s8_128_128_k27|--level 3 --cin 128 --cout 128"
  "s4_128_128_k27|--level 2 --cin 128 --cout 128"

@@ -21,7 +21,13 @@
 // out-of-range request moves no bytes), so every product lands in a fixed accumulator REGISTER -- no accumulator tile in LDS, no
 // pair lists, no flush.  A stage = (offset, 32 input channels): 3 x 16 KB of rows + 24 KB of W fragments by LDS-DMA,
 // double-buffered (144 KB), one barrier per stage; a wave (2 row groups x 4 column groups) multiplies 128 rows x 32 columns:
-// 8 x 2 blocks x 6 products = 96 MFMAs per stage.  One fp32 sum per output over all offsets, channels and pieces.
+// 8 x 2 blocks x 6 products = 96 MFMAs per stage.  Two levels of fp32 sums (per offset, then over the offsets: as the native kernel).
+// A per-tile, per-offset mask of the 16-row blocks that hold a neighbour skips the others (requests and MFMAs alike); the caller
+// sorts the map's rows by their neighbour sets (lidiff_row_mask_keys) so that such blocks are common.  The kernel executes at 0.9 of
+// a dense hipBLASLt bf16 GEMM on the same chip.
+//
+// NP = 2 (opt-in, never the default): the same kernel on TWO fp16 pieces per operand and three products -- 22-bit operands, half the
+// matrix work, fp16's range (reported through LIDIFF_STATUS_F16_RANGE); see lidiff_amd.h and profiles/r06_f16x2.txt.
 #include "spconv.h"
 
 namespace lidiff {

@@ -157,7 +157,7 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
                                    residual=residual, relu=relu, replicas=x.replicas, **hints)
     elif (conv.kernel_size == 3 and not conv.transposed and order is None and nbr is not None
           and ops.split3_layer(x.tensor_stride, rows_out, x.replicas, x.F.shape[1], 0 if extra is None else extra.shape[1],
-                               conv.out_channels)):
+                               conv.out_channels, m_bound=x.F.shape[0] // x.replicas)):
         # the dense levels: the contraction on the bf16 matrix pipe from three-way split operands (fp32 accuracy, ops.SPLIT3), the
         # map's rows sorted by their neighbour sets (whole 16-row blocks then lack an offset and are skipped; same bits).  The
         # output's own pieces are cut in the epilogue -- the next convolution of the level reads them
@@ -166,7 +166,8 @@ def conv_bn_act(conv, bn, x: ME.SparseTensor, relu: bool, residual=None, extra=N
         f = ops.spconv_fwd_split3(x.F, conv.kernel, nbr, m_out, in_b=extra, scale=scale, shift=shift, residual=residual,
                                   relu=relu, replicas=x.replicas, d_rows=d_rows, want_planes=True, row_order=order)
     elif (conv.kernel_size == 1 and nbr is None and order is None and x.F.shape[1] + (0 if extra is None else extra.shape[1]) >= ops.SPLIT3_K1_MIN_CIN
-          and ops.split3_layer(ts_out, rows_out, x.replicas, x.F.shape[1], 0 if extra is None else extra.shape[1], conv.out_channels)):
+          and ops.split3_layer(ts_out, rows_out, x.replicas, x.F.shape[1], 0 if extra is None else extra.shape[1], conv.out_channels,
+                               m_bound=x.F.shape[0] // x.replicas)):
         # the widest 1 x 1 shortcut of the dense levels (384 -> 256 at stride 8: 423 -> 255 us) as a plain row GEMM on the same kernel; narrower
         # ones (192 -> 128: 154 vs 153 us) and the stride-2 up-convolutions (one neighbour per row, 8-stage tiles: 370 vs 316 us) measured no
         # better there and stay on the row / tile kernels

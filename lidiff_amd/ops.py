@@ -1325,9 +1325,12 @@ SPLIT3_SORTED = os.environ.get("LIDIFF_SPLIT3_SORTED", "1") != "0"
 SPLIT3_PRESORT = False
 
 
-def split3_layer(tensor_stride: int, rows: int, replicas: int, c_in_a: int, c_in_b: int, c_out: int) -> bool:
+def split3_layer(tensor_stride: int, rows: int, replicas: int, c_in_a: int, c_in_b: int, c_out: int, m_bound: int | None = None) -> bool:
     """Does the fused plan run a kernel_size-3 convolution of this shape on the split-operand kernel?  (rows: what the host
-    believes -- exact, or the same level of the role's previous pyramid)"""
+    believes -- exact, or the same level of the role's previous pyramid; m_bound: the rows a replica's matrices are allocated for --
+    the split matrices are addressed through 2 GiB buffer descriptors, a larger one keeps the native kernel)"""
+    if m_bound is not None and m_bound * max(c_in_a, c_in_b) * 2 * SPLIT_PIECES >= (1 << 31):
+        return False
     return (SPLIT3 and tensor_stride >= SPLIT3_MIN_STRIDE and split3_conv_applies(c_in_a, c_in_b, c_out)
             and -(-rows * replicas // 256) * (c_out // (128 if c_out % 128 == 0 else 64)) >= SPLIT3_MIN_TILES)
 

@@ -356,3 +356,17 @@ def test_asm_kernel_isa_never_reads_an_in_flight_register(tmp_path, source):
     chk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_regs.py"), out], capture_output=True,
                          text=True, timeout=120)
     assert chk.returncode == 0 and chk.stdout.startswith("0 suspicious"), chk.stdout[:2000]
+
+
+def test_split_operand_rule_respects_the_descriptor_range():
+    """ops.split3_layer -- which layers of the fused plan take the split-operand kernel: tensor stride >= 4, widths the kernel takes,
+    enough tiles to fill the chip, and split matrices that fit the kernel's 2 GiB buffer descriptors (a batch so large that
+    rows x channels x 2 bytes x pieces passes 2^31 keeps the native kernel instead of failing in the C ABI's argument check)."""
+    from lidiff_amd import ops
+    assert ops.split3_layer(8, 120000, 2, 256, 0, 256, m_bound=180000)
+    assert not ops.split3_layer(2, 120000, 2, 256, 0, 256, m_bound=180000)          # stride 2: low-density levels
+    assert not ops.split3_layer(8, 120000, 2, 256, 0, 96, m_bound=180000)           # C_out % 64
+    assert not ops.split3_layer(8, 20000, 1, 256, 0, 256, m_bound=180000)           # < 256 tiles
+    assert not ops.split3_layer(8, 1300000, 2, 256, 0, 256, m_bound=1400000)        # 1.4 M rows x 256 x 6 B = 2.15 GB > 2^31
+    with ops.split_pieces(2):
+        assert ops.split3_layer(8, 1300000, 2, 256, 0, 256, m_bound=1400000)        # ... 4 B per element: fits
